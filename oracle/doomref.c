@@ -1,0 +1,1347 @@
+/* doomref.c — ORACLE: CPU restatement of the reference renderer.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Follows freewilll/doom-rust-renderer (reference tree /root/reference) function by function; each
+ * function cites the file:line it restates.  Semantics reproduced: release-mode Rust (wrapping
+ * integer arithmetic), Rust `as` casts (float->int truncates, saturates, NaN->0; int->narrower int
+ * wraps), IEEE binary32 with no FMA contraction (build with -ffp-contract=off, never -ffast-math).
+ *
+ * PARITY UNPINNED: the reference has no tests or golden vectors and cannot be built in this
+ * environment; this file is pinned only by KATs derived from the formulas (tests/test_oracle_kat.py).
+ * Nothing under doom-rust-renderer_amd/ may include, link or call this file.
+ */
+#include "doomref.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* errors (the reference panics; we unwind to dr_load / dr_render with a message)              */
+static char g_err[256];
+const char *dr_last_error(void) { return g_err; }
+static int fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Rust `as` casts                                                                             */
+int16_t dr_f32_as_i16(float f) {
+    if (f != f) return 0;
+    if (f <= -32768.0f) return INT16_MIN;
+    if (f >= 32767.0f) return INT16_MAX;
+    return (int16_t)f;
+}
+int32_t dr_f32_as_i32(float f) {
+    if (f != f) return 0;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    return (int32_t)f;
+}
+uint8_t dr_f32_as_u8(float f) {
+    if (!(f > 0.0f)) return 0; /* NaN, negatives, -0 */
+    if (f >= 255.0f) return 255;
+    return (uint8_t)f;
+}
+static size_t f32_as_usize(float f) {
+    if (!(f > 0.0f)) return 0;
+    if (f >= 18446744073709551616.0f) return SIZE_MAX;
+    return (size_t)f;
+}
+#define F2I16 dr_f32_as_i16
+#define F2I32 dr_f32_as_i32
+#define F2U8 dr_f32_as_u8
+static inline int16_t wadd16(int16_t a, int16_t b) { return (int16_t)(uint16_t)((uint16_t)a + (uint16_t)b); }
+static inline int16_t wsub16(int16_t a, int16_t b) { return (int16_t)(uint16_t)((uint16_t)a - (uint16_t)b); }
+static inline int16_t wmul16(int16_t a, int16_t b) { return (int16_t)(uint16_t)((uint32_t)(int32_t)a * (uint32_t)(int32_t)b); }
+static inline int16_t i32_as_i16(int32_t v) { return (int16_t)(uint16_t)(uint32_t)v; }
+static inline int16_t min16(int16_t a, int16_t b) { return a < b ? a : b; }
+static inline int16_t max16(int16_t a, int16_t b) { return a > b ? a : b; }
+/* f32::min / f32::max (NaN-ignoring; operands here are never NaN) */
+static inline float fmin32(float a, float b) { return (a != a) ? b : (b != b) ? a : (a < b ? a : b); }
+static inline float fmax32(float a, float b) { return (a != a) ? b : (b != b) ? a : (a > b ? a : b); }
+
+static const float PI_F = 3.14159265358979323846f; /* std::f32::consts::PI */
+
+/* ------------------------------------------------------------------------------------------ */
+/* geometry: src/map/vertexes.rs:15-67, src/geometry.rs:46-91                                  */
+typedef struct { float x, y; } Vtx;
+typedef struct { Vtx start, end; } Line;
+
+static inline Vtx vsub(Vtx a, Vtx b) { Vtx r = { a.x - b.x, a.y - b.y }; return r; }   /* vertexes.rs:58-67 */
+static inline Vtx vadd(Vtx a, Vtx b) { Vtx r = { a.x + b.x, a.y + b.y }; return r; }   /* vertexes.rs:47-56 */
+/* Vertex::rotate vertexes.rs:20-25 with cos/sin supplied (frame constants) */
+static inline Vtx vrot(Vtx v, float c, float s) {
+    Vtx r;
+    r.x = v.x * c - v.y * s;
+    r.y = v.y * c + v.x * s;
+    return r;
+}
+static inline float vcross(Vtx a, Vtx b) { return a.x * b.y - a.y * b.x; }             /* vertexes.rs:27-29 */
+static inline int is_left_of_line(Vtx v, const Line *l) {                               /* vertexes.rs:32-34 */
+    return vcross(vsub(v, l->start), vsub(l->end, l->start)) <= 0.0f;
+}
+static inline float vdist(Vtx a, Vtx b) {                                               /* vertexes.rs:36-38 */
+    float dx = a.x - b.x, dy = a.y - b.y;
+    return sqrtf(dx * dx + dy * dy);
+}
+static inline float line_length(const Line *l) {                                        /* geometry.rs:84-86 */
+    float dx = l->start.x - l->end.x, dy = l->start.y - l->end.y;
+    return sqrtf(dx * dx + dy * dy);
+}
+/* Line::intersection geometry.rs:56-82; returns 1 = Ok, 0 = Err("parallel") */
+static int line_intersection(const Line *a, const Line *b, Vtx *out) {
+    float x1 = a->start.x, y1 = a->start.y, x2 = a->end.x, y2 = a->end.y;
+    float x3 = b->start.x, y3 = b->start.y, x4 = b->end.x, y4 = b->end.y;
+    float quot = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);
+    if (fabsf(quot) < 0.001f) return 0;
+    float invquot = 1.0f / quot;
+    out->x = invquot * ((x1 * y2 - y1 * x2) * (x3 - x4) - (x1 - x2) * (x3 * y4 - y3 * x4));
+    out->y = invquot * ((x1 * y2 - y1 * x2) * (y3 - y4) - (y1 - y2) * (x3 * y4 - y3 * x4));
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* scene model                                                                                 */
+typedef struct { int w, h; int16_t *px; } Bitmap; /* px[y*w+x], -1 = None  (graphics/bitmap.rs:11-15) */
+typedef struct { char name[9]; Bitmap bm; int16_t left_offset, top_offset; int loaded; } Picture;
+typedef struct { char name[9]; uint8_t px[4096]; } Flat; /* flats.rs:19-22 */
+typedef struct { int16_t ox, oy, pnum; } Patch;
+typedef struct { char name[9]; int16_t w, h; int npatch; Patch *patches; Bitmap bm; int loaded; } TexDef;
+
+typedef struct { int16_t floor_h, ceil_h; char floor_tex[9], ceil_tex[9]; int16_t light, special, tag; } Sector;
+typedef struct { float xoff, yoff; char upper[9], lower[9], middle[9]; int sector; } Sidedef;
+typedef struct { int v1, v2; int16_t flags, special, tag; int front, back; } Linedef;
+typedef struct { int v1, v2; int16_t angle; int linedef; int direction; int16_t offset; } Seg;
+typedef struct { int first, count; } SubSector;
+typedef struct { float x, y, dx, dy; int16_t rchild, lchild; } Node;
+typedef struct { float x, y, angle; int16_t type, flags; } Thing;
+typedef struct { Vtx pos; float angle; char sprite[5]; uint8_t frame; int full_bright, is_null; } MapObject;
+
+typedef struct { char name[5]; uint8_t frame; int rotate; Picture *pics[8]; int valid; } SpriteFrame;
+
+typedef struct { uint32_t offset, size; char name[9]; } DirEntry;
+
+struct dr_scene {
+    uint8_t *file; size_t len;
+    DirEntry *dirs; int ndirs;
+    int first_sprite_lump, last_sprite_lump;
+    char map_name[16];
+    Vtx *vertexes; int nvertexes;
+    Sector *sectors; int nsectors;
+    Sidedef *sidedefs; int nsidedefs;
+    Linedef *linedefs; int nlinedefs;
+    Seg *segs; int nsegs;
+    SubSector *subsectors; int nsubsectors;
+    Node *nodes; int nnodes;
+    Thing *things; int nthings;
+    MapObject *mobjs; int nmobjs;
+    uint8_t palette[768];
+    char (*pnames)[9]; int npnames;
+    TexDef *texdefs; int ntexdefs;
+    Picture **pictures; int npictures, cappictures;  /* cache by lump name */
+    Flat **flats; int nflats, capflats;              /* cache by requested name */
+    SpriteFrame *sframes; int nsframes, capsframes;
+    TexDef *sky_texture;
+};
+
+/* ---- WAD access: src/wad.rs ---- */
+static int16_t rd_i16(const dr_scene *s, size_t off) { return (int16_t)(uint16_t)(s->file[off] | (s->file[off + 1] << 8)); } /* wad.rs:185-187 */
+static float rd_f32_i16(const dr_scene *s, size_t off) { return (float)rd_i16(s, off); }                                       /* wad.rs:189-191 */
+static uint32_t rd_u32(const dr_scene *s, size_t off) {                                                                        /* wad.rs:193-195 */
+    return (uint32_t)s->file[off] | ((uint32_t)s->file[off + 1] << 8) | ((uint32_t)s->file[off + 2] << 16) | ((uint32_t)s->file[off + 3] << 24);
+}
+/* read_lump_name wad.rs:112-126 (no case change) */
+static void rd_name(const dr_scene *s, size_t off, char out[9]) {
+    memcpy(out, s->file + off, 8);
+    out[8] = 0;
+    if (s->file[off + 7] == 0) out[strlen(out)] = 0;
+}
+static void upper_copy(char *dst, const char *src, size_t cap) {
+    size_t i = 0;
+    for (; src[i] && i + 1 < cap; i++) dst[i] = (char)toupper((unsigned char)src[i]);
+    dst[i] = 0;
+}
+/* get_dir_entry wad.rs:166-172: HashMap keyed by upper-cased name; a later lump with the same
+ * name replaced the earlier one at insert time (wad.rs:153-154) => search from the end. */
+static const DirEntry *get_dir_entry(const dr_scene *s, const char *name) {
+    char up[16];
+    upper_copy(up, name, sizeof up);
+    for (int i = s->ndirs - 1; i >= 0; i--)
+        if (strcmp(s->dirs[i].name, up) == 0) return &s->dirs[i];
+    return NULL;
+}
+/* get_dir_entry_for_map_lump wad.rs:175-183: FIRST lump named like the map, + k */
+static const DirEntry *map_lump(const dr_scene *s, int k) {
+    char up[16];
+    upper_copy(up, s->map_name, sizeof up);
+    for (int i = 0; i < s->ndirs; i++)
+        if (strcmp(s->dirs[i].name, up) == 0) return (i + k < s->ndirs) ? &s->dirs[i + k] : NULL;
+    return NULL;
+}
+enum { L_THINGS = 1, L_LINEDEFS, L_SIDEDEFS, L_VERTEXES, L_SEGS, L_SSECTORS, L_NODES, L_SECTORS }; /* wad.rs:8-19 */
+
+static int bitmap_alloc(Bitmap *b, int w, int h) {
+    b->w = w; b->h = h;
+    size_t n = (size_t)(w > 0 ? w : 0) * (size_t)(h > 0 ? h : 0);
+    b->px = (int16_t *)malloc((n ? n : 1) * sizeof(int16_t));
+    if (!b->px) return -1;
+    for (size_t i = 0; i < n; i++) b->px[i] = -1;
+    return 0;
+}
+
+/* Picture::new + read_pixels: graphics/pictures.rs:66-126 */
+static Picture *get_picture(dr_scene *s, const char *name) {
+    char up[16];
+    upper_copy(up, name, sizeof up);
+    for (int i = 0; i < s->npictures; i++)
+        if (strcmp(s->pictures[i]->name, up) == 0) return s->pictures[i];
+    const DirEntry *de = get_dir_entry(s, name);
+    if (!de) { fail("Could not find lump %s", name); return NULL; }
+    size_t off = de->offset;
+    if (off + 8 > s->len) { fail("picture %s out of file", name); return NULL; }
+    Picture *p = (Picture *)calloc(1, sizeof *p);
+    upper_copy(p->name, name, sizeof p->name);
+    int16_t w = rd_i16(s, off), h = rd_i16(s, off + 2);
+    p->left_offset = rd_i16(s, off + 4);
+    p->top_offset = rd_i16(s, off + 6);
+    if (w < 0 || h < 0 || bitmap_alloc(&p->bm, w, h)) { free(p); fail("bad picture %s", name); return NULL; }
+    for (int col = 0; col < w; col++) {                                         /* pictures.rs:101-125 */
+        if (off + (size_t)col * 4 + 12 > s->len) { fail("picture %s column table out of file", name); return NULL; }
+        size_t co = off + rd_u32(s, off + (size_t)col * 4 + 8);
+        for (;;) {
+            if (co + 1 >= s->len) { fail("picture %s post out of file", name); return NULL; }
+            uint8_t yoff = s->file[co];
+            if (yoff == 0xff) break;
+            uint8_t length = s->file[co + 1];
+            for (int row = 0; row < length; row++) {
+                if (co + (size_t)row + 3 >= s->len) { fail("picture %s post data out of file", name); return NULL; }
+                int y = row + yoff;
+                if (y >= h) { fail("picture %s: post row %d >= height %d (reference panics)", name, y, h); return NULL; }
+                p->bm.px[(size_t)y * (size_t)w + (size_t)col] = s->file[co + (size_t)row + 3];
+            }
+            co += (size_t)length + 4;
+        }
+    }
+    p->loaded = 1;
+    if (s->npictures == s->cappictures) {
+        s->cappictures = s->cappictures ? s->cappictures * 2 : 64;
+        s->pictures = (Picture **)realloc(s->pictures, (size_t)s->cappictures * sizeof *s->pictures);
+    }
+    s->pictures[s->npictures++] = p;
+    return p;
+}
+/* Picture::mirror pictures.rs:129-147 */
+static Picture *mirror_picture(const Picture *src) {
+    Picture *p = (Picture *)calloc(1, sizeof *p);
+    *p = *src;
+    bitmap_alloc(&p->bm, src->bm.w, src->bm.h);
+    for (int y = 0; y < src->bm.h; y++)
+        for (int x = 0; x < src->bm.w; x++)
+            p->bm.px[y * src->bm.w + x] = src->bm.px[y * src->bm.w + (src->bm.w - 1 - x)];
+    return p;
+}
+
+/* Textures::new / load_pnames / load_texture_list: graphics/textures.rs:132-151,182-255 */
+static int load_texture_list(dr_scene *s, const DirEntry *de) {
+    size_t base = de->offset;
+    uint32_t count = rd_u32(s, base);
+    for (uint32_t i = 0; i < count; i++) {
+        size_t off = base + rd_u32(s, base + 4 + 4 * (size_t)i);
+        if (off + 22 > s->len) return fail("texture list out of file");
+        s->texdefs = (TexDef *)realloc(s->texdefs, (size_t)(s->ntexdefs + 1) * sizeof *s->texdefs);
+        TexDef *t = &s->texdefs[s->ntexdefs++];
+        memset(t, 0, sizeof *t);
+        char nm[9];
+        rd_name(s, off, nm);
+        upper_copy(t->name, nm, sizeof t->name);
+        t->w = rd_i16(s, off + 12);
+        t->h = rd_i16(s, off + 14);
+        int16_t pc = rd_i16(s, off + 20);
+        t->npatch = pc > 0 ? pc : 0;
+        t->patches = (Patch *)calloc((size_t)t->npatch + 1, sizeof(Patch));
+        for (int j = 0; j < t->npatch; j++) {
+            size_t po = off + 22 + (size_t)j * 10;
+            t->patches[j].ox = rd_i16(s, po);
+            t->patches[j].oy = rd_i16(s, po + 2);
+            t->patches[j].pnum = rd_i16(s, po + 4);
+        }
+    }
+    return 0;
+}
+/* Textures::get + Texture::load: textures.rs:154-179, 74-103.  HashMap insert => last definition wins. */
+static TexDef *get_texture(dr_scene *s, const char *name) {
+    char up[16];
+    upper_copy(up, name, sizeof up);
+    TexDef *t = NULL;
+    for (int i = s->ntexdefs - 1; i >= 0; i--)
+        if (strcmp(s->texdefs[i].name, up) == 0) { t = &s->texdefs[i]; break; }
+    if (!t) { fail("Unknown texture %s", name); return NULL; }
+    if (t->loaded) return t;
+    if (t->w < 0 || t->h < 0 || bitmap_alloc(&t->bm, t->w, t->h)) { fail("bad texture %s", name); return NULL; }
+    for (int j = 0; j < t->npatch; j++) {
+        Patch *pa = &t->patches[j];
+        if (pa->pnum < 0 || pa->pnum >= s->npnames) { fail("texture %s: bad patch number", name); return NULL; }
+        Picture *pic = get_picture(s, s->pnames[pa->pnum]);
+        if (!pic) return NULL;
+        for (int x = 0; x < pic->bm.w; x++)
+            for (int y = 0; y < pic->bm.h; y++) {
+                int16_t v = pic->bm.px[y * pic->bm.w + x];
+                int16_t px = wadd16((int16_t)x, pa->ox), py = wadd16((int16_t)y, pa->oy);
+                if (px >= 0 && px < t->bm.w && py >= 0 && py < t->bm.h) t->bm.px[py * t->bm.w + px] = v; /* incl. None */
+            }
+    }
+    t->loaded = 1;
+    return t;
+}
+
+/* Flats::get + Flat::new: flats.rs:92-100,116-136 (cache keyed by the requested name, verbatim) */
+static Flat *get_flat(dr_scene *s, const char *name) {
+    for (int i = 0; i < s->nflats; i++)
+        if (strcmp(s->flats[i]->name, name) == 0) return s->flats[i];
+    const DirEntry *de = get_dir_entry(s, name);
+    if (!de) { fail("Could not find lump %s", name); return NULL; }
+    if ((size_t)de->offset + 4096 > s->len) { fail("flat %s out of file", name); return NULL; }
+    Flat *f = (Flat *)calloc(1, sizeof *f);
+    strncpy(f->name, name, 8);
+    memcpy(f->px, s->file + de->offset, 4096);
+    if (s->nflats == s->capflats) {
+        s->capflats = s->capflats ? s->capflats * 2 : 32;
+        s->flats = (Flat **)realloc(s->flats, (size_t)s->capflats * sizeof *s->flats);
+    }
+    s->flats[s->nflats++] = f;
+    return f;
+}
+/* Flats::get_animated flats.rs:30-75,103-111 */
+static const char *const ANIM_LISTS[9][5] = {
+    { "NUKAGE1", "NUKAGE2", "NUKAGE3", NULL, NULL },  { "FWATER1", "FWATER2", "FWATER3", "FWATER4", NULL },
+    { "SWATER1", "SWATER2", "SWATER3", "SWATER4", NULL }, { "LAVA1", "LAVA2", "LAVA3", "LAVA4", NULL },
+    { "BLOOD1", "BLOOD2", "BLOOD3", NULL, NULL },     { "RROCK05", "RROCK06", "RROCK07", "RROCK08", NULL },
+    { "SLIME01", "SLIME02", "SLIME03", "SLIME04", NULL }, { "SLIME05", "SLIME06", "SLIME07", "SLIME08", NULL },
+    { "SLIME09", "SLIME10", "SLIME11", "SLIME12", NULL },
+};
+static Flat *get_flat_animated(dr_scene *s, const char *name, float timestamp) {
+    for (int l = 0; l < 9; l++)
+        for (int k = 0; ANIM_LISTS[l][k]; k++)
+            if (strcmp(ANIM_LISTS[l][k], name) == 0) {
+                size_t n = 0;
+                while (ANIM_LISTS[l][n]) n++;
+                size_t cycle = f32_as_usize(timestamp * 3.0f) % n;
+                return get_flat(s, ANIM_LISTS[l][cycle]);
+            }
+    return get_flat(s, name);
+}
+
+/* thing type -> spawn state (sprite, frame, full_bright): map_objects.rs:25-50 + info.rs tables */
+typedef struct { int16_t id; const char *sprite; uint8_t frame; uint8_t full_bright; uint8_t is_null; } SpawnRow;
+static const SpawnRow SPAWN_TABLE[] = {
+#include "../data/mobj_spawn_table.inc"
+};
+
+/* Sprites::new restricted to one (sprite, frame): graphics/sprites.rs:26-97 */
+static SpriteFrame *get_sprite_frame(dr_scene *s, const char *sprite, uint8_t frame) {
+    for (int i = 0; i < s->nsframes; i++)
+        if (s->sframes[i].frame == frame && strcmp(s->sframes[i].name, sprite) == 0) return &s->sframes[i];
+    if (s->nsframes == s->capsframes) {
+        s->capsframes = s->capsframes ? s->capsframes * 2 : 32;
+        s->sframes = (SpriteFrame *)realloc(s->sframes, (size_t)s->capsframes * sizeof *s->sframes);
+    }
+    SpriteFrame *sf = &s->sframes[s->nsframes++];
+    memset(sf, 0, sizeof *sf);
+    strncpy(sf->name, sprite, 4);
+    sf->frame = frame;
+    Picture *rot[256];
+    int have[256];
+    memset(have, 0, sizeof have);
+    for (int idx = s->first_sprite_lump; idx < s->last_sprite_lump; idx++) {     /* sprites.rs:35 */
+        const DirEntry *de = &s->dirs[idx];
+        if (strncmp(de->name, sprite, 4) != 0 || strlen(sprite) != 4) continue;    /* starts_with */
+        size_t nl = strlen(de->name);
+        if (nl < 6) { fail("sprite lump %s too short (reference panics)", de->name); return NULL; }
+        Picture *pic = get_picture(s, de->name);
+        if (!pic) return NULL;
+        uint8_t fr = (uint8_t)(de->name[4] - 65), ro = (uint8_t)(de->name[5] - 48);
+        if (fr == frame) { rot[ro] = pic; have[ro] = 1; }
+        if (nl > 6) {
+            if (nl < 8) { fail("sprite lump %s malformed", de->name); return NULL; }
+            uint8_t fr2 = (uint8_t)(de->name[6] - 65), ro2 = (uint8_t)(de->name[7] - 48);
+            if (fr2 == frame) { rot[ro2] = mirror_picture(pic); have[ro2] = 1; }
+        }
+    }
+    int nkeys = 0;
+    for (int i = 0; i < 256; i++) nkeys += have[i];
+    if (nkeys == 0) return sf; /* frame absent: get_picture would panic "Unknown frame" on use */
+    sf->rotate = nkeys != 1;                                                     /* sprites.rs:65 */
+    if (sf->rotate) {
+        if (nkeys != 8) { fail("Got something other than 8 rotations for %s/%d: %d", sprite, frame, nkeys); return NULL; }
+        for (int r = 1; r < 9; r++) {
+            if (!have[r]) { fail("sprite %s/%d missing rotation %d", sprite, frame, r); return NULL; }
+            sf->pics[r - 1] = rot[r];
+        }
+    } else {
+        if (!have[0]) { fail("sprite %s/%d single rotation is not 0", sprite, frame); return NULL; }
+        sf->pics[0] = rot[0];
+    }
+    sf->valid = 1;
+    return sf;
+}
+
+/* get_sky_texture src/game.rs:199-227 (regex `e(\d+)m(\d+)` then `(\d\d)`, unanchored, case-sensitive) */
+static TexDef *get_sky_texture(dr_scene *s, const char *map_name) {
+    size_t n = strlen(map_name);
+    for (size_t i = 0; i < n; i++) {
+        if (map_name[i] != 'e') continue;
+        size_t j = i + 1;
+        if (j >= n || !isdigit((unsigned char)map_name[j])) continue;
+        /* greedy \d+ with backtracking so that 'm' follows */
+        size_t e = j;
+        while (e < n && isdigit((unsigned char)map_name[e])) e++;
+        for (size_t k = e; k > j; k--) {
+            if (k < n && map_name[k] == 'm' && k + 1 < n && isdigit((unsigned char)map_name[k + 1])) {
+                long episode = strtol(map_name + j, NULL, 10); /* digits j..k (strtol stops at 'm') */
+                char tmp[32];
+                size_t dl = k - j < sizeof tmp - 1 ? k - j : sizeof tmp - 1;
+                memcpy(tmp, map_name + j, dl);
+                tmp[dl] = 0;
+                episode = strtol(tmp, NULL, 10);
+                return get_texture(s, episode == 2 ? "SKY2" : episode == 3 ? "SKY3" : "SKY1");
+            }
+        }
+    }
+    for (size_t i = 0; i + 1 < n; i++)
+        if (isdigit((unsigned char)map_name[i]) && isdigit((unsigned char)map_name[i + 1])) {
+            int map = (map_name[i] - '0') * 10 + (map_name[i + 1] - '0');
+            return get_texture(s, map < 12 ? "SKY1" : map < 21 ? "SKY2" : "SKY3");
+        }
+    return get_texture(s, "SKY1");
+}
+
+void dr_free(dr_scene *s) {
+    if (!s) return;
+    /* test infrastructure: scenes live for the process; release the big blocks only */
+    free(s->file); free(s->dirs); free(s->vertexes); free(s->sectors); free(s->sidedefs); free(s->linedefs);
+    free(s->segs); free(s->subsectors); free(s->nodes); free(s->things); free(s->mobjs); free(s->pnames);
+    for (int i = 0; i < s->ntexdefs; i++) { free(s->texdefs[i].patches); free(s->texdefs[i].bm.px); }
+    free(s->texdefs);
+    for (int i = 0; i < s->npictures; i++) { free(s->pictures[i]->bm.px); free(s->pictures[i]); }
+    free(s->pictures);
+    for (int i = 0; i < s->nflats; i++) free(s->flats[i]);
+    free(s->flats); free(s->sframes);
+    free(s);
+}
+
+dr_scene *dr_load(const uint8_t *wad, size_t len, const char *map_name) {
+    g_err[0] = 0;
+    if (len < 12) { fail("file too short"); return NULL; }
+    dr_scene *s = (dr_scene *)calloc(1, sizeof *s);
+    s->file = (uint8_t *)malloc(len);
+    memcpy(s->file, wad, len);
+    s->len = len;
+    strncpy(s->map_name, map_name, sizeof s->map_name - 1);
+    /* WadFile::new wad.rs:86-109 */
+    if (memcmp(s->file, "IWAD", 4) != 0) { fail("Unhandled WAD file type: %.4s", (const char *)s->file); goto bad; }
+    uint32_t lump_count = rd_u32(s, 4), dir_offset = rd_u32(s, 8);
+    if ((size_t)dir_offset + (size_t)lump_count * 16 > len) { fail("directory out of file"); goto bad; }
+    s->ndirs = (int)lump_count;
+    s->dirs = (DirEntry *)calloc((size_t)lump_count + 1, sizeof(DirEntry));
+    for (uint32_t i = 0; i < lump_count; i++) {                                  /* load_dirs wad.rs:128-157 */
+        size_t eo = (size_t)dir_offset + (size_t)i * 16;
+        s->dirs[i].offset = rd_u32(s, eo);
+        s->dirs[i].size = rd_u32(s, eo + 4);
+        char nm[9];
+        rd_name(s, eo + 8, nm);
+        upper_copy(s->dirs[i].name, nm, sizeof s->dirs[i].name);
+    }
+    {
+        const DirEntry *a = get_dir_entry(s, "S_START"), *b = get_dir_entry(s, "S_END");
+        if (!a || !b) { fail("Could not find lump S_START/S_END"); goto bad; }
+        s->first_sprite_lump = (int)(a - s->dirs);
+        s->last_sprite_lump = (int)(b - s->dirs);
+    }
+    /* Map::new map/mod.rs:48-78 */
+    const DirEntry *de;
+#define NEED(k) do { de = map_lump(s, k); if (!de || (size_t)de->offset + de->size > len) { fail("Could not find lump %d in map %s", k, map_name); goto bad; } } while (0)
+    NEED(L_THINGS);                                                             /* things.rs:25-44 */
+    s->nthings = (int)(de->size / 10);
+    s->things = (Thing *)calloc((size_t)s->nthings + 1, sizeof(Thing));
+    for (int i = 0; i < s->nthings; i++) {
+        size_t o = de->offset + (size_t)i * 10;
+        s->things[i].x = rd_f32_i16(s, o);
+        s->things[i].y = rd_f32_i16(s, o + 2);
+        s->things[i].angle = rd_f32_i16(s, o + 4) * (PI_F / 180.0f);            /* f32::to_radians */
+        s->things[i].type = rd_i16(s, o + 6);
+        s->things[i].flags = rd_i16(s, o + 8);
+    }
+    NEED(L_VERTEXES);                                                           /* vertexes.rs:69-84 */
+    s->nvertexes = (int)(de->size / 4);
+    s->vertexes = (Vtx *)calloc((size_t)s->nvertexes + 1, sizeof(Vtx));
+    for (int i = 0; i < s->nvertexes; i++) {
+        s->vertexes[i].x = rd_f32_i16(s, de->offset + (size_t)i * 4);
+        s->vertexes[i].y = rd_f32_i16(s, de->offset + (size_t)i * 4 + 2);
+    }
+    NEED(L_SECTORS);                                                            /* sectors.rs:20-41 */
+    s->nsectors = (int)(de->size / 26);
+    s->sectors = (Sector *)calloc((size_t)s->nsectors + 1, sizeof(Sector));
+    for (int i = 0; i < s->nsectors; i++) {
+        size_t o = de->offset + (size_t)i * 26;
+        Sector *sc = &s->sectors[i];
+        sc->floor_h = rd_i16(s, o); sc->ceil_h = rd_i16(s, o + 2);
+        rd_name(s, o + 4, sc->floor_tex); rd_name(s, o + 12, sc->ceil_tex);
+        sc->light = rd_i16(s, o + 20); sc->special = rd_i16(s, o + 22); sc->tag = rd_i16(s, o + 24);
+    }
+    NEED(L_SIDEDEFS);                                                           /* sidedefs.rs:24-41 */
+    s->nsidedefs = (int)(de->size / 30);
+    s->sidedefs = (Sidedef *)calloc((size_t)s->nsidedefs + 1, sizeof(Sidedef));
+    for (int i = 0; i < s->nsidedefs; i++) {
+        size_t o = de->offset + (size_t)i * 30;
+        Sidedef *sd = &s->sidedefs[i];
+        sd->xoff = rd_f32_i16(s, o); sd->yoff = rd_f32_i16(s, o + 2);
+        rd_name(s, o + 4, sd->upper); rd_name(s, o + 12, sd->lower); rd_name(s, o + 20, sd->middle);
+        int16_t sec = rd_i16(s, o + 28);
+        if (sec < 0 || sec >= s->nsectors) { fail("sidedef %d: bad sector", i); goto bad; }
+        sd->sector = sec;
+    }
+    NEED(L_LINEDEFS);                                                           /* linedefs.rs:40-72 */
+    s->nlinedefs = (int)(de->size / 14);
+    s->linedefs = (Linedef *)calloc((size_t)s->nlinedefs + 1, sizeof(Linedef));
+    for (int i = 0; i < s->nlinedefs; i++) {
+        size_t o = de->offset + (size_t)i * 14;
+        Linedef *ld = &s->linedefs[i];
+        int16_t v1 = rd_i16(s, o), v2 = rd_i16(s, o + 2), f = rd_i16(s, o + 10), b = rd_i16(s, o + 12);
+        ld->flags = rd_i16(s, o + 4); ld->special = rd_i16(s, o + 6); ld->tag = rd_i16(s, o + 8);
+        if ((uint16_t)v1 >= (unsigned)s->nvertexes || (uint16_t)v2 >= (unsigned)s->nvertexes) { fail("linedef %d: bad vertex", i); goto bad; }
+        if ((f != -1 && (uint16_t)f >= (unsigned)s->nsidedefs) || (b != -1 && (uint16_t)b >= (unsigned)s->nsidedefs)) { fail("linedef %d: bad sidedef", i); goto bad; }
+        ld->v1 = (uint16_t)v1; ld->v2 = (uint16_t)v2;
+        ld->front = f == -1 ? -1 : (int)(uint16_t)f;
+        ld->back = b == -1 ? -1 : (int)(uint16_t)b;
+    }
+    NEED(L_SEGS);                                                               /* map/segs.rs:23-39 */
+    s->nsegs = (int)(de->size / 12);
+    s->segs = (Seg *)calloc((size_t)s->nsegs + 1, sizeof(Seg));
+    for (int i = 0; i < s->nsegs; i++) {
+        size_t o = de->offset + (size_t)i * 12;
+        Seg *sg = &s->segs[i];
+        int16_t v1 = rd_i16(s, o), v2 = rd_i16(s, o + 2), ld = rd_i16(s, o + 6);
+        if ((uint16_t)v1 >= (unsigned)s->nvertexes || (uint16_t)v2 >= (unsigned)s->nvertexes || (uint16_t)ld >= (unsigned)s->nlinedefs) { fail("seg %d: bad index", i); goto bad; }
+        sg->v1 = (uint16_t)v1; sg->v2 = (uint16_t)v2; sg->angle = rd_i16(s, o + 4); sg->linedef = (uint16_t)ld;
+        sg->direction = rd_i16(s, o + 8) != 0; sg->offset = rd_i16(s, o + 10);
+    }
+    NEED(L_SSECTORS);                                                           /* subsectors.rs:11-31 */
+    s->nsubsectors = (int)(de->size / 4);
+    s->subsectors = (SubSector *)calloc((size_t)s->nsubsectors + 1, sizeof(SubSector));
+    for (int i = 0; i < s->nsubsectors; i++) {
+        int16_t cnt = rd_i16(s, de->offset + (size_t)i * 4), first = rd_i16(s, de->offset + (size_t)i * 4 + 2);
+        if (cnt < 0 || first < 0 || first + cnt > s->nsegs) { fail("subsector %d: bad seg range", i); goto bad; }
+        s->subsectors[i].first = first; s->subsectors[i].count = cnt;
+    }
+    NEED(L_NODES);                                                              /* nodes.rs:45-83 */
+    s->nnodes = (int)(de->size / 28);
+    if (s->nnodes < 1) { fail("map has no nodes"); goto bad; }
+    s->nodes = (Node *)calloc((size_t)s->nnodes + 1, sizeof(Node));
+    for (int i = 0; i < s->nnodes; i++) {
+        size_t o = de->offset + (size_t)i * 28;
+        Node *n = &s->nodes[i];
+        n->x = rd_f32_i16(s, o); n->y = rd_f32_i16(s, o + 2); n->dx = rd_f32_i16(s, o + 4); n->dy = rd_f32_i16(s, o + 6);
+        n->rchild = rd_i16(s, o + 24); n->lchild = rd_i16(s, o + 26);
+        for (int c = 0; c < 2; c++) {                                           /* nodes.rs:17-26: children precede parents */
+            int16_t ch = c ? n->lchild : n->rchild;
+            int idx = ch & 0x7fff;
+            if (ch & (int16_t)0x8000) { if (idx >= s->nsubsectors) { fail("node %d: bad subsector child", i); goto bad; } }
+            else if (idx >= i) { fail("node %d: child node %d not yet loaded (reference panics)", i, idx); goto bad; }
+        }
+    }
+#undef NEED
+    /* Palette::new palette.rs:11-28 */
+    de = get_dir_entry(s, "PLAYPAL");
+    if (!de || (size_t)de->offset + 768 > len) { fail("Could not find lump PLAYPAL"); goto bad; }
+    memcpy(s->palette, s->file + de->offset, 768);
+    /* Textures::new textures.rs:132-151 */
+    de = get_dir_entry(s, "PNAMES");
+    if (!de) { fail("Could not find lump PNAMES"); goto bad; }
+    s->npnames = (int)rd_u32(s, de->offset);
+    s->pnames = (char (*)[9])calloc((size_t)s->npnames + 1, 9);
+    for (int i = 0; i < s->npnames; i++) rd_name(s, de->offset + 4 + (size_t)i * 8, s->pnames[i]);
+    de = get_dir_entry(s, "TEXTURE1");
+    if (!de) { fail("Could not find lump TEXTURE1"); goto bad; }
+    if (load_texture_list(s, de)) goto bad;
+    de = get_dir_entry(s, "TEXTURE2");
+    if (de && load_texture_list(s, de)) goto bad;
+    s->sky_texture = get_sky_texture(s, map_name);
+    if (!s->sky_texture) goto bad;
+    /* MapObjects::new map_objects.rs:25-50 */
+    s->mobjs = (MapObject *)calloc((size_t)s->nthings + 1, sizeof(MapObject));
+    for (int i = 0; i < s->nthings; i++) {
+        int16_t ty = s->things[i].type;
+        if ((ty >= 1 && ty <= 4) || ty == 11) continue;
+        const SpawnRow *row = NULL;
+        for (size_t k = 0; k < sizeof SPAWN_TABLE / sizeof SPAWN_TABLE[0]; k++)
+            if (SPAWN_TABLE[k].id == ty) row = &SPAWN_TABLE[k];
+        if (!row) { fail("unknown thing type %d (reference panics on unwrap)", ty); goto bad; }
+        MapObject *mo = &s->mobjs[s->nmobjs++];
+        mo->pos.x = s->things[i].x; mo->pos.y = s->things[i].y; mo->angle = s->things[i].angle;
+        strncpy(mo->sprite, row->sprite, 4);
+        mo->frame = row->frame; mo->full_bright = row->full_bright; mo->is_null = row->is_null;
+    }
+    return s;
+bad:
+    dr_free(s);
+    return NULL;
+}
+
+int dr_player_start(const dr_scene *s, float *x, float *y, float *angle) {    /* game.rs:151-156, things.rs:46-55 */
+    for (int i = 0; i < s->nthings; i++)
+        if (s->things[i].type == 1) { *x = s->things[i].x; *y = s->things[i].y; *angle = s->things[i].angle; return 0; }
+    return fail("Could not find thing of type 1");
+}
+
+/* get_sector_from_vertex renderer/bsp.rs:9-44; returns sector index or -1 */
+static int sector_from_vertex(const dr_scene *s, Vtx v) {
+    int ni = s->nnodes - 1;
+    for (;;) {
+        const Node *n = &s->nodes[ni];
+        Vtx v1 = { n->x, n->y }, d = { n->dx, n->dy };
+        Line l = { v1, vadd(v1, d) };
+        int16_t child = is_left_of_line(v, &l) ? n->lchild : n->rchild;
+        if (child & (int16_t)0x8000) {
+            const SubSector *ss = &s->subsectors[child & 0x7fff];
+            for (int k = 0; k < ss->count; k++) {
+                const Seg *sg = &s->segs[ss->first + k];
+                const Linedef *ld = &s->linedefs[sg->linedef];
+                int sd = sg->direction ? ld->back : ld->front;
+                if (sd >= 0) return s->sidedefs[sd].sector;
+            }
+            return -1;
+        }
+        ni = child & 0x7fff;
+    }
+}
+int dr_floor_height_at(const dr_scene *s, float x, float y, float *h) {
+    Vtx v = { x, y };
+    int sec = sector_from_vertex(s, v);
+    if (sec < 0) return 1;
+    *h = (float)s->sectors[sec].floor_h;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* renderer                                                                                    */
+typedef struct { float ARC, GSW, GCFX, CFX, CFY; } Consts;
+static Consts make_consts(int W, int H) {                                    /* renderer/constants.rs:3-17 */
+    Consts c;
+    c.ARC = 200.0f / 240.0f;
+    c.GSW = (float)W / c.ARC;
+    c.GCFX = c.GSW / 2.0f;
+    c.CFX = (float)W / 2.0f;
+    c.CFY = (float)H / 2.0f;
+    return c;
+}
+void dr_constants(int W, int H, float out5[5]) {
+    Consts c = make_consts(W, H);
+    out5[0] = c.ARC; out5[1] = c.GSW; out5[2] = c.GCFX; out5[3] = c.CFX; out5[4] = c.CFY;
+}
+static const float PLAYER_EYE_HEIGHT = 41.0f;
+
+typedef struct { int32_t x, y; } Pt;
+typedef struct { Pt start, end; } SdlLine;                                   /* sdl_line.rs */
+typedef struct { Line line; float start_offset; } ClippedLine;               /* clipped_line.rs */
+
+enum { ST_SOLID, ST_TWOSIDED, ST_DRAWN, ST_MAPOBJECT };                      /* bitmap_render.rs:11-17 */
+typedef struct { int32_t x, ctop, cbot, bot_y, top_y; } Column;               /* bitmap_render.rs:19-25 */
+typedef struct {                                                             /* bitmap_render.rs:29-45 */
+    int state;
+    const Bitmap *bitmap;
+    int16_t light_level;
+    ClippedLine cl;
+    int32_t start_x, end_x;
+    float bottom_height, top_height;
+    int16_t offset_x, offset_y;
+    int ext_bottom, ext_top, draw_ceiling;
+    Column *cols; int ncols, capcols;
+} BitmapRender;
+typedef struct {                                                             /* visplanes.rs:17-40 */
+    const Flat *flat;
+    int16_t height, light_level, left, right;
+    int16_t *top, *bottom; /* [W] */
+} Visplane;
+
+typedef struct {
+    dr_scene *s;
+    int W, H;
+    Consts k;
+    const dr_view *view;
+    Vtx ppos;
+    int flags;
+    uint8_t *pix;
+    BitmapRender *segs; int nsegs, capsegs;
+    Visplane *visplanes; int nvis, capvis;
+    uint8_t *hor_ocl; int16_t *floor_ocl, *ceil_ocl;                         /* segs.rs:37-39 */
+    int err;
+    int cur_kind; /* 0 = inline wall, 1 = masked two-sided replay, 2 = map object replay (stats only) */
+    dr_stats st;
+} R;
+
+static dr_stats g_stats;
+void dr_last_stats(dr_stats *out) { *out = g_stats; }
+
+/* Pixels::set pixels.rs:22-31 (x,y arrive as `as usize` of i32/i16: negatives become huge) */
+static inline void px_set(R *r, int64_t x, int64_t y, uint8_t cr, uint8_t cg, uint8_t cb) {
+    if (x < 0 || x >= r->W || y < 0 || y > r->H) return;
+    if (y == r->H) { r->err = fail("Pixels::set y == H (reference would index out of bounds)"); return; }
+    uint8_t *p = r->pix + 3 * ((size_t)y * (size_t)r->W + (size_t)x);
+    p[0] = cr; p[1] = cg; p[2] = cb;
+}
+
+/* diminish_color bitmap_render.rs:190-208 */
+void dr_diminish_color(const uint8_t in[3], int16_t light_level, int16_t distance, uint8_t out[3]) {
+    float factor = (float)light_level / 255.0f;
+    const float dimishing_factor = 1.0f / (16.0f * 256.0f);
+    factor -= (float)distance * dimishing_factor;
+    if (factor < 0.0f) factor = 0.0f;
+    out[0] = F2U8((float)in[0] * factor);
+    out[1] = F2U8((float)in[1] * factor);
+    out[2] = F2U8((float)in[2] * factor);
+}
+
+/* render_vertical_bitmap_line bitmap_render.rs:213-276 (debug outline flags are compile-time false) */
+static void render_vertical_bitmap_line(R *r, const Bitmap *bitmap, int16_t light_level, const ClippedLine *cl,
+                                        int32_t start_x, int32_t end_x, float bottom_height, float top_height,
+                                        int16_t offset_x, int16_t offset_y, int32_t x, int32_t clipped_bottom_y,
+                                        int32_t clipped_top_y, int32_t bottom_y, int32_t top_y) {
+    float len = line_length(&cl->line);
+    float ux0 = 0.0f, ux1 = len;
+    float uy0 = 0.0f, uy1 = top_height - bottom_height;
+    float uz0 = cl->line.start.x, uz1 = cl->line.end.x;
+
+    float ax = (float)(x - start_x) / (float)(end_x - start_x);
+    int16_t tx = F2I16(((1.0f - ax) * (ux0 / uz0) + ax * (ux1 / uz1)) / ((1.0f - ax) * (1.0f / uz0) + ax * (1.0f / uz1)));
+    tx = wadd16(tx, wadd16(F2I16(cl->start_offset), offset_x));
+    int16_t bw = (int16_t)bitmap->w, bh = (int16_t)bitmap->h;
+    if (bw == 0 || bh == 0) { r->err = fail("zero-sized bitmap (reference divides by zero)"); return; }
+    if (tx < 0) tx = wadd16(tx, wmul16(bw, wsub16(1, (int16_t)(tx / bw))));
+    tx = (int16_t)(tx % bw);
+
+    int16_t z = F2I16(((1.0f - ax) + ax) / ((1.0f - ax) * (1.0f / uz0) + ax * (1.0f / uz1)));
+
+    for (int32_t y = clipped_top_y; y < clipped_bottom_y + 1; y++) {
+        float ay = (float)(y - top_y) / (float)(bottom_y - top_y);
+        int16_t ty = F2I16((float)bh + (1.0f - ay) * uy0 + ay * uy1);
+        ty = wadd16(ty, offset_y);
+        if (ty < 0) ty = wadd16(ty, wmul16(bh, wsub16(1, (int16_t)(ty / bh))));
+        ty = (int16_t)(ty % bh);
+        if (ty < 0 || tx < 0) { r->err = fail("negative texel index (reference would panic)"); return; }
+        int16_t cv = bitmap->px[(size_t)ty * (size_t)bitmap->w + (size_t)tx];
+        if (cv >= 0) {
+            uint8_t out[3];
+            dr_diminish_color(&r->s->palette[3 * cv], light_level, z, out);
+            px_set(r, x, y, out[0], out[1], out[2]);
+            if (r->cur_kind == 0) r->st.wall_pixels++;
+            else if (r->cur_kind == 1) r->st.masked_pixels++;
+            else r->st.mobj_pixels++;
+        }
+    }
+}
+
+/* BitmapRender::render bitmap_render.rs:101-135 */
+static void bitmap_render_render(R *r, BitmapRender *br) {
+    if (br->state == ST_SOLID || br->state == ST_DRAWN) return;
+    r->cur_kind = br->state == ST_MAPOBJECT ? 2 : 1;
+    if (br->bitmap)
+        for (int i = 0; i < br->ncols && !r->err; i++) {
+            const Column *c = &br->cols[i];
+            render_vertical_bitmap_line(r, br->bitmap, br->light_level, &br->cl, br->start_x, br->end_x, br->bottom_height,
+                                        br->top_height, br->offset_x, br->offset_y, c->x, c->cbot, c->ctop, c->bot_y, c->top_y);
+        }
+    br->state = ST_DRAWN;
+}
+/* BitmapRender::is_behind_vertex bitmap_render.rs:137-165 */
+static int is_behind_vertex(const BitmapRender *br, Vtx v) {
+    float min_x = fmin32(br->cl.line.start.x, br->cl.line.end.x);
+    float max_x = fmax32(br->cl.line.start.x, br->cl.line.end.x);
+    if (min_x > v.x) return 1;
+    if (max_x > v.x && !is_left_of_line(v, &br->cl.line)) return 1;
+    return 0;
+}
+static void add_column(BitmapRender *br, int16_t x, int16_t ctop, int16_t cbot, int16_t bot_y, int16_t top_y) { /* :84-99 */
+    if (br->ncols == br->capcols) {
+        br->capcols = br->capcols ? br->capcols * 2 : 32;
+        br->cols = (Column *)realloc(br->cols, (size_t)br->capcols * sizeof(Column));
+    }
+    Column *c = &br->cols[br->ncols++];
+    c->x = x; c->ctop = ctop; c->cbot = cbot; c->bot_y = bot_y; c->top_y = top_y;
+}
+
+/* clip_to_viewport renderer/misc.rs:13-115; returns 1 = Some */
+static int clip_to_viewport(const Line *line, ClippedLine *out) {
+    Line left = { { 0.0f, 0.0f }, { 1.0f, 1.0f } };
+    Line right = { { 0.0f, 0.0f }, { 1.0f, -1.0f } };
+
+    int start_outside_left = is_left_of_line(line->start, &left);
+    int end_outside_left = is_left_of_line(line->end, &left);
+    int start_outside_right = !is_left_of_line(line->start, &right);
+    int end_outside_right = !is_left_of_line(line->end, &right);
+
+    int start_in_viewport = line->start.x > 0.0f && !start_outside_left && !start_outside_right;
+    int end_in_viewport = line->end.x > 0.0f && !end_outside_left && !end_outside_right;
+
+    if (start_in_viewport && end_in_viewport) {
+        out->line = *line;
+        out->start_offset = 0.0f;
+        return 1;
+    }
+
+    Vtx li, ri;
+    int li_ok = line_intersection(line, &left, &li);
+    int ri_ok = line_intersection(line, &right, &ri);
+    int left_intersected = li_ok ? (li.x >= 0.0f) : 0;
+    int right_intersected = ri_ok ? (ri.x >= 0.0f) : 0;
+
+    if (!start_in_viewport && !end_in_viewport && !left_intersected && !right_intersected) return 0;
+    if (!start_in_viewport && !end_in_viewport && (left_intersected != right_intersected)) return 0;
+    if ((right_intersected && start_outside_right && end_outside_right) || (left_intersected && start_outside_left && end_outside_left)) return 0;
+
+    float start_offset = 0.0f;
+    Vtx start = line->start, end = line->end;
+    if (left_intersected) {
+        if (start_outside_left) {
+            Vtx new_start = li;
+            start_offset = vdist(new_start, start);
+            start = new_start;
+        }
+        if (end_outside_left) end = li;
+    }
+    if (right_intersected) {
+        if (start_outside_right) start = ri;
+        if (end_outside_right) end = ri;
+    }
+    out->line.start = start;
+    out->line.end = end;
+    out->start_offset = start_offset;
+    return 1;
+}
+
+/* perspective_transform + make_sidedef_non_vertical_line renderer/misc.rs:130-161 */
+static SdlLine make_sidedef_non_vertical_line(const R *r, const Line *line, float height) {
+    const Consts *k = &r->k;
+    Vtx ts, te;
+    ts.x = k->GCFX * line->start.y / line->start.x;
+    ts.y = k->GCFX * height / line->start.x;
+    te.x = k->GCFX * line->end.y / line->end.x;
+    te.y = k->GCFX * height / line->end.x;
+    ts.x *= k->ARC;
+    te.x *= k->ARC;
+    SdlLine o;
+    o.start.x = F2I32(k->CFX - ts.x);
+    o.start.y = F2I32(k->CFY - ts.y);
+    o.end.x = F2I32(k->CFX - te.x);
+    o.end.y = F2I32(k->CFY - te.y);
+    if (o.start.x > r->W - 1) o.start.x = r->W - 1;
+    if (o.end.x > r->W - 1) o.end.x = r->W - 1;
+    return o;
+}
+
+/* Visplane::new visplanes.rs:28-40 */
+static void visplane_init(const R *r, Visplane *v, const Flat *flat, int16_t height, int16_t light) {
+    v->flat = flat; v->height = height; v->light_level = light; v->left = -1; v->right = -1;
+    memset(v->top, 0, (size_t)r->W * sizeof(int16_t));
+    memset(v->bottom, 0, (size_t)r->W * sizeof(int16_t));
+}
+/* SidedefVisPlanes sidedef_visplanes.rs:7-83 */
+typedef struct {
+    int16_t light_level; const Flat *floor_flat, *ceiling_flat; int16_t floor_height, ceiling_height;
+    Visplane bottom_visplane, top_visplane; int bottom_used, top_used;
+} SidedefVisPlanes;
+static void push_visplane(R *r, const Visplane *v) {                        /* visplanes.push(clone) */
+    if (r->nvis == r->capvis) {
+        r->capvis = r->capvis ? r->capvis * 2 : 64;
+        r->visplanes = (Visplane *)realloc(r->visplanes, (size_t)r->capvis * sizeof(Visplane));
+    }
+    Visplane *d = &r->visplanes[r->nvis++];
+    *d = *v;
+    d->top = (int16_t *)malloc((size_t)r->W * sizeof(int16_t));
+    d->bottom = (int16_t *)malloc((size_t)r->W * sizeof(int16_t));
+    memcpy(d->top, v->top, (size_t)r->W * sizeof(int16_t));
+    memcpy(d->bottom, v->bottom, (size_t)r->W * sizeof(int16_t));
+}
+static void svp_flush(R *r, SidedefVisPlanes *p) {                           /* sidedef_visplanes.rs:41-57 */
+    if (p->bottom_used) {
+        push_visplane(r, &p->bottom_visplane);
+        visplane_init(r, &p->bottom_visplane, p->floor_flat, p->floor_height, p->light_level);
+        p->bottom_used = 0;
+    }
+    if (p->top_used) {
+        push_visplane(r, &p->top_visplane);
+        visplane_init(r, &p->top_visplane, p->ceiling_flat, p->ceiling_height, p->light_level);
+        p->top_used = 0;
+    }
+}
+static void svp_add_bottom_point(SidedefVisPlanes *p, int16_t x, int16_t top_y, int16_t bottom_y) { /* :60-70 */
+    if (!p->bottom_used) p->bottom_visplane.left = x;
+    p->bottom_visplane.right = x;
+    p->bottom_used = 1;
+    p->bottom_visplane.top[x] = top_y;
+    p->bottom_visplane.bottom[x] = bottom_y;
+}
+static void svp_add_top_point(SidedefVisPlanes *p, int16_t x, int16_t top_y, int16_t bottom_y) {    /* :73-83 */
+    if (!p->top_used) p->top_visplane.left = x;
+    p->top_visplane.right = x;
+    p->top_used = 1;
+    p->top_visplane.top[x] = top_y;
+    p->top_visplane.bottom[x] = bottom_y;
+}
+
+typedef struct {                                                             /* segs.rs:42-51 */
+    const ClippedLine *clipped_line; const Sidedef *sidedef; int16_t offset_x, floor_height, ceiling_height;
+    const Flat *floor_flat, *ceiling_flat; int16_t light_level;
+} SideDefDetails;
+typedef struct { int only_occlusions, is_lower_wall, is_upper_wall, draw_ceiling, is_two_sided_middle_wall; } Flags; /* segs.rs:53-59 */
+
+static void occlude_vertical_line(R *r, int16_t x) {                         /* segs.rs:113-117 */
+    r->hor_ocl[x] = 1;
+    r->floor_ocl[x] = (int16_t)((int16_t)r->H / 2);
+    r->ceil_ocl[x] = (int16_t)((int16_t)r->H / 2);
+}
+
+/* Segs::process_sidedef segs.rs:121-350 */
+static void process_sidedef(R *r, const SideDefDetails *sds, float bottom_height, float top_height, int32_t offset_y,
+                            const char *texture_name, Flags flags) {
+    const int W = r->W, H = r->H;
+    SdlLine bottom = make_sidedef_non_vertical_line(r, &sds->clipped_line->line, bottom_height);
+    SdlLine top = make_sidedef_non_vertical_line(r, &sds->clipped_line->line, top_height);
+
+    const TexDef *texture = NULL;
+    if (strcmp(texture_name, "-") != 0) {
+        texture = get_texture(r->s, texture_name);
+        if (!texture) { r->err = -1; return; }
+    }
+    if (bottom.start.x != top.start.x || bottom.end.x != top.end.x) {        /* :140-145 */
+        r->err = fail("Wall start not vertical: %d vs %d or %d vs %d", bottom.start.x, top.start.x, bottom.end.x, top.end.x);
+        return;
+    }
+    if (i32_as_i16(bottom.start.x) == i32_as_i16(bottom.end.x) || i32_as_i16(top.start.x) == i32_as_i16(top.end.x)) return; /* :149 */
+    if (bottom.start.x < 0 || bottom.start.x >= W || bottom.end.x < 0 || bottom.end.x >= W || top.start.x < 0 ||
+        top.start.x >= W || top.end.x < 0 || top.end.x >= W) {               /* :103-111,153-154 */
+        r->err = fail("Invalid line x: %d..%d", bottom.start.x, bottom.end.x);
+        return;
+    }
+    float bottom_delta = ((float)bottom.start.y - (float)bottom.end.y) / ((float)bottom.start.x - (float)bottom.end.x);
+    float top_delta = ((float)top.start.y - (float)top.end.y) / ((float)top.start.x - (float)top.end.x);
+
+    SidedefVisPlanes svp;                                                    /* :163-169 */
+    svp.light_level = sds->light_level; svp.floor_flat = sds->floor_flat; svp.ceiling_flat = sds->ceiling_flat;
+    svp.floor_height = sds->floor_height; svp.ceiling_height = sds->ceiling_height;
+    svp.bottom_visplane.top = (int16_t *)malloc((size_t)W * 2); svp.bottom_visplane.bottom = (int16_t *)malloc((size_t)W * 2);
+    svp.top_visplane.top = (int16_t *)malloc((size_t)W * 2); svp.top_visplane.bottom = (int16_t *)malloc((size_t)W * 2);
+    visplane_init(r, &svp.bottom_visplane, sds->floor_flat, sds->floor_height, sds->light_level);
+    visplane_init(r, &svp.top_visplane, sds->ceiling_flat, sds->ceiling_height, sds->light_level);
+    svp.bottom_used = 0; svp.top_used = 0;
+
+    int is_full_height_wall = !flags.is_lower_wall && !flags.is_upper_wall && !flags.only_occlusions;
+    int16_t off_x = wadd16(F2I16(sds->sidedef->xoff), sds->offset_x);
+    int16_t off_y = wadd16(F2I16(sds->sidedef->yoff), i32_as_i16(offset_y));
+
+    BitmapRender br;                                                         /* :185-200 */
+    memset(&br, 0, sizeof br);
+    br.state = flags.is_two_sided_middle_wall ? ST_TWOSIDED : ST_SOLID;
+    br.bitmap = texture ? &texture->bm : NULL;
+    br.light_level = sds->light_level;
+    br.cl = *sds->clipped_line;
+    br.start_x = bottom.start.x; br.end_x = bottom.end.x;
+    br.bottom_height = bottom_height; br.top_height = top_height;
+    br.offset_x = off_x; br.offset_y = off_y;
+    br.ext_bottom = flags.is_lower_wall || (!flags.is_two_sided_middle_wall && is_full_height_wall);
+    br.ext_top = flags.is_upper_wall || (!flags.is_two_sided_middle_wall && is_full_height_wall);
+    br.draw_ceiling = flags.draw_ceiling;
+
+    int16_t x_end = wadd16(i32_as_i16(bottom.end.x), 1);
+    for (int16_t x = i32_as_i16(bottom.start.x); x < x_end && !r->err; x++) {
+        if (!r->hor_ocl[x]) {
+            int16_t bottom_y = F2I16((float)bottom.start.y + ((float)x - (float)bottom.start.x) * bottom_delta);
+            int16_t top_y = F2I16((float)top.start.y + ((float)x - (float)top.start.x) * top_delta);
+
+            int16_t floor_ver_ocl = r->floor_ocl[x];
+            int16_t ceiling_ver_ocl = r->ceil_ocl[x];
+
+            int16_t clipped_bottom_y = min16(floor_ver_ocl, bottom_y);
+            int16_t clipped_top_y = max16(ceiling_ver_ocl, top_y);
+            clipped_bottom_y = min16((int16_t)(H - 1), clipped_bottom_y);
+            clipped_top_y = max16(0, clipped_top_y);
+
+            int in_ver_clipped_area = clipped_bottom_y >= clipped_top_y;
+
+            if (in_ver_clipped_area) {
+                if (!flags.is_two_sided_middle_wall && !flags.only_occlusions) {
+                    if (texture)
+                        render_vertical_bitmap_line(r, &texture->bm, sds->light_level, sds->clipped_line, bottom.start.x,
+                                                    bottom.end.x, bottom_height, top_height, off_x, off_y, x, clipped_bottom_y,
+                                                    clipped_top_y, bottom_y, top_y);
+                }
+                add_column(&br, x, clipped_top_y, clipped_bottom_y, bottom_y, top_y);
+            }
+
+            if (!flags.is_two_sided_middle_wall && in_ver_clipped_area && (is_full_height_wall || flags.only_occlusions)) {
+                int visplane_added = 0;
+                if (clipped_bottom_y < floor_ver_ocl && clipped_bottom_y != (int16_t)(H - 1)) {
+                    svp_add_bottom_point(&svp, x, clipped_bottom_y, floor_ver_ocl);
+                    visplane_added = 1;
+                }
+                if (!flags.is_two_sided_middle_wall && flags.draw_ceiling && clipped_top_y > ceiling_ver_ocl && clipped_top_y != -1) {
+                    if (flags.draw_ceiling) svp_add_top_point(&svp, x, ceiling_ver_ocl, clipped_top_y);
+                    visplane_added = 1;
+                }
+                if (!visplane_added) svp_flush(r, &svp);
+            } else if (!flags.is_two_sided_middle_wall && !in_ver_clipped_area && (is_full_height_wall || flags.only_occlusions) &&
+                       floor_ver_ocl > ceiling_ver_ocl) {
+                if (bottom_y <= ceiling_ver_ocl) {
+                    svp_add_bottom_point(&svp, x, ceiling_ver_ocl, floor_ver_ocl);
+                    occlude_vertical_line(r, x);
+                }
+                if (flags.draw_ceiling && top_y >= floor_ver_ocl) {
+                    if (flags.draw_ceiling) svp_add_top_point(&svp, x, ceiling_ver_ocl, floor_ver_ocl);
+                    occlude_vertical_line(r, x);
+                }
+            }
+
+            if (!flags.is_two_sided_middle_wall && in_ver_clipped_area && flags.only_occlusions) {
+                r->floor_ocl[x] = clipped_bottom_y;
+                if (flags.draw_ceiling) r->ceil_ocl[x] = clipped_top_y;
+            }
+            if (!flags.is_two_sided_middle_wall && in_ver_clipped_area && flags.is_lower_wall) r->floor_ocl[x] = clipped_top_y;
+            if (!flags.is_two_sided_middle_wall && in_ver_clipped_area && flags.is_upper_wall) r->ceil_ocl[x] = clipped_bottom_y;
+        } else {
+            svp_flush(r, &svp);
+        }
+        if (!flags.is_two_sided_middle_wall && is_full_height_wall) occlude_vertical_line(r, x);
+    }
+    svp_flush(r, &svp);
+    free(svp.bottom_visplane.top); free(svp.bottom_visplane.bottom); free(svp.top_visplane.top); free(svp.top_visplane.bottom);
+
+    if (r->nsegs == r->capsegs) {                                            /* :349 */
+        r->capsegs = r->capsegs ? r->capsegs * 2 : 128;
+        r->segs = (BitmapRender *)realloc(r->segs, (size_t)r->capsegs * sizeof(BitmapRender));
+    }
+    r->segs[r->nsegs++] = br;
+}
+
+static int contains_sky(const char *s) { return strstr(s, "SKY") != NULL; }
+
+/* Segs::process_seg segs.rs:353-590 */
+static void process_seg(R *r, const Seg *seg) {
+    dr_scene *s = r->s;
+    const Linedef *linedef = &s->linedefs[seg->linedef];
+    int fsd = seg->direction ? linedef->back : linedef->front;
+    int bsd = seg->direction ? linedef->front : linedef->back;
+    if (fsd < 0) return;
+    const Sidedef *front_sidedef = &s->sidedefs[fsd];
+    const Sidedef *back_sidedef = bsd >= 0 ? &s->sidedefs[bsd] : NULL;
+    const Sector *front_sector = &s->sectors[front_sidedef->sector];
+
+    float floor_height = (float)front_sector->floor_h;
+    float ceiling_height = (float)front_sector->ceil_h;
+
+    int has_pb = 0, has_pt = 0;
+    float portal_bottom_height = 0.0f, portal_top_height = 0.0f;
+    if (back_sidedef) {
+        const Sector *back_sector = &s->sectors[back_sidedef->sector];
+        if (back_sector->floor_h > front_sector->floor_h) { has_pb = 1; portal_bottom_height = (float)back_sector->floor_h; }
+        if (back_sector->ceil_h < front_sector->ceil_h) { has_pt = 1; portal_top_height = (float)back_sector->ceil_h; }
+    }
+    int is_two_sided = (linedef->flags & 4) != 0;
+    int top_is_unpegged = (linedef->flags & 8) != 0;
+    int bottom_is_unpegged = (linedef->flags & 16) != 0;
+
+    Vtx moved_start = vsub(s->vertexes[seg->v1], r->ppos);
+    Vtx moved_end = vsub(s->vertexes[seg->v2], r->ppos);
+    Line line;
+    line.start = vrot(moved_start, r->view->cos_na, r->view->sin_na);
+    line.end = vrot(moved_end, r->view->cos_na, r->view->sin_na);
+
+    ClippedLine clipped_line;
+    if (!clip_to_viewport(&line, &clipped_line)) return;
+    if (clipped_line.line.start.x < -0.01f) { r->err = fail("Clipped line x < -0.01: %g", (double)clipped_line.line.start.x); return; }
+
+    float player_height = r->view->floor_height + PLAYER_EYE_HEIGHT;
+    SdlLine floor = make_sidedef_non_vertical_line(r, &clipped_line.line, floor_height - player_height);
+    if (floor.start.x > floor.end.x) return;
+
+    const Flat *floor_flat = get_flat_animated(s, front_sector->floor_tex, r->view->timestamp);
+    const Flat *ceiling_flat = get_flat_animated(s, front_sector->ceil_tex, r->view->timestamp);
+    if (!floor_flat || !ceiling_flat) { r->err = -1; return; }
+
+    int draw_ceiling = 1;
+    if (back_sidedef) {                                                      /* sky hack :463-477 */
+        const Sector *back_sector = &s->sectors[back_sidedef->sector];
+        if (contains_sky(front_sector->ceil_tex) && contains_sky(back_sector->ceil_tex)) {
+            float back_ceiling = (float)back_sector->ceil_h;
+            has_pt = 0;
+            ceiling_height = fmin32(back_ceiling, ceiling_height);
+            draw_ceiling = 0;
+        }
+    }
+
+    SideDefDetails sds;
+    sds.clipped_line = &clipped_line; sds.sidedef = front_sidedef; sds.offset_x = seg->offset;
+    sds.floor_height = front_sector->floor_h; sds.ceiling_height = front_sector->ceil_h;
+    sds.floor_flat = floor_flat; sds.ceiling_flat = ceiling_flat; sds.light_level = front_sector->light;
+
+    if (!is_two_sided) {
+        int32_t offset_y = bottom_is_unpegged ? F2I32(floor_height - ceiling_height) : 0;
+        Flags f = { 0, 0, 0, draw_ceiling, 0 };
+        process_sidedef(r, &sds, floor_height - player_height, ceiling_height - player_height, offset_y, front_sidedef->middle, f);
+    } else {
+        Flags f1 = { 1, 0, 0, draw_ceiling, 0 };
+        process_sidedef(r, &sds, floor_height - player_height, ceiling_height - player_height, 0, front_sidedef->middle, f1);
+        if (r->err) return;
+        float mid_floor = floor_height, mid_ceiling = ceiling_height;
+        if (has_pb) mid_floor = portal_bottom_height;
+        if (has_pt) mid_ceiling = portal_top_height;
+        Flags f2 = { 0, 0, 0, draw_ceiling, 1 };
+        process_sidedef(r, &sds, mid_floor - player_height, mid_ceiling - player_height, 0, front_sidedef->middle, f2);
+        if (r->err) return;
+        if (has_pb) {
+            int32_t offset_y = bottom_is_unpegged ? F2I32(ceiling_height - portal_bottom_height) : 0;
+            Flags f3 = { 0, 1, 0, draw_ceiling, 0 };
+            process_sidedef(r, &sds, floor_height - player_height, portal_bottom_height - player_height, offset_y, front_sidedef->lower, f3);
+            if (r->err) return;
+        }
+        if (has_pt) {
+            int32_t offset_y = top_is_unpegged ? 0 : F2I32(portal_top_height - ceiling_height);
+            Flags f4 = { 0, 0, 1, draw_ceiling, 0 };
+            process_sidedef(r, &sds, portal_top_height - player_height, ceiling_height - player_height, offset_y, front_sidedef->upper, f4);
+        }
+    }
+}
+
+/* Renderer::render_node / process_subsector renderer/mod.rs:61-104 */
+static void process_child(R *r, int16_t child);
+static void render_node(R *r, int ni) {
+    const Node *n = &r->s->nodes[ni];
+    Vtx v1 = { n->x, n->y }, d = { n->dx, n->dy };
+    Line l = { v1, vadd(v1, d) };
+    int is_left = is_left_of_line(r->ppos, &l);
+    int16_t front = is_left ? n->lchild : n->rchild;
+    int16_t back = is_left ? n->rchild : n->lchild;
+    process_child(r, front);
+    if (r->err) return;
+    process_child(r, back);
+}
+static void process_child(R *r, int16_t child) {
+    if (child & (int16_t)0x8000) {
+        const SubSector *ss = &r->s->subsectors[child & 0x7fff];
+        for (int k = 0; k < ss->count && !r->err; k++) process_seg(r, &r->s->segs[ss->first + k]);
+    } else {
+        render_node(r, child & 0x7fff);
+    }
+}
+
+/* draw_sky visplanes.rs:42-80 */
+static void draw_sky(R *r, const Visplane *vp) {
+    const int16_t SKY_W = 256, SKY_H = 128;
+    const Bitmap *sky = &r->s->sky_texture->bm;
+    int16_t tx_offset = wadd16(F2I16((float)(-SKY_W) * r->view->angle / (PI_F / 2.0f)), SKY_W);
+    if (tx_offset < 0) tx_offset = wadd16(tx_offset, wmul16(SKY_W, wsub16(1, (int16_t)(tx_offset / SKY_W))));
+    int16_t x_end = wadd16(vp->right, 1);
+    for (int16_t x = vp->left; x < x_end && !r->err; x++) {
+        if (x < 0 || x >= r->W) { r->err = fail("visplane x out of range"); return; }
+        int16_t top = max16(vp->top[x], 0);
+        int16_t bottom = min16(vp->bottom[x], (int16_t)(r->H - 1));
+        for (int16_t y = top; y < (int16_t)(bottom + 1); y++) {
+            int16_t tx = F2I16((float)x * (float)SKY_W / (float)r->W);
+            tx = (int16_t)(wadd16(tx, tx_offset) % SKY_W);
+            int16_t ty = F2I16((float)y * (float)SKY_H * 2.0f / (float)r->H);
+            if (ty < 0) ty = wadd16(ty, SKY_H);
+            ty = (int16_t)(ty % SKY_H);
+            if (tx < 0 || ty < 0 || tx >= sky->w || ty >= sky->h) { r->err = fail("sky texel (%d,%d) outside %dx%d texture (reference panics)", tx, ty, sky->w, sky->h); return; }
+            int16_t cv = sky->px[(size_t)ty * (size_t)sky->w + (size_t)tx];
+            if (cv >= 0) {
+                const uint8_t *c = &r->s->palette[3 * cv];
+                px_set(r, x, y, c[0], c[1], c[2]);
+                r->st.sky_pixels++;
+            }
+        }
+    }
+}
+/* draw_visplane visplanes.rs:82-152 */
+static void draw_visplane(R *r, const Visplane *vp) {
+    if (contains_sky(vp->flat->name)) { draw_sky(r, vp); return; }
+    const Consts *k = &r->k;
+    int16_t x_end = wadd16(vp->right, 1);
+    for (int16_t x = vp->left; x < x_end; x++) {
+        if (x < 0 || x >= r->W) { r->err = fail("visplane x out of range"); return; }
+        int16_t top = max16(vp->top[x], 0);
+        int16_t bottom = min16(vp->bottom[x], (int16_t)(r->H - 1));
+        if ((int16_t)(bottom - top) <= 1) continue;
+        for (int16_t y = top; y < (int16_t)(bottom + 1); y++) {
+            float vx = (k->CFX - (float)x) / k->ARC;
+            float vy = k->CFY - (float)y;
+            float wz = (float)vp->height - r->view->floor_height - PLAYER_EYE_HEIGHT;
+            float wx = k->GCFX * wz / vy;
+            float wy = wz * vx / vy;
+            float c, sn;
+            if (r->flags & 1) { c = cosf(r->view->angle); sn = sinf(r->view->angle); } /* vertexes.rs:20-25 literal */
+            else { c = r->view->cos_a; sn = r->view->sin_a; }
+            float rx = wx * c - wy * sn;
+            float ry = wy * c + wx * sn;
+            int16_t tx = wadd16(F2I16(rx), F2I16(r->ppos.x));
+            int16_t ty = wadd16(F2I16(ry), F2I16(r->ppos.y));
+            tx &= 63; ty &= 63;
+            uint8_t out[3];
+            dr_diminish_color(&r->s->palette[3 * vp->flat->px[ty * 64 + tx]], vp->light_level, F2I16(wx), out);
+            px_set(r, x, y, out[0], out[1], out[2]);
+            r->st.flat_pixels++;
+        }
+    }
+}
+
+/* draw_map_objects renderer/map_objects.rs:19-241 */
+static void draw_map_objects(R *r) {
+    dr_scene *s = r->s;
+    const int W = r->W, H = r->H;
+    BitmapRender *mo = (BitmapRender *)calloc((size_t)s->nmobjs + 1, sizeof(BitmapRender));
+    int nmo = 0;
+    int16_t *top_seg_clip = (int16_t *)malloc((size_t)W * 2), *bottom_seg_clip = (int16_t *)malloc((size_t)W * 2);
+
+    for (int i = 0; i < s->nmobjs && !r->err; i++) {
+        const MapObject *m = &s->mobjs[i];
+        if (m->is_null) continue;
+
+        float angle = r->view->angle - m->angle - PI_F;                      /* :55-67 */
+        angle += PI_F / 16.0f;
+        angle = fmodf(angle, 2.0f * PI_F);
+        if (angle < 0.0f) angle += 2.0f * PI_F;
+        angle = fmodf(angle, 2.0f * PI_F);
+        uint8_t rotation = F2U8(angle * 8.0f / (2.0f * PI_F));
+
+        SpriteFrame *sf = get_sprite_frame(s, m->sprite, m->frame);          /* sprites.rs:99-117 */
+        if (!sf) { r->err = -1; break; }
+        if (!sf->valid) { r->err = fail("Unknown frame %d for %s", m->frame, m->sprite); break; }
+        if (rotation > 7) { r->err = fail("Invalid rotation %d", rotation); break; }
+        const Picture *picture = sf->rotate ? sf->pics[rotation] : sf->pics[0];
+
+        Vtx moved = vsub(m->pos, r->ppos);
+        Vtx vpv = vrot(moved, r->view->cos_na, r->view->sin_na);
+        int16_t width = (int16_t)picture->bm.w;
+        Vtx o1 = { 0.0f, (float)(int16_t)(-width) / 2.0f }, o2 = { 0.0f, (float)width / 2.0f };
+        Line line = { vsub(vpv, o1), vsub(vpv, o2) };
+
+        ClippedLine cl;
+        if (!clip_to_viewport(&line, &cl)) continue;
+        if (cl.line.start.x < -0.01f) { r->err = fail("Clipped line x < -0.01 (map object)"); break; }
+
+        int sec = sector_from_vertex(s, m->pos);
+        if (sec < 0) continue;
+        int16_t light_level = m->full_bright ? 255 : s->sectors[sec].light;
+
+        float player_height = r->view->floor_height + PLAYER_EYE_HEIGHT;
+        int16_t z = s->sectors[sec].floor_h;
+        int16_t bh = (int16_t)picture->bm.h;
+        float bottom_height = (float)z - player_height;
+        float top_height = (float)z + (float)bh - 1.0f - player_height;
+        bottom_height += (float)picture->top_offset - (float)bh;
+        top_height += (float)picture->top_offset - (float)bh;
+
+        SdlLine bottom = make_sidedef_non_vertical_line(r, &cl.line, bottom_height);
+        SdlLine top = make_sidedef_non_vertical_line(r, &cl.line, top_height);
+
+        for (int x = 0; x < W; x++) { top_seg_clip[x] = -1; bottom_seg_clip[x] = (int16_t)H; }
+        for (int k = 0; k < r->nsegs; k++) {                                 /* :135-166 */
+            const BitmapRender *seg = &r->segs[k];
+            if (is_behind_vertex(seg, vpv)) continue;
+            for (int c = 0; c < seg->ncols; c++) {
+                const Column *col = &seg->cols[c];
+                int x = col->x;
+                if (seg->state == ST_SOLID) {
+                    if (seg->ext_bottom) bottom_seg_clip[x] = min16(bottom_seg_clip[x], (int16_t)col->ctop);
+                    if (seg->ext_top) top_seg_clip[x] = max16(top_seg_clip[x], (int16_t)col->cbot);
+                } else if (seg->state == ST_TWOSIDED) {
+                    if (seg->draw_ceiling) top_seg_clip[x] = max16(top_seg_clip[x], (int16_t)col->top_y);
+                    bottom_seg_clip[x] = min16(bottom_seg_clip[x], (int16_t)col->bot_y);
+                }
+            }
+        }
+
+        BitmapRender *br = &mo[nmo];
+        memset(br, 0, sizeof *br);
+        br->state = ST_MAPOBJECT; br->bitmap = &picture->bm; br->light_level = light_level; br->cl = cl;
+        br->start_x = bottom.start.x; br->end_x = bottom.end.x; br->bottom_height = bottom_height; br->top_height = top_height;
+
+        float bottom_delta = ((float)bottom.start.y - (float)bottom.end.y) / ((float)bottom.start.x - (float)bottom.end.x);
+        float top_delta = ((float)top.start.y - (float)top.end.y) / ((float)top.start.x - (float)top.end.x);
+        for (int16_t x = i32_as_i16(bottom.start.x); x < i32_as_i16(bottom.end.x); x++) {
+            if (x < 0 || x >= W) { r->err = fail("map object column out of range (reference panics)"); break; }
+            int16_t bottom_y = F2I16((float)bottom.start.y + ((float)x - (float)bottom.start.x) * bottom_delta);
+            int16_t top_y = F2I16((float)top.start.y + ((float)x - (float)top.start.x) * top_delta);
+            int16_t clipped_top_y = max16(top_y, top_seg_clip[x]);
+            int16_t clipped_bottom_y = min16(bottom_y, bottom_seg_clip[x]);
+            clipped_top_y = max16(0, clipped_top_y);
+            clipped_bottom_y = min16((int16_t)(H - 1), clipped_bottom_y);
+            add_column(br, x, clipped_top_y, clipped_bottom_y, bottom_y, top_y);
+        }
+        nmo++;
+    }
+    free(top_seg_clip); free(bottom_seg_clip);
+
+    /* sort() (stable, key = line.start.x as i16, bitmap_render.rs:168-174) then reverse()  :216-217 */
+    for (int i = 1; i < nmo; i++) {
+        BitmapRender t = mo[i];
+        int16_t kt = F2I16(t.cl.line.start.x);
+        int j = i - 1;
+        while (j >= 0 && F2I16(mo[j].cl.line.start.x) > kt) { mo[j + 1] = mo[j]; j--; }
+        mo[j + 1] = t;
+    }
+    for (int i = 0, j = nmo - 1; i < j; i++, j--) { BitmapRender t = mo[i]; mo[i] = mo[j]; mo[j] = t; }
+
+    for (int i = 0; i < nmo && !r->err; i++) {                                /* :220-240 */
+        BitmapRender *m = &mo[i];
+        Vtx v;
+        v.x = (m->cl.line.start.x + m->cl.line.end.x) / 2.0f;
+        v.y = (m->cl.line.start.y + m->cl.line.end.y) / 2.0f;
+        for (int k = 0; k < r->nsegs && !r->err; k++)
+            if (is_behind_vertex(&r->segs[k], v)) bitmap_render_render(r, &r->segs[k]);
+        bitmap_render_render(r, m);
+    }
+    r->st.n_mobj_records = nmo;
+    for (int i = 0; i < nmo; i++) { r->st.n_columns += mo[i].ncols; free(mo[i].cols); }
+    free(mo);
+}
+
+int dr_render(dr_scene *s, int W, int H, const dr_view *view_in, uint8_t *rgb, int flags) {
+    g_err[0] = 0;
+    if (W <= 0 || H <= 0 || W > 32767 || H > 32767) return fail("bad frame size");
+    dr_view view = *view_in;
+    if (!view.trig_valid) {
+        view.cos_a = cosf(view.angle); view.sin_a = sinf(view.angle);
+        view.cos_na = cosf(-view.angle); view.sin_na = sinf(-view.angle);
+    }
+    R r;
+    memset(&r, 0, sizeof r);
+    r.s = s; r.W = W; r.H = H; r.k = make_consts(W, H); r.view = &view; r.flags = flags; r.pix = rgb;
+    r.ppos.x = view.x; r.ppos.y = view.y;
+    memset(rgb, 0, (size_t)3 * (size_t)W * (size_t)H);                       /* Pixels::new pixels.rs:10-14 */
+    r.hor_ocl = (uint8_t *)calloc((size_t)W, 1);                             /* Segs::new segs.rs:97-99 */
+    r.floor_ocl = (int16_t *)malloc((size_t)W * 2);
+    r.ceil_ocl = (int16_t *)malloc((size_t)W * 2);
+    for (int x = 0; x < W; x++) { r.floor_ocl[x] = (int16_t)H; r.ceil_ocl[x] = -1; }
+
+    render_node(&r, s->nnodes - 1);                                          /* mod.rs:118-136 */
+    if (!r.err)
+        for (int i = 0; i < r.nvis && !r.err; i++) draw_visplane(&r, &r.visplanes[i]);
+    if (!r.err) {
+        for (int i = 0, j = r.nsegs - 1; i < j; i++, j--) { BitmapRender t = r.segs[i]; r.segs[i] = r.segs[j]; r.segs[j] = t; } /* :124 */
+        draw_map_objects(&r);
+    }
+    if (!r.err)
+        for (int i = 0; i < r.nsegs && !r.err; i++) bitmap_render_render(&r, &r.segs[i]); /* draw_remaining_segs segs.rs:593-597 */
+
+    r.st.n_records = r.nsegs; r.st.n_visplanes = r.nvis;
+    for (int i = 0; i < r.nsegs; i++) { r.st.n_columns += r.segs[i].ncols; free(r.segs[i].cols); }
+    for (int i = 0; i < r.nvis; i++) { free(r.visplanes[i].top); free(r.visplanes[i].bottom); }
+    free(r.segs); free(r.visplanes); free(r.hor_ocl); free(r.floor_ocl); free(r.ceil_ocl);
+    g_stats = r.st;
+    return r.err ? -1 : 0;
+}

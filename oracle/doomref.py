@@ -1,0 +1,99 @@
+"""ctypes binding for the ORACLE (oracle/libdoomref.so).  TEST INFRASTRUCTURE ONLY: importable from
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never from the product package."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libdoomref.so")
+
+
+class View(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in "x y angle floor_height cos_a sin_a cos_na sin_na timestamp".split()] + \
+               [("trig_valid", ctypes.c_int32)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in "n_records n_columns n_visplanes n_mobj_records".split()] + \
+               [(n, ctypes.c_int64) for n in "wall_pixels flat_pixels sky_pixels masked_pixels mobj_pixels".split()]
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(_HERE, f) for f in ("doomref.c", "doomref.h")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        L.dr_load.restype = ctypes.c_void_p
+        L.dr_load.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.dr_free.argtypes = [ctypes.c_void_p]
+        L.dr_last_error.restype = ctypes.c_char_p
+        L.dr_render.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(View), ctypes.c_void_p, ctypes.c_int]
+        L.dr_player_start.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_float)] * 3
+        L.dr_floor_height_at.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float)]
+        L.dr_diminish_color.argtypes = [ctypes.c_char_p, ctypes.c_int16, ctypes.c_int16, ctypes.c_char_p]
+        L.dr_f32_as_i16.restype = ctypes.c_int16
+        L.dr_f32_as_i16.argtypes = [ctypes.c_float]
+        L.dr_f32_as_i32.restype = ctypes.c_int32
+        L.dr_f32_as_i32.argtypes = [ctypes.c_float]
+        L.dr_f32_as_u8.restype = ctypes.c_uint8
+        L.dr_f32_as_u8.argtypes = [ctypes.c_float]
+        L.dr_constants.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        L.dr_last_stats.argtypes = [ctypes.POINTER(Stats)]
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+class Scene:
+    """dr_scene handle: the reference's Game::new minus SDL (src/game.rs:142-167)."""
+
+    def __init__(self, wad: bytes, map_name: str = "e1m1"):
+        self._h = lib().dr_load(wad, len(wad), map_name.encode())
+        if not self._h:
+            raise OracleError(lib().dr_last_error().decode())
+
+    def player_start(self):
+        x, y, a = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
+        if lib().dr_player_start(self._h, x, y, a):
+            raise OracleError(lib().dr_last_error().decode())
+        return x.value, y.value, a.value
+
+    def floor_height_at(self, x: float, y: float, default: float = 0.0) -> float:
+        h = ctypes.c_float(default)
+        lib().dr_floor_height_at(self._h, x, y, h)
+        return h.value
+
+    def render(self, W: int, H: int, view, flags: int = 0, out=None):
+        """view: camera-path record of 8 (or 9) f32: x, y, angle, cos, sin, cos(-a), sin(-a), floor_height[, timestamp]
+        (camera_path.view_record) -> bytes (3*W*H)."""
+        x, y, a, c, s, cn, sn, fh = [float(t) for t in view[:8]]
+        v = View(x, y, a, fh, c, s, cn, sn, float(view[8]) if len(view) > 8 else 0.0, 1)
+        buf = out if out is not None else ctypes.create_string_buffer(3 * W * H)
+        ptr = ctypes.cast(buf, ctypes.c_void_p) if out is None else ctypes.c_void_p(out)
+        if lib().dr_render(self._h, W, H, ctypes.byref(v), ptr, flags):
+            raise OracleError(lib().dr_last_error().decode())
+        return buf.raw if out is None else None
+
+    def stats(self) -> dict:
+        st = Stats()
+        lib().dr_last_stats(ctypes.byref(st))
+        return {n: getattr(st, n) for n, _ in st._fields_}
+
+    def close(self):
+        if self._h:
+            lib().dr_free(self._h)
+            self._h = None

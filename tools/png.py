@@ -1,0 +1,9 @@
+"""Minimal PNG writer for eyeballing frames (debug aid only)."""
+import struct, zlib
+def write_png(path, w, h, rgb: bytes):
+    raw = b"".join(b"\0" + rgb[y*w*3:(y+1)*w*3] for y in range(h))
+    def chunk(t, d):
+        c = struct.pack(">I", len(d)) + t + d
+        return c + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                           chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
