@@ -1,0 +1,544 @@
+// frontend.cpp — host list generation: BSP walk, seg classification, projection, per-column clip arrays,
+// visplane assembly, sprite projection/clipping/sorting.  No pixel work happens here; see frontend.hpp.
+//
+// Arithmetic contract: IEEE f32, no contraction (-ffp-contract=off), Rust `as` casts via rust_num.h.
+#include "frontend.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "rust_num.h"
+
+namespace dg {
+
+namespace {
+
+const float kPi = 3.14159265358979323846f;
+const float kEye = 41.0f;  // PLAYER_EYE_HEIGHT, src/renderer/constants.rs:3
+
+struct V2 { float x, y; };
+struct Seg2 { V2 a, b; };
+
+inline V2 sub(V2 p, V2 q) { return V2{p.x - q.x, p.y - q.y}; }
+inline V2 rot(V2 v, float c, float s) { return V2{v.x * c - v.y * s, v.y * c + v.x * s}; }          // vertexes.rs:20-25
+inline bool left_of(V2 v, const Seg2 &l) {                                                           // vertexes.rs:27-34
+    V2 p = sub(v, l.a), d = sub(l.b, l.a);
+    return p.x * d.y - p.y * d.x <= 0.0f;
+}
+inline float dist(V2 p, V2 q) { float dx = p.x - q.x, dy = p.y - q.y; return std::sqrt(dx * dx + dy * dy); }
+
+// Line::intersection, src/geometry.rs:56-82
+inline bool intersect(const Seg2 &m, const Seg2 &n, V2 &out) {
+    float x1 = m.a.x, y1 = m.a.y, x2 = m.b.x, y2 = m.b.y, x3 = n.a.x, y3 = n.a.y, x4 = n.b.x, y4 = n.b.y;
+    float quot = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);
+    if (std::fabs(quot) < 0.001f) return false;
+    float inv = 1.0f / quot;
+    float c12 = x1 * y2 - y1 * x2, c34 = x3 * y4 - y3 * x4;
+    out.x = inv * (c12 * (x3 - x4) - (x1 - x2) * c34);
+    out.y = inv * (c12 * (y3 - y4) - (y1 - y2) * c34);
+    return true;
+}
+
+struct Clipped { Seg2 line; float start_offset; };
+
+// clip_to_viewport, src/renderer/misc.rs:13-115
+bool clip_to_viewport(const Seg2 &line, Clipped &out) {
+    const Seg2 left{{0.0f, 0.0f}, {1.0f, 1.0f}}, right{{0.0f, 0.0f}, {1.0f, -1.0f}};
+    bool s_out_l = left_of(line.a, left), e_out_l = left_of(line.b, left);
+    bool s_out_r = !left_of(line.a, right), e_out_r = !left_of(line.b, right);
+    bool s_in = line.a.x > 0.0f && !s_out_l && !s_out_r;
+    bool e_in = line.b.x > 0.0f && !e_out_l && !e_out_r;
+    if (s_in && e_in) { out.line = line; out.start_offset = 0.0f; return true; }
+    V2 li{0.0f, 0.0f}, ri{0.0f, 0.0f};
+    bool l_hit = intersect(line, left, li) && li.x >= 0.0f;
+    bool r_hit = intersect(line, right, ri) && ri.x >= 0.0f;
+    if (!s_in && !e_in && !l_hit && !r_hit) return false;
+    if (!s_in && !e_in && (l_hit != r_hit)) return false;
+    if ((r_hit && s_out_r && e_out_r) || (l_hit && s_out_l && e_out_l)) return false;
+    V2 s = line.a, e = line.b;
+    float so = 0.0f;
+    if (l_hit) {
+        if (s_out_l) { so = dist(li, s); s = li; }
+        if (e_out_l) e = li;
+    }
+    if (r_hit) {
+        if (s_out_r) s = ri;
+        if (e_out_r) e = ri;
+    }
+    out.line = Seg2{s, e};
+    out.start_offset = so;
+    return true;
+}
+
+struct ScreenLine { int32_t sx, sy, ex, ey; };
+
+// perspective_transform + make_sidedef_non_vertical_line, src/renderer/misc.rs:130-161
+inline ScreenLine project(const FrameConsts &k, const Seg2 &l, float height) {
+    float tsx = k.GCFX * l.a.y / l.a.x, tsy = k.GCFX * height / l.a.x;
+    float tex = k.GCFX * l.b.y / l.b.x, tey = k.GCFX * height / l.b.x;
+    tsx *= k.ARC;
+    tex *= k.ARC;
+    ScreenLine o;
+    o.sx = f32_as_i32(k.CFX - tsx);
+    o.sy = f32_as_i32(k.CFY - tsy);
+    o.ex = f32_as_i32(k.CFX - tex);
+    o.ey = f32_as_i32(k.CFY - tey);
+    o.sx = std::min(o.sx, k.W - 1);
+    o.ex = std::min(o.ex, k.W - 1);
+    return o;
+}
+
+enum : uint8_t { ST_SOLID, ST_TWOSIDED, ST_DRAWN, ST_MAPOBJECT };   // bitmap_render.rs:11-17
+
+}  // namespace
+
+struct FrameArena::Rec {                                             // bitmap_render.rs:29-45
+    Seg2 line;
+    float start_offset, bottom_height, top_height;
+    float min_x, max_x;            // of line.a.x / line.b.x, for is_behind_vertex
+    int32_t start_x, end_x, bitmap;
+    uint32_t first_col, n_cols;
+    int32_t out_index;             // index in arena.renders once emitted, else -1
+    int16_t light, offset_x, offset_y;
+    uint8_t state, ext_bottom, ext_top, draw_ceiling;
+    int16_t sort_key;              // map objects: line.start.x as i16 (bitmap_render.rs:168-174)
+};
+
+FrameArena::FrameArena() : recs(new std::vector<Rec>()) {}
+FrameArena::~FrameArena() { delete recs; }
+
+FrameConsts make_consts(int W, int H) {
+    FrameConsts k;
+    k.ARC = 200.0f / 240.0f;
+    k.GSW = (float)W / k.ARC;
+    k.GCFX = k.GSW / 2.0f;
+    k.CFX = (float)W / 2.0f;
+    k.CFY = (float)H / 2.0f;
+    k.W = W;
+    k.H = H;
+    return k;
+}
+
+void fill_view_trig(dg_view &v) {
+    if (v.trig_valid) return;
+    v.cos_a = cosf(v.angle);
+    v.sin_a = sinf(v.angle);
+    v.cos_na = cosf(-v.angle);
+    v.sin_na = sinf(-v.angle);
+    v.trig_valid = 1;
+}
+
+namespace {
+
+using Rec = FrameArena::Rec;
+
+struct PlaneBuilder {          // one open visplane of SidedefVisPlanes (sidedef_visplanes.rs:7-17)
+    bool used = false;
+    int16_t left = -1, right = -1;
+    uint32_t first = 0;        // entry index in its pool
+};
+
+struct Walker {
+    const Scene &sc;
+    const FrameConsts k;
+    const dg_view &view;
+    FrameArena &A;
+    std::vector<Rec> &recs;
+    std::string &err;
+    V2 ppos;
+    float player_height;
+    int status = DG_OK;
+    uint32_t n_floor_planes_marker = 0;
+    // visplanes carry a pool tag in the top bit of first_entry until finalisation
+    static constexpr uint32_t kCeilPool = 0x80000000u;
+
+    Walker(const Scene &s, int W, int H, const dg_view &v, FrameArena &a, std::string &e)
+        : sc(s), k(make_consts(W, H)), view(v), A(a), recs(*a.recs), err(e) {
+        ppos = V2{v.x, v.y};
+        player_height = v.floor_height + kEye;
+    }
+
+    int fail(const std::string &m) {
+        if (status == DG_OK) { status = DG_ERR_RENDER; err = m; }
+        return status;
+    }
+
+    // Flats::get_animated at this frame's timestamp
+    int resolve_flat(int flat, int anim) {
+        if (anim < 0) return flat;
+        const AnimList &a = sc.anim[(size_t)anim];
+        float t = view.timestamp * 3.0f;
+        size_t cyc = !(t > 0.0f) ? 0 : (t >= 18446744073709551616.0f ? SIZE_MAX : (size_t)t);
+        return a.flat[cyc % (size_t)a.n];
+    }
+
+    void occlude(int x) {                                           // segs.rs:113-117
+        A.hor_ocl[(size_t)x] = 1;
+        A.floor_ocl[(size_t)x] = (int16_t)((int16_t)k.H / 2);
+        A.ceil_ocl[(size_t)x] = (int16_t)((int16_t)k.H / 2);
+    }
+
+    void plane_add(PlaneBuilder &p, std::vector<int16_t> &pool, int16_t x, int16_t top, int16_t bottom) {
+        if (!p.used) {                                              // sidedef_visplanes.rs:60-83
+            p.left = x;
+            p.first = (uint32_t)(pool.size() / 2);
+            p.used = true;
+        } else {
+            for (int g = p.right + 1; g < x; g++) { pool.push_back(0); pool.push_back(0); }  // Visplane::new zero fill
+        }
+        p.right = x;
+        pool.push_back(top);
+        pool.push_back(bottom);
+    }
+    void plane_flush(PlaneBuilder &p, bool ceil, int flat, int16_t height, int16_t light) {
+        if (!p.used) return;
+        dg_visplane v;
+        v.flat = flat; v.height = height; v.light_level = light; v.left = p.left; v.right = p.right;
+        v.first_entry = p.first | (ceil ? kCeilPool : 0u);
+        A.visplanes.push_back(v);
+        p.used = false;
+    }
+
+    struct Side {                                                   // SideDefDetails, segs.rs:42-51
+        const Clipped *cl;
+        const SidedefRec *sd;
+        int16_t offset_x, floor_h, ceil_h, light;
+        int floor_flat, ceil_flat;
+    };
+    struct Flags { bool only_occlusions, lower, upper, draw_ceiling, two_sided_mid; };   // segs.rs:53-59
+
+    void emit_draw(Rec &r) {
+        if (r.out_index < 0) {
+            dg_bitmap_render o;
+            std::memset(&o, 0, sizeof o);
+            o.bitmap = r.bitmap; o.light_level = r.light; o.offset_x = r.offset_x; o.offset_y = r.offset_y;
+            o.line_start_x = r.line.a.x; o.line_start_y = r.line.a.y; o.line_end_x = r.line.b.x; o.line_end_y = r.line.b.y;
+            o.start_offset = r.start_offset; o.start_x = r.start_x; o.end_x = r.end_x;
+            o.bottom_height = r.bottom_height; o.top_height = r.top_height;
+            o.first_column = r.first_col; o.n_columns = r.n_cols;
+            r.out_index = (int32_t)A.renders.size();
+            A.renders.push_back(o);
+        }
+        A.order.push_back(dg_draw_cmd{0u, (uint32_t)r.out_index});
+    }
+
+    // Segs::process_sidedef, segs.rs:121-350
+    void process_sidedef(const Side &s, float bottom_height, float top_height, int32_t offset_y, int tex, Flags f) {
+        const int W = k.W, H = k.H;
+        ScreenLine bot = project(k, s.cl->line, bottom_height);
+        ScreenLine top = project(k, s.cl->line, top_height);
+        if (tex == TEX_UNKNOWN) { fail("Unknown texture (Textures::get panics, textures.rs:158)"); return; }
+        if (bot.sx != top.sx || bot.ex != top.ex) { fail("Wall start not vertical (segs.rs:140-145)"); return; }
+        if (wrap_i16(bot.sx) == wrap_i16(bot.ex) || wrap_i16(top.sx) == wrap_i16(top.ex)) return;
+        if (bot.sx < 0 || bot.sx >= W || bot.ex < 0 || bot.ex >= W) { fail("Invalid line x (segs.rs:103-111)"); return; }
+
+        float bottom_delta = ((float)bot.sy - (float)bot.ey) / ((float)bot.sx - (float)bot.ex);
+        float top_delta = ((float)top.sy - (float)top.ey) / ((float)top.sx - (float)top.ex);
+
+        PlaneBuilder pb, pt;
+        bool full_height = !f.lower && !f.upper && !f.only_occlusions;
+
+        Rec r;
+        r.line = s.cl->line;
+        r.start_offset = s.cl->start_offset;
+        r.bottom_height = bottom_height; r.top_height = top_height;
+        r.min_x = std::fmin(r.line.a.x, r.line.b.x); r.max_x = std::fmax(r.line.a.x, r.line.b.x);
+        r.start_x = bot.sx; r.end_x = bot.ex; r.bitmap = tex;
+        r.first_col = (uint32_t)A.columns.size(); r.n_cols = 0; r.out_index = -1;
+        r.light = s.light;
+        r.offset_x = (int16_t)wrap_i16(f32_as_i16(s.sd->xoff) + s.offset_x);
+        r.offset_y = (int16_t)wrap_i16(f32_as_i16(s.sd->yoff) + wrap_i16(offset_y));
+        r.state = f.two_sided_mid ? ST_TWOSIDED : ST_SOLID;
+        r.ext_bottom = f.lower || (!f.two_sided_mid && full_height);
+        r.ext_top = f.upper || (!f.two_sided_mid && full_height);
+        r.draw_ceiling = f.draw_ceiling;
+        r.sort_key = 0;
+
+        const bool planes_here = !f.two_sided_mid && (full_height || f.only_occlusions);
+        const int16_t hm1 = (int16_t)(H - 1);
+        for (int x = bot.sx; x <= bot.ex; x++) {
+            if (!A.hor_ocl[(size_t)x]) {
+                int16_t bottom_y = (int16_t)f32_as_i16((float)bot.sy + ((float)x - (float)bot.sx) * bottom_delta);
+                int16_t top_y = (int16_t)f32_as_i16((float)top.sy + ((float)x - (float)top.sx) * top_delta);
+                int16_t fo = A.floor_ocl[(size_t)x], co = A.ceil_ocl[(size_t)x];
+                int16_t cb = std::min(hm1, std::min(fo, bottom_y));
+                int16_t ct = std::max((int16_t)0, std::max(co, top_y));
+                bool vis = cb >= ct;
+                if (vis) {
+                    A.columns.push_back(dg_bitmap_column{(int16_t)x, ct, cb, bottom_y, top_y});
+                    r.n_cols++;
+                }
+                if (planes_here && vis) {
+                    bool added = false;
+                    if (cb < fo && cb != hm1) { plane_add(pb, A.floor_tb, (int16_t)x, cb, fo); added = true; }
+                    if (f.draw_ceiling && ct > co && ct != -1) { plane_add(pt, A.ceil_tb, (int16_t)x, co, ct); added = true; }
+                    if (!added) {
+                        plane_flush(pb, false, s.floor_flat, s.floor_h, s.light);
+                        plane_flush(pt, true, s.ceil_flat, s.ceil_h, s.light);
+                    }
+                } else if (planes_here && !vis && fo > co) {        // occluded wall, open vertical gap (segs.rs:293-318)
+                    if (bottom_y <= co) { plane_add(pb, A.floor_tb, (int16_t)x, co, fo); occlude(x); }
+                    if (f.draw_ceiling && top_y >= fo) { plane_add(pt, A.ceil_tb, (int16_t)x, co, fo); occlude(x); }
+                }
+                if (!f.two_sided_mid && vis) {
+                    if (f.only_occlusions) {
+                        A.floor_ocl[(size_t)x] = cb;
+                        if (f.draw_ceiling) A.ceil_ocl[(size_t)x] = ct;
+                    }
+                    if (f.lower) A.floor_ocl[(size_t)x] = ct;
+                    if (f.upper) A.ceil_ocl[(size_t)x] = cb;
+                }
+            } else {
+                plane_flush(pb, false, s.floor_flat, s.floor_h, s.light);
+                plane_flush(pt, true, s.ceil_flat, s.ceil_h, s.light);
+            }
+            if (!f.two_sided_mid && full_height) occlude(x);
+        }
+        plane_flush(pb, false, s.floor_flat, s.floor_h, s.light);
+        plane_flush(pt, true, s.ceil_flat, s.ceil_h, s.light);
+
+        recs.push_back(r);
+        // inline draw of solid / upper / lower parts (segs.rs:231-258)
+        if (!f.two_sided_mid && !f.only_occlusions && tex >= 0 && r.n_cols > 0) emit_draw(recs.back());
+    }
+
+    // Segs::process_seg, segs.rs:353-590
+    void process_seg(const SegRec &sg) {
+        const LinedefRec &ld = sc.linedefs[(size_t)sg.linedef];
+        int fsd = sg.direction ? ld.back : ld.front;
+        int bsd = sg.direction ? ld.front : ld.back;
+        if (fsd < 0) return;
+        const SidedefRec &front = sc.sidedefs[(size_t)fsd];
+        const SectorRec &fs = sc.sectors[(size_t)front.sector];
+        const SectorRec *bs = bsd >= 0 ? &sc.sectors[(size_t)sc.sidedefs[(size_t)bsd].sector] : nullptr;
+
+        float floor_height = (float)fs.floor_h, ceiling_height = (float)fs.ceil_h;
+        bool has_pb = false, has_pt = false;
+        float pb_h = 0.0f, pt_h = 0.0f;
+        if (bs) {
+            if (bs->floor_h > fs.floor_h) { has_pb = true; pb_h = (float)bs->floor_h; }
+            if (bs->ceil_h < fs.ceil_h) { has_pt = true; pt_h = (float)bs->ceil_h; }
+        }
+        bool two_sided = (ld.flags & 4) != 0, top_unpegged = (ld.flags & 8) != 0, bottom_unpegged = (ld.flags & 16) != 0;
+
+        V2 a = rot(sub(V2{sc.vx[(size_t)sg.v1], sc.vy[(size_t)sg.v1]}, ppos), view.cos_na, view.sin_na);
+        V2 b = rot(sub(V2{sc.vx[(size_t)sg.v2], sc.vy[(size_t)sg.v2]}, ppos), view.cos_na, view.sin_na);
+        Clipped cl;
+        if (!clip_to_viewport(Seg2{a, b}, cl)) return;
+        if (cl.line.a.x < -0.01f) { fail("Clipped line x < -0.01 (segs.rs:431-436)"); return; }
+
+        ScreenLine fl = project(k, cl.line, floor_height - player_height);
+        if (fl.sx > fl.ex) return;                                   // back face
+
+        int floor_flat = resolve_flat(fs.floor_flat, fs.floor_anim);
+        int ceil_flat = resolve_flat(fs.ceil_flat, fs.ceil_anim);
+        if (floor_flat < 0 || ceil_flat < 0) { fail("Could not find flat lump (Flat::new unwrap, flats.rs:117)"); return; }
+
+        bool draw_ceiling = true;
+        if (bs && fs.ceil_tex_sky && bs->ceil_tex_sky) {             // sky hack, segs.rs:463-477
+            has_pt = false;
+            ceiling_height = std::fmin((float)bs->ceil_h, ceiling_height);
+            draw_ceiling = false;
+        }
+        Side s{&cl, &front, sg.offset, fs.floor_h, fs.ceil_h, fs.light, floor_flat, ceil_flat};
+
+        if (!two_sided) {
+            int32_t oy = bottom_unpegged ? f32_as_i32(floor_height - ceiling_height) : 0;
+            process_sidedef(s, floor_height - player_height, ceiling_height - player_height, oy, front.middle,
+                            Flags{false, false, false, draw_ceiling, false});
+            return;
+        }
+        process_sidedef(s, floor_height - player_height, ceiling_height - player_height, 0, front.middle,
+                        Flags{true, false, false, draw_ceiling, false});
+        if (status) return;
+        float mid_floor = has_pb ? pb_h : floor_height, mid_ceil = has_pt ? pt_h : ceiling_height;
+        process_sidedef(s, mid_floor - player_height, mid_ceil - player_height, 0, front.middle,
+                        Flags{false, false, false, draw_ceiling, true});
+        if (status) return;
+        if (has_pb) {
+            int32_t oy = bottom_unpegged ? f32_as_i32(ceiling_height - pb_h) : 0;
+            process_sidedef(s, floor_height - player_height, pb_h - player_height, oy, front.lower,
+                            Flags{false, true, false, draw_ceiling, false});
+            if (status) return;
+        }
+        if (has_pt) {
+            int32_t oy = top_unpegged ? 0 : f32_as_i32(pt_h - ceiling_height);
+            process_sidedef(s, pt_h - player_height, ceiling_height - player_height, oy, front.upper,
+                            Flags{false, false, true, draw_ceiling, false});
+        }
+    }
+
+    // Renderer::render_node, mod.rs:69-104 — iterative, front child first, no culling (the reference has none)
+    void walk_bsp() {
+        int16_t stack[256];
+        int sp = 0;
+        stack[sp++] = (int16_t)(sc.nodes.size() - 1);
+        while (sp > 0 && !status) {
+            int16_t c = stack[--sp];
+            if (c & (int16_t)0x8000) {
+                const SubSectorRec &ss = sc.subsectors[(size_t)(c & 0x7fff)];
+                for (int i = 0; i < ss.count && !status; i++) process_seg(sc.segs[(size_t)(ss.first + i)]);
+                continue;
+            }
+            const NodeRec &n = sc.nodes[(size_t)c];
+            V2 v1{n.x, n.y}, v2{n.x + n.dx, n.y + n.dy};
+            bool is_left = left_of(ppos, Seg2{v1, v2});
+            int16_t front = is_left ? n.lchild : n.rchild, back = is_left ? n.rchild : n.lchild;
+            if (sp + 2 > 256) { fail("BSP deeper than 256"); return; }
+            stack[sp++] = back;
+            stack[sp++] = front;
+        }
+    }
+
+    static bool behind(const Rec &r, V2 v) {                         // is_behind_vertex, bitmap_render.rs:137-165
+        if (r.min_x > v.x) return true;
+        if (r.max_x > v.x && !left_of(v, r.line)) return true;
+        return false;
+    }
+
+    // draw_map_objects, renderer/map_objects.rs:19-241
+    void map_objects() {
+        const int W = k.W, H = k.H;
+        const size_t n_wall_recs = recs.size();
+        std::vector<uint32_t> mo;   // indices of map-object records in recs
+        for (const MapObjectRec &m : sc.mobjs) {
+            if (m.sprite_frame < 0) continue;                         // S_NULL
+            float angle = view.angle - m.angle - kPi;
+            angle += kPi / 16.0f;
+            angle = std::fmod(angle, 2.0f * kPi);
+            if (angle < 0.0f) angle += 2.0f * kPi;
+            angle = std::fmod(angle, 2.0f * kPi);
+            int rotation = f32_as_u8(angle * 8.0f / (2.0f * kPi));
+            if (rotation > 7) { fail("Invalid rotation (sprites.rs:106-108)"); return; }
+            const SpriteFrameRec &sf = sc.sprite_frames[(size_t)m.sprite_frame];
+            int bitmap = sf.rotate ? sf.bitmap[rotation] : sf.bitmap[0];
+            const BitmapInfo &bi = sc.bitmaps[(size_t)bitmap];
+
+            V2 vpv = rot(sub(V2{m.x, m.y}, ppos), view.cos_na, view.sin_na);
+            int16_t width = (int16_t)bi.w;
+            V2 a = sub(vpv, V2{0.0f, (float)(int16_t)(-width) / 2.0f});
+            V2 b = sub(vpv, V2{0.0f, (float)width / 2.0f});
+            Clipped cl;
+            if (!clip_to_viewport(Seg2{a, b}, cl)) continue;
+            if (cl.line.a.x < -0.01f) { fail("Clipped line x < -0.01 (map_objects.rs:92-97)"); return; }
+            if (m.sector < 0) continue;                               // "Thing is outside map"
+            const SectorRec &sec = sc.sectors[(size_t)m.sector];
+            int16_t light = m.full_bright ? (int16_t)255 : sec.light;
+
+            int16_t bh = (int16_t)bi.h;
+            float bottom_height = (float)sec.floor_h - player_height;
+            float top_height = (float)sec.floor_h + (float)bh - 1.0f - player_height;
+            bottom_height += (float)bi.top_offset - (float)bh;
+            top_height += (float)bi.top_offset - (float)bh;
+            ScreenLine bot = project(k, cl.line, bottom_height);
+            ScreenLine top = project(k, cl.line, top_height);
+
+            int x0 = wrap_i16(bot.sx), x1 = wrap_i16(bot.ex);        // columns [x0, x1)
+            if (x0 < x1 && (x0 < 0 || x1 > W)) { fail("map object column out of range (index panic)"); return; }
+            for (int x = x0; x < x1; x++) { A.top_clip[(size_t)x] = -1; A.bottom_clip[(size_t)x] = (int16_t)H; }
+            if (x0 < x1) {
+                for (size_t ri = 0; ri < n_wall_recs; ri++) {         // :135-166 (only x in [x0,x1) is ever read back)
+                    const Rec &r = recs[ri];
+                    if (r.n_cols == 0 || behind(r, vpv)) continue;
+                    bool solid = r.state == ST_SOLID;
+                    if (solid && !r.ext_bottom && !r.ext_top) continue;
+                    const dg_bitmap_column *c0 = &A.columns[r.first_col], *c1 = c0 + r.n_cols;
+                    const dg_bitmap_column *c = std::lower_bound(c0, c1, x0, [](const dg_bitmap_column &q, int v) { return q.x < v; });
+                    for (; c < c1 && c->x < x1; ++c) {
+                        size_t x = (size_t)c->x;
+                        if (solid) {
+                            if (r.ext_bottom) A.bottom_clip[x] = std::min(A.bottom_clip[x], c->clipped_top_y);
+                            if (r.ext_top) A.top_clip[x] = std::max(A.top_clip[x], c->clipped_bottom_y);
+                        } else {                                       // ST_TWOSIDED (nothing is ST_DRAWN yet)
+                            if (r.draw_ceiling) A.top_clip[x] = std::max(A.top_clip[x], c->top_y);
+                            A.bottom_clip[x] = std::min(A.bottom_clip[x], c->bottom_y);
+                        }
+                    }
+                }
+            }
+            Rec r;
+            r.line = cl.line; r.start_offset = cl.start_offset;
+            r.bottom_height = bottom_height; r.top_height = top_height;
+            r.min_x = std::fmin(r.line.a.x, r.line.b.x); r.max_x = std::fmax(r.line.a.x, r.line.b.x);
+            r.start_x = bot.sx; r.end_x = bot.ex; r.bitmap = bitmap;
+            r.first_col = (uint32_t)A.columns.size(); r.n_cols = 0; r.out_index = -1;
+            r.light = light; r.offset_x = 0; r.offset_y = 0;
+            r.state = ST_MAPOBJECT; r.ext_bottom = r.ext_top = r.draw_ceiling = 0;
+            r.sort_key = (int16_t)f32_as_i16(cl.line.a.x);
+            float bottom_delta = ((float)bot.sy - (float)bot.ey) / ((float)bot.sx - (float)bot.ex);
+            float top_delta = ((float)top.sy - (float)top.ey) / ((float)top.sx - (float)top.ex);
+            for (int x = x0; x < x1; x++) {
+                int16_t bottom_y = (int16_t)f32_as_i16((float)bot.sy + ((float)x - (float)bot.sx) * bottom_delta);
+                int16_t top_y = (int16_t)f32_as_i16((float)top.sy + ((float)x - (float)top.sx) * top_delta);
+                int16_t ct = std::max((int16_t)0, std::max(top_y, A.top_clip[(size_t)x]));
+                int16_t cb = std::min((int16_t)(H - 1), std::min(bottom_y, A.bottom_clip[(size_t)x]));
+                A.columns.push_back(dg_bitmap_column{(int16_t)x, ct, cb, bottom_y, top_y});
+                r.n_cols++;
+            }
+            mo.push_back((uint32_t)recs.size());
+            recs.push_back(r);
+        }
+        // sort() is stable ascending on the key, then reverse()  (map_objects.rs:216-217)
+        std::stable_sort(mo.begin(), mo.end(), [&](uint32_t p, uint32_t q) { return recs[p].sort_key < recs[q].sort_key; });
+        std::reverse(mo.begin(), mo.end());
+
+        // `segs` was reversed before this call (mod.rs:124): iterate wall records back to front
+        for (uint32_t mi : mo) {
+            const Rec &m = recs[mi];
+            V2 v{(m.line.a.x + m.line.b.x) / 2.0f, (m.line.a.y + m.line.b.y) / 2.0f};
+            for (size_t ri = n_wall_recs; ri-- > 0;) {
+                Rec &r = recs[ri];
+                if (r.state != ST_TWOSIDED || !behind(r, v)) continue;
+                if (r.bitmap >= 0 && r.n_cols > 0) emit_draw(r);
+                r.state = ST_DRAWN;
+            }
+            emit_draw(recs[mi]);
+        }
+        for (size_t ri = n_wall_recs; ri-- > 0;) {                   // draw_remaining_segs, segs.rs:593-597
+            Rec &r = recs[ri];
+            if (r.state != ST_TWOSIDED) continue;
+            if (r.bitmap >= 0 && r.n_cols > 0) emit_draw(r);
+            r.state = ST_DRAWN;
+        }
+    }
+};
+
+}  // namespace
+
+int build_frame_lists(const Scene &sc, int W, int H, const dg_view &view, FrameArena &A, dg_frame_lists &out, std::string &err) {
+    if (W <= 0 || H <= 0 || W > 16384 || H > 16384) { err = "bad frame size"; return DG_ERR_INVALID; }
+    A.renders.clear(); A.columns.clear(); A.visplanes.clear(); A.plane_tb.clear(); A.order.clear();
+    A.recs->clear(); A.floor_tb.clear(); A.ceil_tb.clear();
+    A.hor_ocl.assign((size_t)W, 0);                                  // Segs::new, segs.rs:97-99
+    A.floor_ocl.assign((size_t)W, (int16_t)H);
+    A.ceil_ocl.assign((size_t)W, (int16_t)-1);
+    A.top_clip.resize((size_t)W);
+    A.bottom_clip.resize((size_t)W);
+
+    Walker wk(sc, W, H, view, A, err);
+    wk.walk_bsp();
+    if (wk.status) return wk.status;
+    // visplanes are drawn after all inline walls, in push order (mod.rs:122)
+    const uint32_t n_floor_entries = (uint32_t)(A.floor_tb.size() / 2);
+    A.plane_tb.reserve(A.floor_tb.size() + A.ceil_tb.size());
+    A.plane_tb.insert(A.plane_tb.end(), A.floor_tb.begin(), A.floor_tb.end());
+    A.plane_tb.insert(A.plane_tb.end(), A.ceil_tb.begin(), A.ceil_tb.end());
+    for (uint32_t i = 0; i < A.visplanes.size(); i++) {
+        dg_visplane &v = A.visplanes[i];
+        if (v.first_entry & Walker::kCeilPool) v.first_entry = (v.first_entry & ~Walker::kCeilPool) + n_floor_entries;
+        A.order.push_back(dg_draw_cmd{1u, i});
+    }
+    wk.map_objects();
+    if (wk.status) return wk.status;
+
+    out.view = view;
+    out.renders = A.renders.data(); out.n_renders = (uint32_t)A.renders.size();
+    out.columns = A.columns.data(); out.n_columns = (uint32_t)A.columns.size();
+    out.visplanes = A.visplanes.data(); out.n_visplanes = (uint32_t)A.visplanes.size();
+    out.plane_tb = A.plane_tb.data(); out.n_plane_tb = (uint32_t)A.plane_tb.size();
+    out.order = A.order.data(); out.n_order = (uint32_t)A.order.size();
+    return DG_OK;
+}
+
+}  // namespace dg

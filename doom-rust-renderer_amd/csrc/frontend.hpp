@@ -1,0 +1,51 @@
+// frontend.hpp — per-frame list generation on the host.
+//
+// The reference draws solid walls inline while it walks the BSP and records a replay list for masked walls
+// and sprites (src/renderer/segs.rs:185-200,231-260,349).  Here the same walk records *everything* — no
+// pixel is touched on the host — and emits the lists in the order the reference would have drawn them:
+//   1. solid / upper / lower wall records, BSP front-to-back           (src/renderer/mod.rs:61-104)
+//   2. visplanes in push order                                          (src/renderer/mod.rs:106-116)
+//   3. sprites far->near, each preceded by the masked walls behind it  (src/renderer/map_objects.rs:216-240)
+//   4. remaining masked walls                                           (src/renderer/segs.rs:593-597)
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/doomgpu.h"
+#include "scene.hpp"
+
+namespace dg {
+
+struct FrameConsts {   // src/renderer/constants.rs:3-17, evaluated in f32 exactly like the const items
+    float ARC, GSW, GCFX, CFX, CFY;
+    int W, H;
+};
+FrameConsts make_consts(int W, int H);
+
+// Reusable per-thread storage: one build() call fills it, the dg_frame_lists view points into it.
+struct FrameArena {
+    std::vector<dg_bitmap_render> renders;
+    std::vector<dg_bitmap_column> columns;
+    std::vector<dg_visplane> visplanes;
+    std::vector<int16_t> plane_tb;
+    std::vector<dg_draw_cmd> order;
+    // scratch
+    struct Rec;
+    std::vector<Rec> *recs = nullptr;   // opaque (defined in frontend.cpp)
+    std::vector<int16_t> floor_tb, ceil_tb;
+    std::vector<uint8_t> hor_ocl;
+    std::vector<int16_t> floor_ocl, ceil_ocl, top_clip, bottom_clip;
+    FrameArena();
+    ~FrameArena();
+    FrameArena(const FrameArena &) = delete;
+    FrameArena &operator=(const FrameArena &) = delete;
+};
+
+// Fills `arena` and `out` (pointers into arena).  Returns DG_OK or DG_ERR_RENDER with `err` set where the
+// reference would panic.  `view` must have its trig fields filled.
+int build_frame_lists(const Scene &sc, int W, int H, const dg_view &view, FrameArena &arena, dg_frame_lists &out, std::string &err);
+
+void fill_view_trig(dg_view &v);
+
+}  // namespace dg

@@ -1,0 +1,81 @@
+// lists_dev.h — device-side list formats (plain structs shared by the host binner and the HIP kernels).
+//
+// Layout in HBM for one submission of F frames (all arrays are slabs sized at dg_create for max_batch):
+//   DevFrame   frames[F]                 per-frame constants + bases into the arrays below
+//   uint32_t   col_off[F][W + 1]         column-major index: spans of column x of frame f are
+//                                        spans[frames[f].span_base + col_off[f][x] .. + col_off[f][x+1])
+//   DevSpan    spans[]                   16 B each, per column in DRAW ORDER (later span overwrites earlier)
+//   DevSpanAux aux[]                     8 B each, written by the setup kernel (texture column address, light factor)
+//   DevWallRec walls[]                   48 B per drawn BitmapRender (per-record constants of render_vertical_bitmap_line)
+//   DevPlaneRec planes[]                 16 B per drawn visplane
+// plus the immutable scene: palette (256 x RGBX u32), texel index plane + opacity plane (u8, column-major
+// per bitmap: off + x*h + y), flats (4096 B each, [y][x]).
+#pragma once
+#include <stdint.h>
+
+namespace dg {
+
+enum : uint8_t { SPAN_WALL = 0, SPAN_FLAT = 1, SPAN_SKY = 2 };
+
+struct DevSpan {              // one vertical run of one draw call in one screen column
+    int16_t ctop, cbot;       // rows to write, inclusive, already clamped to [0, H-1]
+    int16_t top_y, bot_y;     // WALL: unclipped column extent (BitmapColumn.top_y / bottom_y)
+    uint16_t rec;             // index into the frame's walls[] (WALL) or planes[] (FLAT)
+    uint8_t kind, pad0;
+    int16_t x, pad1;
+};
+static_assert(sizeof(DevSpan) == 16, "DevSpan must be 16 bytes");
+
+struct DevSpanAux {           // setup-kernel output
+    uint32_t texcol;          // WALL/SKY: texel offset of the bitmap column (bitmap off + tx*h)
+    float factor;             // WALL: light_level/255 - z/4096 clamped at 0 (diminish_color, bitmap_render.rs:190-201)
+};
+static_assert(sizeof(DevSpanAux) == 8, "DevSpanAux must be 8 bytes");
+
+struct DevWallRec {           // bitmap_render.rs:233-251 hoisted per record
+    float A, B, C, D;         // ux0/uz0 (= 0.0/uz0), ux1/uz1 (= len/uz1), 1.0/uz0, 1.0/uz1
+    float uy1;                // top_height - bottom_height
+    float lightf;             // light_level as f32 / 255.0
+    float dxf;                // (end_x - start_x) as f32
+    int32_t start_x;
+    uint32_t texel_off;
+    int16_t w, h;
+    int16_t off_x;            // clipped_line.start_offset as i16 + offset_x (wrapping)
+    int16_t off_y;
+    uint32_t has_holes;
+};
+static_assert(sizeof(DevWallRec) == 48, "DevWallRec must be 48 bytes");
+
+struct DevPlaneRec {          // visplanes.rs:103-126 hoisted per visplane
+    float wz;                 // height as f32 - player.floor_height - 41.0
+    float gwz;                // GAME_CAMERA_FOCUS_X * wz
+    float lightf;             // light_level as f32 / 255.0
+    uint32_t flat_off;        // byte offset of the 64x64 flat
+};
+static_assert(sizeof(DevPlaneRec) == 16, "DevPlaneRec must be 16 bytes");
+
+struct DevFrame {
+    float cos_a, sin_a;       // rotate(player.angle)
+    int32_t pos_x_i16, pos_y_i16;   // player.position.{x,y} as i16
+    int32_t sky_tx_offset;    // draw_sky's tx_offset after the negative fix-up (visplanes.rs:54-58)
+    uint32_t span_base, n_spans;
+    uint32_t wall_base, plane_base;
+    uint32_t pad[3];
+};
+static_assert(sizeof(DevFrame) == 48, "DevFrame must be 48 bytes");
+
+struct DevScene {             // immutable, uploaded once per map
+    const uint32_t *palette;  // 256 x (r | g<<8 | b<<16)
+    const uint8_t *texel_idx;
+    const uint8_t *texel_opq;
+    const uint8_t *flats;
+    uint32_t sky_texel_off;   // sky bitmap (256 x 128 expected)
+    int32_t sky_w, sky_h;
+};
+
+struct DevConsts {            // src/renderer/constants.rs, as f32 bit patterns computed on the host
+    float ARC, GCFX, CFX, CFY;
+    int32_t W, H;
+};
+
+}  // namespace dg
