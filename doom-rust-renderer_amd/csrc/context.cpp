@@ -1,0 +1,496 @@
+// context.cpp — dg_ctx: one GPU's resident scene, per-slot list slabs / framebuffer slabs / streams, and the
+// host thread pool that builds the per-frame lists.  Implements the C-ABI declared in include/doomgpu.h.
+//
+// HBM layout (sized once at dg_create for 288 GB parts: nothing is reallocated on the submit path):
+//   scene   : palette 1 KB | texel index plane | texel opacity plane | flats (4 KB each)      immutable per map
+//   per slot: list slab  [DevFrame x F | col_off x F*(W+1) | DevWallRec.. | DevPlaneRec.. | DevSpan..]  one H2D copy
+//             aux slab   DevSpanAux per span (device-only, written by dg_setup_spans)
+//             framebuffer slab  F x 3*W*H bytes RGB24 (the reference's Pixels.pixels, one per frame)
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/doomgpu.h"
+#include "binner.hpp"
+#include "frontend.hpp"
+#include "kernels.hpp"
+#include "scene.hpp"
+
+using namespace dg;
+
+static thread_local std::string t_err;
+static int set_err(int code, const std::string &m) { t_err = m; return code; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return set_err(DG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct dg_scene { Scene *sc; };
+
+namespace {
+
+// Minimal persistent pool: parallel_for over [0, n) with dynamic chunking.
+class Pool {
+public:
+    explicit Pool(int n) {
+        for (int i = 0; i < n; i++) workers_.emplace_back([this, i] { loop(i); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    int size() const { return (int)workers_.size(); }
+    // fn(index, worker_id); worker ids are 0..size() (the caller participates as id size()).
+    void parallel_for(int n, const std::function<void(int, int)> &fn) {
+        if (n <= 0) return;
+        { std::lock_guard<std::mutex> l(m_); fn_ = &fn; n_ = n; next_.store(0); pending_ = (int)workers_.size(); gen_++; }
+        cv_.notify_all();
+        run(fn, (int)workers_.size());
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    void run(const std::function<void(int, int)> &fn, int wid) {
+        for (;;) {
+            int i = next_.fetch_add(1);
+            if (i >= n_) break;
+            fn(i, wid);
+        }
+    }
+    void loop(int wid) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int, int)> *fn;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_;
+            }
+            if (fn) run(*fn, wid);
+            { std::lock_guard<std::mutex> l(m_); if (--pending_ == 0) done_.notify_all(); }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int, int)> *fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_raster = nullptr, ev_done = nullptr;
+    uint8_t *h_lists = nullptr;   // pinned staging
+    uint8_t *d_lists = nullptr;
+    DevSpanAux *d_aux = nullptr;
+    uint8_t *d_fb = nullptr;
+    size_t lists_cap = 0;
+    // last submission
+    RasterParams P{};
+    uint32_t max_spans = 0;
+    uint64_t n_spans = 0, covered = 0;
+    int n_frames = 0;
+    bool busy = false, timed = false;
+};
+
+}  // namespace
+
+struct dg_ctx {
+    dg_config cfg{};
+    FrameConsts fk{};
+    DevConsts dk{};
+    const Scene *scene = nullptr;
+    // device scene
+    uint32_t *d_palette = nullptr;
+    uint8_t *d_texel_idx = nullptr, *d_texel_opq = nullptr, *d_flats = nullptr;
+    DevScene dscene{};
+    std::vector<Slot> slots;
+    std::unique_ptr<Pool> pool;
+    std::vector<std::unique_ptr<FrameArena>> arenas;   // one per worker (+ caller)
+    std::vector<BinnedFrame> binned;                   // one per frame of a batch
+    size_t span_cap_per_batch = 0, wall_cap_per_batch = 0, plane_cap_per_batch = 0;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void free_ctx(dg_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    for (Slot &s : c->slots) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.h_lists) (void)hipHostFree(s.h_lists);
+        if (s.d_lists) (void)hipFree(s.d_lists);
+        if (s.d_aux) (void)hipFree(s.d_aux);
+        if (s.d_fb) (void)hipFree(s.d_fb);
+        if (s.ev_start) (void)hipEventDestroy(s.ev_start);
+        if (s.ev_setup) (void)hipEventDestroy(s.ev_setup);
+        if (s.ev_raster) (void)hipEventDestroy(s.ev_raster);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    if (c->d_palette) (void)hipFree(c->d_palette);
+    if (c->d_texel_idx) (void)hipFree(c->d_texel_idx);
+    if (c->d_texel_opq) (void)hipFree(c->d_texel_opq);
+    if (c->d_flats) (void)hipFree(c->d_flats);
+    delete c;
+}
+
+// Build + bin the lists of n views in parallel, pack them into the slot's pinned slab, fill slot.P.
+int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *given, int n) {
+    if (!c->scene) return set_err(DG_ERR_INVALID, "no scene uploaded (dg_upload_scene)");
+    if (n <= 0 || n > c->cfg.max_batch) return set_err(DG_ERR_CAPACITY, "batch size outside [1, max_batch]");
+    const Scene &sc = *c->scene;
+    const int W = c->cfg.width, H = c->cfg.height;
+    std::vector<int> rc((size_t)n, 0);
+    std::vector<std::string> errs((size_t)n);
+    c->pool->parallel_for(n, [&](int i, int wid) {
+        BinnedFrame &bf = c->binned[(size_t)i];
+        if (given) {
+            dg_frame_lists fl = given[i];
+            fill_view_trig(fl.view);
+            rc[(size_t)i] = bin_frame(sc, c->fk, fl, bf, errs[(size_t)i]);
+        } else {
+            dg_view v = views[i];
+            fill_view_trig(v);
+            dg_frame_lists fl;
+            rc[(size_t)i] = build_frame_lists(sc, W, H, v, *c->arenas[(size_t)wid], fl, errs[(size_t)i]);
+            if (!rc[(size_t)i]) rc[(size_t)i] = bin_frame(sc, c->fk, fl, bf, errs[(size_t)i]);
+        }
+    });
+    for (int i = 0; i < n; i++)
+        if (rc[(size_t)i]) return set_err(rc[(size_t)i], "frame " + std::to_string(i) + ": " + errs[(size_t)i]);
+
+    // prefix sums -> bases
+    uint64_t spans = 0, walls = 0, planes = 0, covered = 0;
+    uint32_t max_spans = 0;
+    for (int i = 0; i < n; i++) {
+        BinnedFrame &bf = c->binned[(size_t)i];
+        bf.hdr.span_base = (uint32_t)spans; bf.hdr.wall_base = (uint32_t)walls; bf.hdr.plane_base = (uint32_t)planes;
+        spans += bf.spans.size(); walls += bf.walls.size(); planes += bf.planes.size(); covered += bf.covered_pixels;
+        max_spans = std::max<uint32_t>(max_spans, (uint32_t)bf.spans.size());
+    }
+    if (spans > c->span_cap_per_batch || walls > c->wall_cap_per_batch || planes > c->plane_cap_per_batch)
+        return set_err(DG_ERR_CAPACITY, "frame lists exceed the slot's list slab");
+    const size_t off_frames = 0;
+    const size_t off_col = align_up(off_frames + (size_t)n * sizeof(DevFrame), 256);
+    const size_t off_walls = align_up(off_col + (size_t)n * (size_t)(W + 1) * 4, 256);
+    const size_t off_planes = align_up(off_walls + walls * sizeof(DevWallRec), 256);
+    const size_t off_spans = align_up(off_planes + planes * sizeof(DevPlaneRec), 256);
+    const size_t total = off_spans + spans * sizeof(DevSpan);
+    if (total > s.lists_cap) return set_err(DG_ERR_CAPACITY, "list slab too small");
+    c->pool->parallel_for(n, [&](int i, int) {
+        const BinnedFrame &bf = c->binned[(size_t)i];
+        std::memcpy(s.h_lists + off_frames + (size_t)i * sizeof(DevFrame), &bf.hdr, sizeof(DevFrame));
+        std::memcpy(s.h_lists + off_col + (size_t)i * (size_t)(W + 1) * 4, bf.col_off.data(), (size_t)(W + 1) * 4);
+        if (!bf.walls.empty()) std::memcpy(s.h_lists + off_walls + (size_t)bf.hdr.wall_base * sizeof(DevWallRec), bf.walls.data(), bf.walls.size() * sizeof(DevWallRec));
+        if (!bf.planes.empty()) std::memcpy(s.h_lists + off_planes + (size_t)bf.hdr.plane_base * sizeof(DevPlaneRec), bf.planes.data(), bf.planes.size() * sizeof(DevPlaneRec));
+        if (!bf.spans.empty()) std::memcpy(s.h_lists + off_spans + (size_t)bf.hdr.span_base * sizeof(DevSpan), bf.spans.data(), bf.spans.size() * sizeof(DevSpan));
+    });
+    RasterParams &P = s.P;
+    P.scene = c->dscene;
+    P.k = c->dk;
+    P.frames = reinterpret_cast<const DevFrame *>(s.d_lists + off_frames);
+    P.col_off = reinterpret_cast<const uint32_t *>(s.d_lists + off_col);
+    P.walls = reinterpret_cast<const DevWallRec *>(s.d_lists + off_walls);
+    P.planes = reinterpret_cast<const DevPlaneRec *>(s.d_lists + off_planes);
+    P.spans = reinterpret_cast<const DevSpan *>(s.d_lists + off_spans);
+    P.aux = s.d_aux;
+    P.fb = s.d_fb;
+    P.n_frames = n;
+    s.max_spans = max_spans; s.n_spans = spans; s.covered = covered; s.n_frames = n;
+    HIP_TRY(hipMemcpyAsync(s.d_lists, s.h_lists, total, hipMemcpyHostToDevice, s.stream));
+    return DG_OK;
+}
+
+int enqueue_kernels(Slot &s) {
+    HIP_TRY(hipEventRecord(s.ev_start, s.stream));
+    HIP_TRY(launch_setup(s.P, s.max_spans, s.stream));
+    HIP_TRY(hipEventRecord(s.ev_setup, s.stream));
+    HIP_TRY(launch_raster(s.P, s.stream));
+    HIP_TRY(hipEventRecord(s.ev_raster, s.stream));
+    s.busy = true; s.timed = true;
+    return DG_OK;
+}
+
+int check_slot(dg_ctx *c, int slot) {
+    if (!c) return set_err(DG_ERR_INVALID, "null ctx");
+    if (slot < 0 || slot >= (int)c->slots.size()) return set_err(DG_ERR_INVALID, "slot out of range");
+    return DG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *dg_last_error(void) { return t_err.c_str(); }
+const char *dg_version(void) { return "doomgpu 0.1 (gfx950)"; }
+
+int dg_scene_load_wad(const uint8_t *wad, size_t len, const char *map_name, dg_scene **out) {
+    if (!wad || !map_name || !out) return set_err(DG_ERR_INVALID, "null argument");
+    std::string err;
+    Scene *sc = load_scene_from_wad(wad, len, map_name, err);
+    if (!sc) return set_err(DG_ERR_WAD, err);
+    *out = new dg_scene{sc};
+    return DG_OK;
+}
+void dg_scene_free(dg_scene *s) { if (s) { delete s->sc; delete s; } }
+int dg_scene_player_start(const dg_scene *s, float *x, float *y, float *angle) {
+    if (!s || !x || !y || !angle) return set_err(DG_ERR_INVALID, "null argument");
+    if (!s->sc->has_start) return set_err(DG_ERR_WAD, "Could not find thing of type 1 (src/map/things.rs:46-55)");
+    *x = s->sc->start_x; *y = s->sc->start_y; *angle = s->sc->start_angle;
+    return DG_OK;
+}
+int dg_scene_floor_height_at(const dg_scene *s, float x, float y, float *h) {
+    if (!s || !h) return set_err(DG_ERR_INVALID, "null argument");
+    int sec = s->sc->sector_from_vertex(x, y);
+    if (sec < 0) return 1;
+    *h = (float)s->sc->sectors[(size_t)sec].floor_h;
+    return DG_OK;
+}
+int dg_scene_sector_count(const dg_scene *s) { return s ? (int)s->sc->sectors.size() : DG_ERR_INVALID; }
+int dg_scene_set_sector_light(dg_scene *s, int sector, int16_t light) {
+    if (!s || sector < 0 || (size_t)sector >= s->sc->sectors.size()) return set_err(DG_ERR_INVALID, "bad sector");
+    s->sc->sectors[(size_t)sector].light = light;
+    s->sc->revision++;
+    return DG_OK;
+}
+int dg_scene_mobj_count(const dg_scene *s) { return s ? (int)s->sc->mobjs.size() : DG_ERR_INVALID; }
+int dg_scene_set_mobj_state(dg_scene *s, int mobj, const char *sprite, uint8_t frame, int full_bright) {
+    if (!s || mobj < 0 || (size_t)mobj >= s->sc->mobjs.size()) return set_err(DG_ERR_INVALID, "bad map object");
+    MapObjectRec &m = s->sc->mobjs[(size_t)mobj];
+    if (!sprite) { m.sprite_frame = -1; return DG_OK; }
+    std::string err;
+    int sf = s->sc->find_or_add_sprite_frame(sprite, frame, err);
+    if (sf < 0) return set_err(DG_ERR_WAD, err);
+    m.sprite_frame = sf; m.full_bright = full_bright;
+    return DG_OK;
+}
+int dg_scene_texture_id(const dg_scene *s, const char *name) { return (s && name) ? s->sc->texture_id(name) : DG_ERR_INVALID; }
+int dg_scene_flat_id(const dg_scene *s, const char *name, float ts) { return (s && name) ? s->sc->flat_id(name, ts) : DG_ERR_INVALID; }
+int dg_scene_sprite_bitmap_id(const dg_scene *s, const char *sprite, uint8_t frame, uint8_t rot) {
+    return (s && sprite) ? s->sc->sprite_bitmap_id(sprite, frame, rot) : DG_ERR_INVALID;
+}
+int dg_scene_bitmap_size(const dg_scene *s, int bitmap, int *w, int *h) {
+    if (!s || bitmap < 0 || (size_t)bitmap >= s->sc->bitmaps.size()) return set_err(DG_ERR_INVALID, "bad bitmap id");
+    if (w) *w = s->sc->bitmaps[(size_t)bitmap].w;
+    if (h) *h = s->sc->bitmaps[(size_t)bitmap].h;
+    return DG_OK;
+}
+
+int dg_build_lists(const dg_scene *s, int width, int height, const dg_view *view, dg_frame_lists *out) {
+    if (!s || !view || !out) return set_err(DG_ERR_INVALID, "null argument");
+    static thread_local FrameArena arena;
+    dg_view v = *view;
+    fill_view_trig(v);
+    std::string err;
+    int rc = build_frame_lists(*s->sc, width, height, v, arena, *out, err);
+    return rc ? set_err(rc, err) : DG_OK;
+}
+
+int dg_create(const dg_config *cfg, dg_ctx **out) {
+    if (!cfg || !out) return set_err(DG_ERR_INVALID, "null argument");
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->width % 4 != 0 || cfg->width > 16384 || cfg->height > 16384)
+        return set_err(DG_ERR_INVALID, "width/height must be positive, width % 4 == 0, both <= 16384");
+    if (cfg->max_batch <= 0 || cfg->max_batch > 65535 || cfg->slots <= 0 || cfg->slots > 16)
+        return set_err(DG_ERR_INVALID, "max_batch must be in [1, 65535], slots in [1, 16]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(DG_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return set_err(DG_ERR_NO_DEVICE, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(DG_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 only");
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    dg_ctx *c = new dg_ctx();
+    c->cfg = *cfg;
+    c->fk = make_consts(cfg->width, cfg->height);
+    c->dk = DevConsts{c->fk.ARC, c->fk.GCFX, c->fk.CFX, c->fk.CFY, cfg->width, cfg->height};
+    int nthreads = cfg->host_threads > 0 ? cfg->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    nthreads = std::min(nthreads, 256);
+    c->pool.reset(new Pool(nthreads - 1));
+    for (int i = 0; i < nthreads; i++) c->arenas.emplace_back(new FrameArena());
+    c->binned.resize((size_t)cfg->max_batch);
+
+    const size_t W = (size_t)cfg->width, H = (size_t)cfg->height, F = (size_t)cfg->max_batch;
+    c->span_cap_per_batch = F * W * 48;       // 48 spans per column on average; real scenes use 2-20
+    c->wall_cap_per_batch = F * 4096;
+    c->plane_cap_per_batch = F * 4096;
+    const size_t lists_cap = align_up(F * sizeof(DevFrame), 256) + align_up(F * (W + 1) * 4, 256) +
+                             align_up(c->wall_cap_per_batch * sizeof(DevWallRec), 256) +
+                             align_up(c->plane_cap_per_batch * sizeof(DevPlaneRec), 256) + c->span_cap_per_batch * sizeof(DevSpan) + 1024;
+    c->slots.resize((size_t)cfg->slots);
+    for (Slot &s : c->slots) {
+        hipError_t e;
+#define CTX_TRY(expr) if ((e = (expr)) != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(e); free_ctx(c); return set_err(DG_ERR_HIP, m); }
+        CTX_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        CTX_TRY(hipEventCreate(&s.ev_start));
+        CTX_TRY(hipEventCreate(&s.ev_setup));
+        CTX_TRY(hipEventCreate(&s.ev_raster));
+        CTX_TRY(hipEventCreate(&s.ev_done));
+        CTX_TRY(hipHostMalloc((void **)&s.h_lists, lists_cap, hipHostMallocDefault));
+        CTX_TRY(hipMalloc((void **)&s.d_lists, lists_cap));
+        CTX_TRY(hipMalloc((void **)&s.d_aux, c->span_cap_per_batch * sizeof(DevSpanAux)));
+        CTX_TRY(hipMalloc((void **)&s.d_fb, F * 3 * W * H));
+#undef CTX_TRY
+        s.lists_cap = lists_cap;
+    }
+    *out = c;
+    return DG_OK;
+}
+
+void dg_destroy(dg_ctx *ctx) { free_ctx(ctx); }
+
+int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
+    if (!c || !scene) return set_err(DG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    for (Slot &s : c->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+    const Scene &sc = *scene->sc;
+    if (c->d_palette) { (void)hipFree(c->d_palette); c->d_palette = nullptr; }
+    if (c->d_texel_idx) { (void)hipFree(c->d_texel_idx); c->d_texel_idx = nullptr; }
+    if (c->d_texel_opq) { (void)hipFree(c->d_texel_opq); c->d_texel_opq = nullptr; }
+    if (c->d_flats) { (void)hipFree(c->d_flats); c->d_flats = nullptr; }
+    uint32_t pal[256];
+    for (int i = 0; i < 256; i++) pal[i] = (uint32_t)sc.palette[3 * i] | ((uint32_t)sc.palette[3 * i + 1] << 8) | ((uint32_t)sc.palette[3 * i + 2] << 16);
+    const size_t nt = std::max<size_t>(sc.texel_idx.size(), 16), nf = std::max<size_t>(sc.flat_pool.size(), 16);
+    HIP_TRY(hipMalloc((void **)&c->d_palette, sizeof pal));
+    HIP_TRY(hipMalloc((void **)&c->d_texel_idx, nt));
+    HIP_TRY(hipMalloc((void **)&c->d_texel_opq, nt));
+    HIP_TRY(hipMalloc((void **)&c->d_flats, nf));
+    HIP_TRY(hipMemcpy(c->d_palette, pal, sizeof pal, hipMemcpyHostToDevice));
+    if (!sc.texel_idx.empty()) {
+        HIP_TRY(hipMemcpy(c->d_texel_idx, sc.texel_idx.data(), sc.texel_idx.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_texel_opq, sc.texel_opq.data(), sc.texel_opq.size(), hipMemcpyHostToDevice));
+    }
+    if (!sc.flat_pool.empty()) HIP_TRY(hipMemcpy(c->d_flats, sc.flat_pool.data(), sc.flat_pool.size(), hipMemcpyHostToDevice));
+    const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
+    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, sky.texel_off, sky.w, sky.h};
+    c->scene = &sc;
+    return DG_OK;
+}
+
+int dg_submit_views(dg_ctx *c, int slot, const dg_view *views, int n) {
+    int rc = check_slot(c, slot);
+    if (rc) return rc;
+    if (!views) return set_err(DG_ERR_INVALID, "null views");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    Slot &s = c->slots[(size_t)slot];
+    if (s.busy) { HIP_TRY(hipStreamSynchronize(s.stream)); s.busy = false; }
+    rc = build_batch(c, s, views, nullptr, n);
+    if (rc) return rc;
+    return enqueue_kernels(s);
+}
+
+int dg_wait(dg_ctx *c, int slot) {
+    int rc = check_slot(c, slot);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    Slot &s = c->slots[(size_t)slot];
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    s.busy = false;
+    return DG_OK;
+}
+
+int dg_slot_framebuffer(dg_ctx *c, int slot, void **p) {
+    int rc = check_slot(c, slot);
+    if (rc) return rc;
+    if (!p) return set_err(DG_ERR_INVALID, "null argument");
+    *p = c->slots[(size_t)slot].d_fb;
+    return DG_OK;
+}
+
+int dg_readback(dg_ctx *c, int slot, int first, int count, uint8_t *out) {
+    int rc = check_slot(c, slot);
+    if (rc) return rc;
+    Slot &s = c->slots[(size_t)slot];
+    if (!out || first < 0 || count < 0 || first + count > s.n_frames) return set_err(DG_ERR_INVALID, "bad readback range");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const size_t fsz = (size_t)3 * (size_t)c->cfg.width * (size_t)c->cfg.height;
+    HIP_TRY(hipMemcpyAsync(out, s.d_fb + (size_t)first * fsz, (size_t)count * fsz, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    s.busy = false;
+    return DG_OK;
+}
+
+int dg_render_views(dg_ctx *c, const dg_view *views, int n, uint8_t *out) {
+    int rc = dg_submit_views(c, 0, views, n);
+    if (rc) return rc;
+    if (out) return dg_readback(c, 0, 0, n, out);
+    return dg_wait(c, 0);
+}
+
+int dg_prepare_views(dg_ctx *c, int slot, const dg_view *views, int n) {
+    int rc = check_slot(c, slot);
+    if (rc) return rc;
+    if (!views) return set_err(DG_ERR_INVALID, "null views");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    Slot &s = c->slots[(size_t)slot];
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    s.busy = false;
+    rc = build_batch(c, s, views, nullptr, n);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    return DG_OK;
+}
+
+int dg_replay_slot(dg_ctx *c, int slot) {
+    int rc = check_slot(c, slot);
+    if (rc) return rc;
+    Slot &s = c->slots[(size_t)slot];
+    if (s.n_frames <= 0) return set_err(DG_ERR_INVALID, "slot has no prepared lists");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    return enqueue_kernels(s);
+}
+
+int dg_draw_lists(dg_ctx *c, int slot, const dg_frame_lists *frames, int n, uint8_t *out) {
+    int rc = check_slot(c, slot);
+    if (rc) return rc;
+    if (!frames) return set_err(DG_ERR_INVALID, "null frames");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    Slot &s = c->slots[(size_t)slot];
+    if (s.busy) { HIP_TRY(hipStreamSynchronize(s.stream)); s.busy = false; }
+    rc = build_batch(c, s, nullptr, frames, n);
+    if (rc) return rc;
+    rc = enqueue_kernels(s);
+    if (rc) return rc;
+    if (out) return dg_readback(c, slot, 0, n, out);
+    return dg_wait(c, slot);
+}
+
+int dg_slot_timing(dg_ctx *c, int slot, dg_timing *out) {
+    int rc = check_slot(c, slot);
+    if (rc) return rc;
+    if (!out) return set_err(DG_ERR_INVALID, "null argument");
+    Slot &s = c->slots[(size_t)slot];
+    if (!s.timed) return set_err(DG_ERR_INVALID, "slot has not run yet");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipEventSynchronize(s.ev_raster));
+    std::memset(out, 0, sizeof *out);
+    HIP_TRY(hipEventElapsedTime(&out->setup_ms, s.ev_start, s.ev_setup));
+    HIP_TRY(hipEventElapsedTime(&out->raster_ms, s.ev_setup, s.ev_raster));
+    HIP_TRY(hipEventElapsedTime(&out->total_ms, s.ev_start, s.ev_raster));
+    out->n_spans = s.n_spans; out->n_frames = (uint64_t)s.n_frames; out->covered_pixels = s.covered;
+    return DG_OK;
+}
+
+}  // extern "C"

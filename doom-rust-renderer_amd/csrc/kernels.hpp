@@ -1,0 +1,25 @@
+// kernels.hpp — launch interface between the context (host) and kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "lists_dev.h"
+
+namespace dg {
+
+struct RasterParams {
+    DevScene scene;
+    DevConsts k;
+    const DevFrame *frames;      // [n_frames]
+    const uint32_t *col_off;     // [n_frames][W + 1]
+    const DevSpan *spans;
+    DevSpanAux *aux;
+    const DevWallRec *walls;
+    const DevPlaneRec *planes;
+    uint8_t *fb;                 // n_frames x 3*W*H, RGB24
+    int32_t n_frames;
+};
+
+hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hipStream_t stream);
+hipError_t launch_raster(const RasterParams &P, hipStream_t stream);
+
+}  // namespace dg
