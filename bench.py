@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the MI355X rasteriser on the fixed e1m1 camera path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1280 --height 800] [--batch 250]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Workload (config.workload): BASELINE config 2 — the 1 000-frame scripted camera path through the e1m1-like
+map, rendered natively at 1280x800 (the size the ">= 10 000 fps" target is quoted on), one MI355X per rank.  No id
+WAD can be shipped, so the map is the committed synthetic IWAD (seed 1993) and `data` says "synthetic".
+
+A *step* is one pass of the hot path over one batch of `--batch` consecutive path frames whose seg / visplane /
+sprite lists are already resident in HBM (4 slots x 250 frames = the whole path).  `value` = frames / time over exactly
+K steps: span-setup + tile-raster kernels producing K*batch RGB24 frames in HBM.  The PCIe-inclusive number (host list
+generation on T threads + H2D + the same kernels, double-buffered) is reported next to it as `e2e` and is never `value`.
+
+Multi-GPU: the path shards with no exchange step — rank r renders its own camera path (same map, route rotated by
+r/N and reversed for odd r) on GPU LOCAL_RANK; there is NO data-path collective and no RCCL.  torch.distributed (gloo,
+CPU tensors) is used only for the timing barrier and the MAX over ranks; value = sum of frames / max time (weak scaling).
+
+roofline: dominant kernel dg_raster_tiles, HBM-bound model.  achieved = algorithmic bytes per launch / mean launch
+duration from HIP events recorded on the kernel's own stream during the timed steps (dg_slot_timing).  Algorithmic
+bytes per frame = 3*W*H (RGB24 stored once) + W*H (one texel byte per pixel) + list bytes read (24 B per span incl. aux,
+48 B per wall record, 16 B per plane, 4*(W+1) column index) — SURVEY.md §8d, DESIGN.md "Roofline accounting".
+cpu_baseline: the CPU oracle (oracle/doomref.c, a port of the reference renderer) on 1 host core over a bounded
+sample of the same frames at the same size (rank 0, N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def rank_route(route, rank: int, world: int):
+    """Camera path of one rank: same closed route, start rotated by rank/world, direction reversed for odd ranks."""
+    n = len(route)
+    k = (rank * n) // max(world, 1)
+    r = route[k:] + route[:k]
+    return r[::-1] if rank % 2 else r
+
+
+def aggregate_fps(frames_per_rank: int, world: int, max_seconds: float) -> float:
+    return frames_per_rank * world / max_seconds
+
+
+def dist_max(seconds: float, dist) -> float:
+    if dist is None:
+        return seconds
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--batch", type=int, default=250)
+    ap.add_argument("--slots", type=int, default=4)
+    ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=4, help="cpu_baseline renders every n-th path frame")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # torch first: its bundled HIP runtime must be the one libdoomgpu.so binds to (same soname, loaded once).
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")     # timing barrier / MAX only; the data path has no collective
+    torch.cuda.set_device(local_rank)
+
+    import numpy as np
+    dg = importlib.import_module("doom-rust-renderer_amd")
+    sw = importlib.import_module("doom-rust-renderer_amd.synth_wad")
+    cp = importlib.import_module("doom-rust-renderer_amd.camera_path")
+
+    W, H, B = args.width, args.height, args.batch
+    wad = sw.build_synth_iwad(1993)
+    scene = dg.Scene(wad, "e1m1")
+    route = rank_route(sw.synth_route(1993), rank, world)
+    path = cp.make_camera_path(route, lambda x, y, d: scene.floor_height_at(x, y, d), 1000)
+    n_slots = max(1, min(args.slots, (1000 + B - 1) // B))
+    ctx = dg.Context(W, H, max_batch=B, slots=n_slots, device=local_rank, host_threads=args.host_threads)
+    ctx.upload_scene(scene)
+
+    batches = [np.concatenate([path, path])[b0:b0 + B] for b0 in range(0, n_slots * B, B)]
+    views = [dg.make_views(b) for b in batches]
+    for s in range(n_slots):                         # lists resident in HBM before any timed region
+        ctx.prepare(s, views[s])
+
+    def sync_all():
+        for s in range(n_slots):
+            ctx.wait(s)
+        torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ---- resident-list steps: warmup, then exactly K timed steps -------------------------------------------------
+    for i in range(args.warmup):
+        ctx.replay(i % n_slots)
+    sync_all()
+    barrier()
+    sync_all()
+    raster_ms, setup_ms, alg_bytes = [], [], []
+    stats = {}
+
+    def collect(slot):
+        t = ctx.timing(slot)
+        raster_ms.append(t["raster_ms"])
+        setup_ms.append(t["setup_ms"])
+        nf = t["n_frames"]
+        alg_bytes.append(nf * (3 * W * H + W * H + 4 * (W + 1)) + 24 * t["n_spans"] + 48 * t["n_walls"] + 16 * t["n_planes"])
+        stats.update(t)
+
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        s = i % n_slots
+        if i >= n_slots:
+            ctx.wait(s)
+            collect(s)
+        ctx.replay(s)
+    sync_all()
+    barrier()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    for i in range(max(0, args.steps - n_slots), args.steps):
+        collect(i % n_slots)
+    elapsed = dist_max(elapsed, dist)
+    frames_per_rank = args.steps * B
+    value = aggregate_fps(frames_per_rank, world, elapsed)
+
+    # ---- PCIe-inclusive end-to-end (host list generation + H2D + kernels), double-buffered ----------------------
+    e2e = None
+    if not args.no_e2e:
+        nb = max(4, min(12, args.steps))
+        for i in range(2):
+            ctx.submit(i % n_slots, views[i % n_slots])
+        sync_all()
+        barrier()
+        host_ms = []
+        t1 = time.perf_counter()
+        for i in range(nb):
+            s = i % n_slots
+            ctx.submit(s, views[s])
+            host_ms.append(ctx.timing(s)["host_ms"])
+        sync_all()
+        barrier()
+        e2e_s = dist_max(time.perf_counter() - t1, dist)
+        e2e = {"value": aggregate_fps(nb * B, world, e2e_s), "unit": "frames/s",
+               "includes": "host list generation + pinned staging + H2D + setup/raster kernels, frames left in HBM",
+               "host_threads": args.host_threads or (os.cpu_count() or 1), "host_ms_per_batch": float(np.mean(host_ms)),
+               "list_bytes_per_frame": int(stats.get("list_bytes", 0) // max(1, stats.get("n_frames", 1)))}
+
+    # ---- roofline of the dominant kernel ----------------------------------------------------------------------------
+    mean_raster_s = float(np.mean(raster_ms)) / 1e3
+    achieved = float(np.mean(alg_bytes)) / mean_raster_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = f"{W}x{H}x{B}"
+            if key in tj:
+                traffic = tj[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "dg_raster_tiles", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                "frac": achieved / 8000.0, "traffic": traffic, "algorithmic_bytes_per_launch": float(np.mean(alg_bytes)),
+                "mean_launch_ms": mean_raster_s * 1e3, "setup_kernel_mean_ms": float(np.mean(setup_ms)),
+                "frames_per_launch": B, "pixels_per_s": B * W * H / mean_raster_s}
+
+    # ---- CPU baseline (oracle = port of the reference renderer), rank 0, N = 1 only ---------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import doomref
+        osc = doomref.Scene(wad, "e1m1")
+        idx = list(range(0, 1000, max(1, args.cpu_sample)))
+        tc = time.perf_counter()
+        for i in idx:
+            osc.render(W, H, path[i])
+        dt = time.perf_counter() - tc
+        cpu = {"value": len(idx) / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"every {args.cpu_sample}th frame of the same 1000-frame path at {W}x{H} ({len(idx)} frames, {dt:.1f} s), "
+                         "oracle/doomref.c -O2 -ffp-contract=off, cos/sin hoisted per frame",
+               "host_cpus": os.cpu_count()}
+        # parity spot check on the frames just rendered by the GPU (slot 0 holds path[0:B])
+        ctx.replay(0)
+        ctx.wait(0)
+        got = ctx.readback(0, 0, 1)[0]
+        ref = np.frombuffer(osc.render(W, H, path[0]), dtype=np.uint8).reshape(H, W, 3)
+        cpu["gpu_frame0_bit_exact"] = bool(np.array_equal(got, ref))
+
+    if rank == 0:
+        line = {
+            "metric": "frames/sec (fixed e1m1 camera path)", "value": value, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic e1m1-like IWAD (seed 1993), 1000-frame scripted camera path, {W}x{H} native, "
+                                   f"{B} frames per step, lists resident in HBM", "width": W, "height": H, "frames_per_step": B,
+                       "slots": n_slots, "parallelism": f"{world} independent camera path(s), one per GPU, no collective"},
+            "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e,
+        }
+        print(json.dumps(line))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

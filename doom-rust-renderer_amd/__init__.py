@@ -40,7 +40,9 @@ class DgConfig(ctypes.Structure):
 
 class DgTiming(ctypes.Structure):
     _fields_ = [("setup_ms", ctypes.c_float), ("raster_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
-                ("n_spans", ctypes.c_uint64), ("n_frames", ctypes.c_uint64), ("covered_pixels", ctypes.c_uint64)]
+                ("host_ms", ctypes.c_float),
+                ("n_spans", ctypes.c_uint64), ("n_frames", ctypes.c_uint64), ("covered_pixels", ctypes.c_uint64),
+                ("n_walls", ctypes.c_uint64), ("n_planes", ctypes.c_uint64), ("list_bytes", ctypes.c_uint64)]
 
 
 class DgBitmapColumn(ctypes.Structure):

@@ -12,6 +12,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
+#include <chrono>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -106,8 +107,9 @@ struct Slot {
     // last submission
     RasterParams P{};
     uint32_t max_spans = 0;
-    uint64_t n_spans = 0, covered = 0;
+    uint64_t n_spans = 0, covered = 0, list_bytes = 0, n_walls = 0, n_planes = 0;
     int n_frames = 0;
+    float host_ms = 0.0f;         // list generation + binning + packing of the last submission
     bool busy = false, timed = false;
 };
 
@@ -123,6 +125,7 @@ struct dg_ctx {
     uint8_t *d_texel_idx = nullptr, *d_texel_opq = nullptr, *d_flats = nullptr;
     DevScene dscene{};
     std::vector<Slot> slots;
+    hipEvent_t last_raster = nullptr;   // raster kernels of different slots run back to back; list uploads overlap them
     std::unique_ptr<Pool> pool;
     std::vector<std::unique_ptr<FrameArena>> arenas;   // one per worker (+ caller)
     std::vector<BinnedFrame> binned;                   // one per frame of a batch
@@ -157,6 +160,7 @@ void free_ctx(dg_ctx *c) {
 
 // Build + bin the lists of n views in parallel, pack them into the slot's pinned slab, fill slot.P.
 int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *given, int n) {
+    const auto t0 = std::chrono::steady_clock::now();
     if (!c->scene) return set_err(DG_ERR_INVALID, "no scene uploaded (dg_upload_scene)");
     if (n <= 0 || n > c->cfg.max_batch) return set_err(DG_ERR_CAPACITY, "batch size outside [1, max_batch]");
     const Scene &sc = *c->scene;
@@ -217,17 +221,23 @@ int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *
     P.aux = s.d_aux;
     P.fb = s.d_fb;
     P.n_frames = n;
-    s.max_spans = max_spans; s.n_spans = spans; s.covered = covered; s.n_frames = n;
+    s.max_spans = max_spans; s.n_spans = spans; s.covered = covered; s.n_frames = n; s.n_walls = walls; s.n_planes = planes;
+    s.list_bytes = total;
+    s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIP_TRY(hipMemcpyAsync(s.d_lists, s.h_lists, total, hipMemcpyHostToDevice, s.stream));
     return DG_OK;
 }
 
-int enqueue_kernels(Slot &s) {
+int enqueue_kernels(dg_ctx *c, Slot &s) {
+    // The slot's H2D copy is already queued on its stream and may overlap the previous slot's kernels; the kernels
+    // themselves are chained behind the previous submission's raster kernel (they fill the chip on their own).
+    if (c->last_raster && c->last_raster != s.ev_raster) HIP_TRY(hipStreamWaitEvent(s.stream, c->last_raster, 0));
     HIP_TRY(hipEventRecord(s.ev_start, s.stream));
     HIP_TRY(launch_setup(s.P, s.max_spans, s.stream));
     HIP_TRY(hipEventRecord(s.ev_setup, s.stream));
     HIP_TRY(launch_raster(s.P, s.stream));
     HIP_TRY(hipEventRecord(s.ev_raster, s.stream));
+    c->last_raster = s.ev_raster;
     s.busy = true; s.timed = true;
     return DG_OK;
 }
@@ -333,7 +343,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     c->binned.resize((size_t)cfg->max_batch);
 
     const size_t W = (size_t)cfg->width, H = (size_t)cfg->height, F = (size_t)cfg->max_batch;
-    c->span_cap_per_batch = F * W * 48;       // 48 spans per column on average; real scenes use 2-20
+    c->span_cap_per_batch = F * W * 24;       // 24 spans per column on average; real scenes use 2-8
     c->wall_cap_per_batch = F * 4096;
     c->plane_cap_per_batch = F * 4096;
     const size_t lists_cap = align_up(F * sizeof(DevFrame), 256) + align_up(F * (W + 1) * 4, 256) +
@@ -398,7 +408,7 @@ int dg_submit_views(dg_ctx *c, int slot, const dg_view *views, int n) {
     if (s.busy) { HIP_TRY(hipStreamSynchronize(s.stream)); s.busy = false; }
     rc = build_batch(c, s, views, nullptr, n);
     if (rc) return rc;
-    return enqueue_kernels(s);
+    return enqueue_kernels(c, s);
 }
 
 int dg_wait(dg_ctx *c, int slot) {
@@ -459,7 +469,7 @@ int dg_replay_slot(dg_ctx *c, int slot) {
     Slot &s = c->slots[(size_t)slot];
     if (s.n_frames <= 0) return set_err(DG_ERR_INVALID, "slot has no prepared lists");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    return enqueue_kernels(s);
+    return enqueue_kernels(c, s);
 }
 
 int dg_draw_lists(dg_ctx *c, int slot, const dg_frame_lists *frames, int n, uint8_t *out) {
@@ -471,7 +481,7 @@ int dg_draw_lists(dg_ctx *c, int slot, const dg_frame_lists *frames, int n, uint
     if (s.busy) { HIP_TRY(hipStreamSynchronize(s.stream)); s.busy = false; }
     rc = build_batch(c, s, nullptr, frames, n);
     if (rc) return rc;
-    rc = enqueue_kernels(s);
+    rc = enqueue_kernels(c, s);
     if (rc) return rc;
     if (out) return dg_readback(c, slot, 0, n, out);
     return dg_wait(c, slot);
@@ -490,6 +500,8 @@ int dg_slot_timing(dg_ctx *c, int slot, dg_timing *out) {
     HIP_TRY(hipEventElapsedTime(&out->raster_ms, s.ev_setup, s.ev_raster));
     HIP_TRY(hipEventElapsedTime(&out->total_ms, s.ev_start, s.ev_raster));
     out->n_spans = s.n_spans; out->n_frames = (uint64_t)s.n_frames; out->covered_pixels = s.covered;
+    out->host_ms = s.host_ms; out->list_bytes = s.list_bytes;
+    out->n_walls = s.n_walls; out->n_planes = s.n_planes;
     return DG_OK;
 }
 

@@ -493,7 +493,7 @@ struct Walker {
                 if (r.bitmap >= 0 && r.n_cols > 0) emit_draw(r);
                 r.state = ST_DRAWN;
             }
-            emit_draw(recs[mi]);
+            if (recs[mi].n_cols > 0) emit_draw(recs[mi]);
         }
         for (size_t ri = n_wall_recs; ri-- > 0;) {                   // draw_remaining_segs, segs.rs:593-597
             Rec &r = recs[ri];

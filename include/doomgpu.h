@@ -163,7 +163,9 @@ const char *dg_version(void);
 /* Timing of the last dg_replay_slot / submit on a slot, from HIP events on the slot's stream (ms). */
 typedef struct dg_timing {
     float setup_ms, raster_ms, total_ms;
+    float host_ms;            /* host list generation + binning + packing of that submission (wall clock) */
     uint64_t n_spans, n_frames, covered_pixels;
+    uint64_t n_walls, n_planes, list_bytes; /* drawn records / visplanes, bytes of lists copied to HBM */
 } dg_timing;
 int dg_slot_timing(dg_ctx *ctx, int slot, dg_timing *out);
 

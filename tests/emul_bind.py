@@ -1,0 +1,46 @@
+"""ctypes binding of the CPU test harness tests/emul/libdgemul.so (product host logic + kernel bodies on the CPU)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "emul", "libdgemul.so")
+_lib = None
+
+
+class DgView(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in "x y angle floor_height cos_a sin_a cos_na sin_na timestamp".split()] + \
+               [("trig_valid", ctypes.c_int32)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "emul"), "-s"])
+        L = ctypes.CDLL(_LIB)
+        L.emul_load.restype = ctypes.c_void_p
+        L.emul_load.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.emul_free.argtypes = [ctypes.c_void_p]
+        L.emul_last_error.restype = ctypes.c_char_p
+        L.emul_render.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(DgView), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        _lib = L
+    return _lib
+
+
+class EmulScene:
+    def __init__(self, wad: bytes, map_name="e1m1"):
+        self._h = lib().emul_load(wad, len(wad), map_name.encode())
+        if not self._h:
+            raise RuntimeError(lib().emul_last_error().decode())
+
+    def render(self, W, H, rec, timestamp=0.0):
+        v = DgView(float(rec[0]), float(rec[1]), float(rec[2]), float(rec[7]), float(rec[3]), float(rec[4]), float(rec[5]), float(rec[6]),
+                   float(timestamp), 1)
+        buf = np.empty(3 * W * H, dtype=np.uint8)
+        st = (ctypes.c_uint64 * 4)()
+        rc = lib().emul_render(self._h, W, H, ctypes.byref(v), buf.ctypes.data_as(ctypes.c_void_p), st)
+        if rc:
+            raise RuntimeError(f"emul rc {rc}: {lib().emul_last_error().decode()}")
+        return buf.tobytes(), list(st)

@@ -1,0 +1,220 @@
+"""GPU tier: the HIP path, called through the C-ABI, against the oracle (bit-exact RGB24) and the golden fixtures."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import sha
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene1993(dg, wad1993):
+    return dg.Scene(wad1993, "e1m1")
+
+
+@pytest.fixture(scope="module")
+def scene1994(dg, wad1994):
+    return dg.Scene(wad1994, "e1m1")
+
+
+def make_ctx(dg, scene, W, H, batch, slots=2):
+    ctx = dg.Context(W, H, max_batch=batch, slots=slots)
+    ctx.upload_scene(scene)
+    return ctx
+
+
+def test_native_library_is_loaded(dg):
+    dg.lib()
+    assert "libdoomgpu.so" in open("/proc/self/maps").read()
+
+
+def test_full_camera_path_320x200_bit_exact(dg, scene1993, oracle_scene1993, path1993):
+    """BASELINE config 1: 1 000-frame scripted path at 320x200, every frame byte-compared with the CPU oracle."""
+    W, H, B = 320, 200, 250
+    ctx = make_ctx(dg, scene1993, W, H, B)
+    for b0 in range(0, 1000, B):
+        out = ctx.render(dg.make_views(path1993[b0:b0 + B]))
+        for k in range(B):
+            ref = np.frombuffer(oracle_scene1993.render(W, H, path1993[b0 + k]), dtype=np.uint8).reshape(H, W, 3)
+            assert np.array_equal(out[k], ref), f"frame {b0 + k}"
+    ctx.close()
+
+
+@pytest.mark.parametrize("W,H,stride", [(1280, 800, 20), (1024, 768, 100), (2560, 1600, 250), (64, 48, 50), (132, 67, 91)])
+def test_sampled_path_bit_exact(dg, scene1993, oracle_scene1993, path1993, W, H, stride):
+    idx = list(range(0, 1000, stride))
+    ctx = make_ctx(dg, scene1993, W, H, len(idx))
+    out = ctx.render(dg.make_views(path1993[idx]))
+    for k, i in enumerate(idx):
+        ref = np.frombuffer(oracle_scene1993.render(W, H, path1993[i]), dtype=np.uint8).reshape(H, W, 3)
+        assert np.array_equal(out[k], ref), f"frame {i} at {W}x{H}"
+    ctx.close()
+
+
+def test_golden_hashes_on_gpu(dg, scene1993, path1993, golden_frames):
+    for size, frames in golden_frames[1993].items():
+        ts = 0.0
+        if "@t=" in size:
+            size, t = size.split("@t=")
+            ts = float(t)
+        W, H = map(int, size.split("x"))
+        idx = sorted(int(i) for i in frames)
+        ctx = make_ctx(dg, scene1993, W, H, len(idx), slots=1)
+        out = ctx.render(dg.make_views(path1993[idx], timestamp=ts))
+        key = size if ts == 0.0 else f"{size}@t={ts}"
+        for k, i in enumerate(idx):
+            assert sha(out[k].tobytes()) == frames[str(i)], f"{key} frame {i}"
+        ctx.close()
+
+
+def test_heavy_map_bit_exact(dg, scene1994, oracle_scene1994, path1994, golden_frames):
+    W, H = 320, 200
+    idx = list(range(0, 1000, 8))
+    ctx = make_ctx(dg, scene1994, W, H, len(idx))
+    out = ctx.render(dg.make_views(path1994[idx]))
+    for k, i in enumerate(idx):
+        ref = np.frombuffer(oracle_scene1994.render(W, H, path1994[i]), dtype=np.uint8).reshape(H, W, 3)
+        assert np.array_equal(out[k], ref), f"frame {i}"
+    for i, h in golden_frames[1994]["320x200"].items():
+        assert sha(out[idx.index(int(i))].tobytes()) == h
+    ctx.close()
+
+
+def _deep_copy_lists(dg, fl):
+    """dg_build_lists returns pointers into a per-thread arena; copy them so several frames can coexist."""
+    keep = []
+
+    def cp(ptr, n, typ):
+        arr = (typ * max(n, 1))()
+        if n:
+            ctypes.memmove(arr, ptr, n * ctypes.sizeof(typ))
+        keep.append(arr)
+        return ctypes.cast(arr, ctypes.POINTER(typ))
+
+    out = dg.DgFrameLists()
+    out.view = fl.view
+    out.renders, out.n_renders = cp(fl.renders, fl.n_renders, dg.DgBitmapRender), fl.n_renders
+    out.columns, out.n_columns = cp(fl.columns, fl.n_columns, dg.DgBitmapColumn), fl.n_columns
+    out.visplanes, out.n_visplanes = cp(fl.visplanes, fl.n_visplanes, dg.DgVisplane), fl.n_visplanes
+    out.plane_tb, out.n_plane_tb = cp(fl.plane_tb, fl.n_plane_tb, ctypes.c_int16), fl.n_plane_tb
+    out.order, out.n_order = cp(fl.order, fl.n_order, dg.DgDrawCmd), fl.n_order
+    return out, keep
+
+
+def test_list_path_equals_full_path(dg, scene1993, oracle_scene1993, path1993):
+    """dg_draw_lists (caller-supplied BitmapRender / Visplane lists, the 'Rust host feeds lists' boundary)."""
+    W, H = 320, 200
+    idx = [0, 100, 297, 323, 623, 728, 900]
+    views = dg.make_views(path1993[idx])
+    frames = (dg.DgFrameLists * len(idx))()
+    keep = []
+    for k in range(len(idx)):
+        fl, kp = _deep_copy_lists(dg, scene1993.build_lists(W, H, views[k]))
+        frames[k] = fl
+        keep.append(kp)
+    ctx = make_ctx(dg, scene1993, W, H, len(idx))
+    out = ctx.draw_lists(1, frames)
+    for k, i in enumerate(idx):
+        ref = np.frombuffer(oracle_scene1993.render(W, H, path1993[i]), dtype=np.uint8).reshape(H, W, 3)
+        assert np.array_equal(out[k], ref), f"frame {i}"
+    # malformed caller lists are rejected, not rendered
+    bad = (dg.DgFrameLists * 1)()
+    bad[0] = frames[0]
+    bad[0].n_columns = 1
+    with pytest.raises(dg.DoomGpuError) as e:
+        ctx.draw_lists(0, bad)
+    assert e.value.code == dg.DG_ERR_INVALID
+    ctx.close()
+
+
+def test_batch_slot_and_replay_independence(dg, scene1993, path1993):
+    """Size-independent properties at the bench size: a frame's bytes do not depend on its batch position, slot,
+    batch size or on replaying the same lists (idempotence)."""
+    W, H = 1280, 800
+    ctx = make_ctx(dg, scene1993, W, H, 32, slots=2)
+    a = ctx.render(dg.make_views(path1993[0:32]))
+    perm = np.arange(32)[::-1].copy()
+    ctx.submit(1, dg.make_views(path1993[perm]))
+    ctx.wait(1)
+    b = ctx.readback(1, 0, 32)
+    assert np.array_equal(a, b[perm])
+    single = ctx.render(dg.make_views(path1993[7:8]))
+    assert np.array_equal(single[0], a[7])
+    ctx.prepare(0, dg.make_views(path1993[0:32]))
+    ctx.replay(0); ctx.wait(0)
+    r1 = ctx.readback(0, 0, 32)
+    ctx.replay(0); ctx.wait(0)
+    r2 = ctx.readback(0, 0, 32)
+    assert np.array_equal(r1, a) and np.array_equal(r2, a)
+    t = ctx.timing(0)
+    assert t["n_frames"] == 32 and t["raster_ms"] > 0
+    ctx.close()
+
+
+def test_checksum_of_checksums_1280x800(dg, scene1993, oracle_scene1993, path1993):
+    """BASELINE config 2 (bench size): every 10th frame of the path at 1280x800 against the oracle, plus a digest over
+    the whole 1 000-frame run that must be reproducible between two passes (different batch splits)."""
+    import hashlib
+    W, H = 1280, 800
+    ctx = make_ctx(dg, scene1993, W, H, 100, slots=1)
+    digests = []
+    for b0 in range(0, 1000, 100):
+        out = ctx.render(dg.make_views(path1993[b0:b0 + 100]))
+        digests += [hashlib.sha256(out[k].tobytes()).digest() for k in range(100)]
+        for k in range(0, 100, 10):
+            ref = np.frombuffer(oracle_scene1993.render(W, H, path1993[b0 + k]), dtype=np.uint8).reshape(H, W, 3)
+            assert np.array_equal(out[k], ref), f"frame {b0 + k}"
+    ctx.close()
+    total1 = hashlib.sha256(b"".join(digests)).hexdigest()
+    ctx = make_ctx(dg, scene1993, W, H, 40, slots=1)
+    digests2 = []
+    for b0 in range(0, 1000, 40):
+        out = ctx.render(dg.make_views(path1993[b0:b0 + 40]))
+        digests2 += [hashlib.sha256(out[k].tobytes()).digest() for k in range(len(out))]
+    ctx.close()
+    assert hashlib.sha256(b"".join(digests2)).hexdigest() == total1
+
+
+def test_edge_views(dg, scene1993, oracle_scene1993, campath_mod):
+    """Viewpoints in the void / inside walls / far outside the map (mostly empty span lists) and odd eye heights."""
+    W, H = 320, 200
+    rng = np.random.default_rng(5)
+    recs, refs = [], []
+    for _ in range(200):
+        x, y = float(rng.uniform(-600, 4700)), float(rng.uniform(-600, 3700))
+        rec = campath_mod.view_record(x, y, float(rng.uniform(-7, 7)), float(rng.choice([-64, -8, 0, 24, 200])))
+        try:
+            refs.append(np.frombuffer(oracle_scene1993.render(W, H, rec), dtype=np.uint8).reshape(H, W, 3))
+            recs.append(rec)
+        except Exception:
+            pass
+    recs.append(campath_mod.view_record(-30000.0, -30000.0, 0.3, 0.0))      # nothing in view: all-black frame
+    refs.append(np.frombuffer(oracle_scene1993.render(W, H, recs[-1]), dtype=np.uint8).reshape(H, W, 3))
+    ctx = make_ctx(dg, scene1993, W, H, len(recs), slots=1)
+    out = ctx.render(dg.make_views(np.array(recs)))
+    for k in range(len(recs)):
+        assert np.array_equal(out[k], refs[k]), f"view {k}: {recs[k][:3]}"
+    with pytest.raises(dg.DoomGpuError) as e:
+        ctx.render(dg.make_views(np.array(recs + recs)))                    # more frames than max_batch
+    assert e.value.code == dg.DG_ERR_CAPACITY
+    ctx.close()
+
+
+def test_sector_light_snapshot_hook(dg, wad1993, path1993):
+    """Per-frame game-state input (light thinkers mutate sector.light_level, src/lights.rs): changing it changes the
+    frame, restoring it restores the bytes."""
+    sc = dg.Scene(wad1993, "e1m1")
+    ctx = make_ctx(dg, sc, 320, 200, 1, slots=1)
+    v = dg.make_views(path1993[5:6])
+    base = ctx.render(v)
+    n = dg.lib().dg_scene_sector_count(sc._h)
+    for s in range(n):
+        dg.lib().dg_scene_set_sector_light(sc._h, s, 40)
+    dark = ctx.render(v)
+    assert int(dark.astype(np.int64).sum()) < int(base.astype(np.int64).sum())
+    sc2 = dg.Scene(wad1993, "e1m1")
+    ctx.upload_scene(sc2)
+    assert np.array_equal(ctx.render(v), base)
+    ctx.close()

@@ -1,0 +1,135 @@
+"""CPU tier for the PRODUCT's host side: the C-ABI library loads and exports what include/doomgpu.h declares,
+the scene loader agrees with the oracle, and list generation + column binning + the kernel bodies (compiled for
+the CPU by tests/emul, never shipped) reproduce the oracle's frames byte for byte.  No compute call goes to a GPU."""
+import ctypes
+import subprocess
+
+import numpy as np
+import pytest
+
+import emul_bind
+
+
+def test_library_exports_every_declared_symbol(dg):
+    dg.build()
+    names = dg.declared_symbols()
+    assert len(names) >= 25
+    out = subprocess.run(["nm", "-D", "--defined-only", dg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    missing = [n for n in names if n not in exported]
+    assert not missing, missing
+    assert set(dg._SIGNATURES) == set(names)          # the binding covers the whole header
+    L = dg.lib()
+    assert L.dg_version().startswith(b"doomgpu")
+
+
+def test_no_cpu_fallback(dg, gpu_available):
+    """Without a gfx950 device dg_create must fail loudly (DG_ERR_NO_DEVICE), never fall back."""
+    if gpu_available:
+        pytest.skip("a GPU is present")
+    with pytest.raises(dg.DoomGpuError) as e:
+        dg.Context(320, 200, max_batch=1, slots=1)
+    assert e.value.code == dg.DG_ERR_NO_DEVICE
+
+
+def test_create_argument_checks(dg):
+    for (w, h, b, s) in [(0, 200, 1, 1), (322, 200, 1, 1), (320, 0, 1, 1), (320, 200, 0, 1), (320, 200, 1, 0), (320, 200, 1, 99)]:
+        with pytest.raises(dg.DoomGpuError) as e:
+            dg.Context(w, h, max_batch=b, slots=s)
+        assert e.value.code == dg.DG_ERR_INVALID
+
+
+def test_scene_loader_errors(dg, wad1993):
+    with pytest.raises(dg.DoomGpuError) as e:                      # wad.rs:90-92: only IWAD
+        dg.Scene(b"PWAD" + wad1993[4:], "e1m1")
+    assert e.value.code == dg.DG_ERR_WAD
+    with pytest.raises(dg.DoomGpuError) as e:                      # wad.rs:182: unknown map panics
+        dg.Scene(wad1993, "e9m9")
+    assert e.value.code == dg.DG_ERR_WAD
+    with pytest.raises(dg.DoomGpuError):
+        dg.Scene(wad1993[:2000], "e1m1")                           # truncated file
+    with pytest.raises(dg.DoomGpuError):
+        dg.Scene(b"IWAD", "e1m1")
+
+
+def test_scene_queries_match_oracle(dg, oracle, wad1993, oracle_scene1993):
+    sc = dg.Scene(wad1993, "e1m1")
+    assert sc.player_start() == oracle_scene1993.player_start()
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        x, y = float(rng.uniform(-200, 4300)), float(rng.uniform(-200, 3300))
+        assert sc.floor_height_at(x, y, -999.0) == oracle_scene1993.floor_height_at(x, y, -999.0)
+    L = dg.lib()
+    assert L.dg_scene_texture_id(sc._h, b"brick1") >= 0            # Textures::get upper-cases (textures.rs:155)
+    assert L.dg_scene_texture_id(sc._h, b"NOSUCH") < 0
+    assert L.dg_scene_flat_id(sc._h, b"NUKAGE1", 0.0) != L.dg_scene_flat_id(sc._h, b"NUKAGE1", 0.4)
+    assert L.dg_scene_flat_id(sc._h, b"NUKAGE1", 1.0) == L.dg_scene_flat_id(sc._h, b"NUKAGE1", 0.0)   # 3 frames, 3 Hz
+    w, h = ctypes.c_int(), ctypes.c_int()
+    assert L.dg_scene_bitmap_size(sc._h, L.dg_scene_texture_id(sc._h, b"TALL72"), w, h) == 0 and (w.value, h.value) == (64, 72)
+    b0 = L.dg_scene_sprite_bitmap_id(sc._h, b"POSS", 0, 1)
+    b1 = L.dg_scene_sprite_bitmap_id(sc._h, b"POSS", 0, 7)         # rotation 8 is the mirror of rotation 2 (sprites.rs:48-56)
+    assert b0 >= 0 and b1 >= 0 and b0 != b1
+    sc.close()
+
+
+def test_list_invariants(dg, wad1993, path1993):
+    sc = dg.Scene(wad1993, "e1m1")
+    W, H = 320, 200
+    for i in (0, 100, 297, 323, 728):
+        fl = sc.build_lists(W, H, dg.make_views(path1993[i:i + 1])[0])
+        assert fl.n_order >= 1
+        seen_renders = set()
+        phase = 0   # 0 walls (inline), 1 visplanes, 2 sprites/masked
+        for k in range(fl.n_order):
+            cmd = fl.order[k]
+            if cmd.kind == 1:
+                assert phase <= 1
+                phase = 1
+                vp = fl.visplanes[cmd.index]
+                assert 0 <= vp.left <= vp.right < W
+                assert (vp.first_entry + (vp.right - vp.left + 1)) * 2 <= fl.n_plane_tb
+            else:
+                if phase == 1:
+                    phase = 2
+                assert cmd.index not in seen_renders          # a record is drawn exactly once (bitmap_render.rs:132-134)
+                seen_renders.add(cmd.index)
+                r = fl.renders[cmd.index]
+                assert r.n_columns > 0 and r.first_column + r.n_columns <= fl.n_columns
+                xs = [fl.columns[r.first_column + c].x for c in range(r.n_columns)]
+                assert xs == sorted(xs) and len(set(xs)) == len(xs) and 0 <= xs[0] and xs[-1] < W
+        assert len(seen_renders) == fl.n_renders
+    sc.close()
+
+
+@pytest.mark.parametrize("W,H,stride", [(320, 200, 10), (1280, 800, 125), (1024, 768, 250), (318, 199, 111), (64, 48, 37)])
+def test_host_lists_and_kernel_bodies_reproduce_oracle_1993(oracle_scene1993, wad1993, path1993, W, H, stride):
+    es = emul_bind.EmulScene(wad1993)
+    for i in range(0, 1000, stride):
+        got, st = es.render(W, H, path1993[i])
+        assert got == oracle_scene1993.render(W, H, path1993[i]), f"frame {i} {W}x{H}"
+        assert st[0] > 0 and st[3] >= W * H // 2
+
+
+def test_host_lists_and_kernel_bodies_reproduce_oracle_heavy(oracle_scene1994, wad1994, path1994):
+    es = emul_bind.EmulScene(wad1994)
+    for i in range(0, 1000, 20):
+        got, _ = es.render(320, 200, path1994[i])
+        assert got == oracle_scene1994.render(320, 200, path1994[i]), f"frame {i}"
+
+
+def test_animated_flats_and_off_path_views(oracle_scene1993, wad1993, path1993, campath_mod):
+    es = emul_bind.EmulScene(wad1993)
+    for i in (50, 240):
+        assert es.render(320, 200, path1993[i], 0.4)[0] == oracle_scene1993.render(320, 200, list(path1993[i]) + [0.4])
+    # viewpoints the path never visits: inside walls / outside the map / odd angles and eye heights
+    rng = np.random.default_rng(11)
+    for _ in range(60):
+        x, y = float(rng.uniform(-300, 4400)), float(rng.uniform(-300, 3400))
+        rec = campath_mod.view_record(x, y, float(rng.uniform(-7, 7)), float(rng.choice([-64, -8, 0, 24, 200])))
+        try:
+            ref = oracle_scene1993.render(320, 200, rec)
+        except Exception:
+            with pytest.raises(RuntimeError):           # where the reference would panic both sides must refuse
+                es.render(320, 200, rec)
+            continue
+        assert es.render(320, 200, rec)[0] == ref
