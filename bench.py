@@ -164,7 +164,7 @@ def main():
         e2e_s = dist_max(time.perf_counter() - t1, dist)
         e2e = {"value": aggregate_fps(nb * B, world, e2e_s), "unit": "frames/s",
                "includes": "host list generation + pinned staging + H2D + setup/raster kernels, frames left in HBM",
-               "host_threads": args.host_threads or (os.cpu_count() or 1), "host_ms_per_batch": float(np.mean(host_ms)),
+               "host_threads": ctx.host_threads, "host_ms_per_batch": float(np.mean(host_ms)),
                "list_bytes_per_frame": int(stats.get("list_bytes", 0) // max(1, stats.get("n_frames", 1)))}
 
     # ---- roofline of the dominant kernel ----------------------------------------------------------------------------

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "dg_scene_set_mobj_state": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint8, ctypes.c_int]),
     "dg_create": (ctypes.c_int, [ctypes.POINTER(DgConfig), ctypes.POINTER(_P)]),
     "dg_destroy": (None, [_P]),
+    "dg_ctx_host_threads": (ctypes.c_int, [_P]),
     "dg_upload_scene": (ctypes.c_int, [_P, _P]),
     "dg_render_views": (ctypes.c_int, [_P, ctypes.POINTER(DgView), ctypes.c_int, _P]),
     "dg_submit_views": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(DgView), ctypes.c_int]),
@@ -191,6 +192,7 @@ class Context:
         self._h = h
         self.width, self.height, self.max_batch, self.slots = width, height, max_batch, slots
         self.frame_bytes = 3 * width * height
+        self.host_threads = lib().dg_ctx_host_threads(self._h)
         self._scene = None
 
     def upload_scene(self, scene: Scene):

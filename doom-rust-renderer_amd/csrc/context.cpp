@@ -7,6 +7,7 @@
 //             aux slab   DevSpanAux per span (device-only, written by dg_setup_spans)
 //             framebuffer slab  F x 3*W*H bytes RGB24 (the reference's Pixels.pixels, one per frame)
 #include <hip/hip_runtime_api.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -130,6 +131,7 @@ struct dg_ctx {
     std::vector<std::unique_ptr<FrameArena>> arenas;   // one per worker (+ caller)
     std::vector<BinnedFrame> binned;                   // one per frame of a batch
     size_t span_cap_per_batch = 0, wall_cap_per_batch = 0, plane_cap_per_batch = 0;
+    int n_threads = 1;
 };
 
 namespace {
@@ -336,8 +338,16 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     c->cfg = *cfg;
     c->fk = make_consts(cfg->width, cfg->height);
     c->dk = DevConsts{c->fk.ARC, c->fk.GCFX, c->fk.CFX, c->fk.CFY, cfg->width, cfg->height};
-    int nthreads = cfg->host_threads > 0 ? cfg->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    // Default: the process's CPU share (affinity mask), capped at 16 per GPU — an 8-GPU node gives each rank ~1/8 of the cores.
+    int nthreads = cfg->host_threads;
+    if (nthreads <= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        int avail = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+        nthreads = std::max(1, std::min(avail, 16));
+    }
     nthreads = std::min(nthreads, 256);
+    c->n_threads = nthreads;
     c->pool.reset(new Pool(nthreads - 1));
     for (int i = 0; i < nthreads; i++) c->arenas.emplace_back(new FrameArena());
     c->binned.resize((size_t)cfg->max_batch);
@@ -370,6 +380,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
 }
 
 void dg_destroy(dg_ctx *ctx) { free_ctx(ctx); }
+int dg_ctx_host_threads(const dg_ctx *ctx) { return ctx ? ctx->n_threads : DG_ERR_INVALID; }
 
 int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     if (!c || !scene) return set_err(DG_ERR_INVALID, "null argument");

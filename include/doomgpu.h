@@ -78,11 +78,13 @@ typedef struct dg_config {
     int32_t width, height; /* frame size (the reference's SCREEN_WIDTH/HEIGHT, src/game.rs:28-29); width % 4 == 0 */
     int32_t max_batch;     /* frames per submission */
     int32_t slots;         /* in-flight submissions (>= 1); each owns a framebuffer slab of max_batch frames */
-    int32_t host_threads;  /* list-generation threads for dg_render_views / dg_submit_views (0 = hardware) */
+    int32_t host_threads;  /* list-generation threads for dg_render_views / dg_submit_views (0 = CPU affinity share, capped at 16) */
 } dg_config;
 
 int dg_create(const dg_config *cfg, dg_ctx **out);
 void dg_destroy(dg_ctx *ctx);
+/* Number of host threads the ctx uses for list generation (after the default / cap has been applied). */
+int dg_ctx_host_threads(const dg_ctx *ctx);
 /* Copy palette, texel planes, flats to HBM (immutable per map). The scene must outlive the ctx's use of it. */
 int dg_upload_scene(dg_ctx *ctx, const dg_scene *scene);
 

@@ -71,7 +71,7 @@ def test_golden_hashes_on_gpu(dg, scene1993, path1993, golden_frames):
 
 def test_heavy_map_bit_exact(dg, scene1994, oracle_scene1994, path1994, golden_frames):
     W, H = 320, 200
-    idx = list(range(0, 1000, 8))
+    idx = sorted(set(range(0, 1000, 8)) | {int(i) for i in golden_frames[1994]["320x200"]})
     ctx = make_ctx(dg, scene1994, W, H, len(idx))
     out = ctx.render(dg.make_views(path1994[idx]))
     for k, i in enumerate(idx):
