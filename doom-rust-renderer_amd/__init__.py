@@ -17,7 +17,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdoomgpu.so")
+LIB_PATH = os.environ.get("DOOMGPU_LIB") or os.path.join(_HERE, "libdoomgpu.so")   # override only for kernel-variant experiments
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "doomgpu.h")
 
 DG_OK, DG_ERR_INVALID, DG_ERR_NO_DEVICE, DG_ERR_HIP, DG_ERR_WAD, DG_ERR_RENDER, DG_ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6

@@ -4,7 +4,7 @@
 // HBM layout (sized once at dg_create for 288 GB parts: nothing is reallocated on the submit path):
 //   scene   : palette 1 KB | texel index plane | texel opacity plane | flats (4 KB each)      immutable per map
 //   per slot: list slab  [DevFrame x F | col_off x F*(W+1) | DevWallRec.. | DevPlaneRec.. | DevSpan..]  one H2D copy
-//             aux slab   DevSpanAux per span (device-only, written by dg_setup_spans)
+//             rspan slab DevRSpan 32 B per span (device-only, written by dg_setup_spans, walked by dg_raster_tiles)
 //             framebuffer slab  F x 3*W*H bytes RGB24 (the reference's Pixels.pixels, one per frame)
 #include <hip/hip_runtime_api.h>
 #include <sched.h>
@@ -102,7 +102,7 @@ struct Slot {
     hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_raster = nullptr, ev_done = nullptr;
     uint8_t *h_lists = nullptr;   // pinned staging
     uint8_t *d_lists = nullptr;
-    DevSpanAux *d_aux = nullptr;
+    DevRSpan *d_rspans = nullptr;
     uint8_t *d_fb = nullptr;
     size_t lists_cap = 0;
     // last submission
@@ -145,7 +145,7 @@ void free_ctx(dg_ctx *c) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         if (s.h_lists) (void)hipHostFree(s.h_lists);
         if (s.d_lists) (void)hipFree(s.d_lists);
-        if (s.d_aux) (void)hipFree(s.d_aux);
+        if (s.d_rspans) (void)hipFree(s.d_rspans);
         if (s.d_fb) (void)hipFree(s.d_fb);
         if (s.ev_start) (void)hipEventDestroy(s.ev_start);
         if (s.ev_setup) (void)hipEventDestroy(s.ev_setup);
@@ -220,7 +220,7 @@ int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *
     P.walls = reinterpret_cast<const DevWallRec *>(s.d_lists + off_walls);
     P.planes = reinterpret_cast<const DevPlaneRec *>(s.d_lists + off_planes);
     P.spans = reinterpret_cast<const DevSpan *>(s.d_lists + off_spans);
-    P.aux = s.d_aux;
+    P.rspans = s.d_rspans;
     P.fb = s.d_fb;
     P.n_frames = n;
     s.max_spans = max_spans; s.n_spans = spans; s.covered = covered; s.n_frames = n; s.n_walls = walls; s.n_planes = planes;
@@ -370,7 +370,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         CTX_TRY(hipEventCreate(&s.ev_done));
         CTX_TRY(hipHostMalloc((void **)&s.h_lists, lists_cap, hipHostMallocDefault));
         CTX_TRY(hipMalloc((void **)&s.d_lists, lists_cap));
-        CTX_TRY(hipMalloc((void **)&s.d_aux, c->span_cap_per_batch * sizeof(DevSpanAux)));
+        CTX_TRY(hipMalloc((void **)&s.d_rspans, c->span_cap_per_batch * sizeof(DevRSpan)));
         CTX_TRY(hipMalloc((void **)&s.d_fb, F * 3 * W * H));
 #undef CTX_TRY
         s.lists_cap = lists_cap;

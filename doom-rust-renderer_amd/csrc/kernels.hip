@@ -3,13 +3,16 @@
 //
 // Kernel 1  dg_setup_spans   one lane per span: column-invariant part of the wall/sprite mapper
 //                            (bitmap_render.rs:241-251: 3 f32 divides -> texture column + light factor),
-//                            sky texture column, floor/ceiling vx.  Writes DevSpanAux (8 B/span).
-// Kernel 2  dg_raster_tiles  one workgroup per (frame, 128-column x 64-row tile); each of its 4 wavefronts
+//                            sky texture column, floor/ceiling vx; merges the span with its record into one
+//                            self-contained 32-byte DevRSpan.
+// Kernel 2  dg_raster_tiles  one workgroup (8 wavefronts) per (frame, 128-column x 64-row tile); a wavefront
 //                            takes one screen column at a time with lane = row, so that
-//                              * the span list of the column is wave-uniform (one coalesced 1 KB load of up to 64
-//                                spans, then ballot + readlane; spans are applied in draw order so the last
-//                                writer wins exactly as in the reference),
+//                              * the span list of the column is wave-uniform: ONE coalesced load brings in up to 64
+//                                spans (lane i = span i, 2 x 16 B), a ballot picks the ones touching these 64 rows
+//                                and v_readlane broadcasts their 8 words — no dependent record loads; spans are
+//                                applied in draw order so the last writer wins exactly as in the reference,
 //                              * a wall column reads one texture column ([x][y] texel layout => consecutive bytes),
+//                              * the palette lives in LDS (1 KB),
 //                              * finished pixels go to an LDS tile [row][col] and leave the CU as fully
 //                                coalesced 12-byte-per-lane RGB24 row segments (384 B contiguous per tile row).
 //                            Every pixel of the tile is stored (uncovered = 0,0,0) which fuses the reference's
@@ -27,7 +30,8 @@ namespace dg {
 constexpr int TILE_W = 128;       // columns per workgroup
 constexpr int TILE_H = 64;        // rows per workgroup = lanes per wave
 constexpr int TILE_STRIDE = 132;  // dwords per LDS tile row: 16-B aligned rows, breaks the power-of-two stride
-constexpr int WAVES = 4;
+constexpr int WAVES = 8;
+constexpr int THREADS = WAVES * 64;
 
 __global__ __launch_bounds__(256) void dg_setup_spans(RasterParams P) {
     const int f = blockIdx.y;
@@ -35,25 +39,20 @@ __global__ __launch_bounds__(256) void dg_setup_spans(RasterParams P) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= fr.n_spans) return;
     const DevSpan sp = P.spans[fr.span_base + i];
-    DevSpanAux a;
-    if (sp.kind == SPAN_WALL) {
-        a = wall_column_setup(P.walls[fr.wall_base + sp.rec], sp.x);
-    } else if (sp.kind == SPAN_FLAT) {
-        a.texcol = 0;
-        a.factor = flat_column_vx(P.k, sp.x);
-    } else {
-        a.texcol = sky_column_setup(P.scene, P.k, fr, sp.x);
-        a.factor = 0.0f;
-    }
-    P.aux[fr.span_base + i] = a;
+    DevRSpan o;
+    if (sp.kind == SPAN_WALL) o = resolve_wall_span(sp, P.walls[fr.wall_base + sp.rec]);
+    else if (sp.kind == SPAN_FLAT) o = resolve_flat_span(sp, P.planes[fr.plane_base + sp.rec], P.k);
+    else o = resolve_sky_span(sp, P.scene, P.k, fr);
+    uint4 *dst = reinterpret_cast<uint4 *>(&P.rspans[fr.span_base + i]);
+    dst[0] = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
+    dst[1] = make_uint4(o.w[4], o.w[5], o.w[6], o.w[7]);
 }
 
-__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int lane) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
-}
+__device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 
-__global__ __launch_bounds__(256) void dg_raster_tiles(RasterParams P) {
+__global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[TILE_H * TILE_STRIDE];
+    __shared__ uint32_t pal[256];
 
     const int f = blockIdx.z;
     const DevFrame fr = P.frames[f];
@@ -62,11 +61,14 @@ __global__ __launch_bounds__(256) void dg_raster_tiles(RasterParams P) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int y = y0 + lane;
+    const float vy = P.k.CFY - (float)y;      // visplanes.rs:109, a per-row constant
+    const float r_vy = prepare_rcp(vy);
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
-    const DevSpan *spans = P.spans + fr.span_base;
-    const DevSpanAux *aux = P.aux + fr.span_base;
-    const DevWallRec *walls = P.walls + fr.wall_base;
-    const DevPlaneRec *planes = P.planes + fr.plane_base;
+    const DevRSpan *rspans = P.rspans + fr.span_base;
+    const uint8_t *texel_idx = P.scene.texel_idx, *texel_opq = P.scene.texel_opq, *flats = P.scene.flats;
+
+    if (threadIdx.x < 256) pal[threadIdx.x] = P.scene.palette[threadIdx.x];
+    __syncthreads();
 
     for (int c = wave; c < TILE_W; c += WAVES) {
         const int x = x0 + c;
@@ -75,31 +77,33 @@ __global__ __launch_bounds__(256) void dg_raster_tiles(RasterParams P) {
             const uint32_t n0 = coff[x], n1 = coff[x + 1];
             for (uint32_t base = n0; base < n1; base += 64) {
                 const uint32_t i = base + (uint32_t)lane;
-                uint4 raw = make_uint4(0, 0, 0, 0);
+                uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
                 bool hit = false;
                 if (i < n1) {
-                    raw = *reinterpret_cast<const uint4 *>(&spans[i]);
-                    const int ctop = (int)(int16_t)(raw.x & 0xffffu), cbot = (int)(int16_t)(raw.x >> 16);
-                    hit = cbot >= y0 && ctop <= y0 + (TILE_H - 1);
+                    const uint4 *src = reinterpret_cast<const uint4 *>(&rspans[i]);
+                    ra = src[0];
+                    rb = src[1];
+                    hit = hi_i16(ra.x) >= y0 && lo_i16(ra.x) <= y0 + (TILE_H - 1);
                 }
                 unsigned long long m = __ballot(hit);
                 while (m) {
                     const int j = __builtin_ctzll(m);
                     m &= m - 1;
-                    const uint32_t w0 = readlane_u32(raw.x, j), w1 = readlane_u32(raw.y, j), w2 = readlane_u32(raw.z, j);
-                    const int ctop = (int)(int16_t)(w0 & 0xffffu), cbot = (int)(int16_t)(w0 >> 16);
-                    const int top_y = (int)(int16_t)(w1 & 0xffffu), bot_y = (int)(int16_t)(w1 >> 16);
-                    const uint32_t rec = w2 & 0xffffu, kind = (w2 >> 16) & 0xffu;
-                    const DevSpanAux a = aux[base + (uint32_t)j];
-                    if (y >= ctop && y <= cbot) {
+                    const uint32_t w0 = bcast(ra.x, j), w1 = bcast(ra.y, j), w2 = bcast(ra.z, j), w3 = bcast(ra.w, j);
+                    const uint32_t w4 = bcast(rb.x, j), w5 = bcast(rb.y, j), w6 = bcast(rb.z, j), w7 = bcast(rb.w, j);
+                    if (y >= lo_i16(w0) && y <= hi_i16(w0)) {
+                        const uint32_t kind = w6 & 0xffu;
                         if (kind == SPAN_WALL) {
-                            uint32_t rgb;
-                            if (wall_pixel(P.scene, walls[rec], a, top_y, bot_y, y, rgb)) color = rgb;
+                            const uint32_t o = wall_texel_offset(w1, w2, w4, w5, w6, w7, y);
+                            const bool opaque = (w6 & 0x100u) ? texel_opq[o] != 0 : true;
+                            if (opaque) color = shade(pal[texel_idx[o]], bits_f32(w3));
                         } else if (kind == SPAN_FLAT) {
-                            color = flat_pixel(P.scene, P.k, fr, planes[rec], a.factor, y);
+                            float factor;
+                            const uint32_t o = flat_texel_offset(fr, w1, w2, w4, w5, w6, vy, r_vy, factor);
+                            color = shade(pal[flats[o]], factor);
                         } else {
-                            uint32_t rgb;
-                            if (sky_pixel(P.scene, P.k, a.texcol, y, rgb)) color = rgb;
+                            const uint32_t o = sky_texel_offset(P.scene, P.k, w2, y);
+                            if (o != 0xffffffffu && texel_opq[o]) color = pal[texel_idx[o]];
                         }
                     }
                 }
@@ -109,10 +113,10 @@ __global__ __launch_bounds__(256) void dg_raster_tiles(RasterParams P) {
     }
     __syncthreads();
 
-    // Read-out: groups of 4 pixels (16 B of RGBX in LDS -> 12 B of RGB24 in HBM); 32 groups per tile row, lanes
+    // Read-out: groups of 4 pixels (16 B of RGBX in LDS -> 12 B of RGB24 in HBM); 32 groups per tile row, the lanes
     // of a wave cover two full tile rows = 2 x 384 contiguous bytes.
     uint8_t *fb = P.fb + (size_t)f * (size_t)3 * (size_t)W * (size_t)H;
-    for (int g = threadIdx.x; g < TILE_H * (TILE_W / 4); g += 256) {
+    for (int g = threadIdx.x; g < TILE_H * (TILE_W / 4); g += THREADS) {
         const int row = g >> 5, gc = g & 31;
         const int yy = y0 + row, xx = x0 + 4 * gc;
         if (yy < H && xx < W) {   // W % 4 == 0 (checked at dg_create), so a group never straddles the right edge
@@ -138,7 +142,7 @@ hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hip
 hipError_t launch_raster(const RasterParams &P, hipStream_t stream) {
     if (P.n_frames <= 0) return hipSuccess;
     dim3 grid((unsigned)((P.k.W + TILE_W - 1) / TILE_W), (unsigned)((P.k.H + TILE_H - 1) / TILE_H), (unsigned)P.n_frames);
-    hipLaunchKernelGGL(dg_raster_tiles, grid, dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(dg_raster_tiles, grid, dim3(THREADS), 0, stream, P);
     return hipGetLastError();
 }
 

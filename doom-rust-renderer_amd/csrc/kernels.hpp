@@ -12,7 +12,7 @@ struct RasterParams {
     const DevFrame *frames;      // [n_frames]
     const uint32_t *col_off;     // [n_frames][W + 1]
     const DevSpan *spans;
-    DevSpanAux *aux;
+    DevRSpan *rspans;            // written by dg_setup_spans, walked by dg_raster_tiles
     const DevWallRec *walls;
     const DevPlaneRec *planes;
     uint8_t *fb;                 // n_frames x 3*W*H, RGB24

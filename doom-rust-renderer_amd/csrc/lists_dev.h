@@ -5,7 +5,7 @@
 //   uint32_t   col_off[F][W + 1]         column-major index: spans of column x of frame f are
 //                                        spans[frames[f].span_base + col_off[f][x] .. + col_off[f][x+1])
 //   DevSpan    spans[]                   16 B each, per column in DRAW ORDER (later span overwrites earlier)
-//   DevSpanAux aux[]                     8 B each, written by the setup kernel (texture column address, light factor)
+//   DevRSpan   rspans[]                  32 B each, written by the setup kernel: the self-contained record the raster kernel walks
 //   DevWallRec walls[]                   48 B per drawn BitmapRender (per-record constants of render_vertical_bitmap_line)
 //   DevPlaneRec planes[]                 16 B per drawn visplane
 // plus the immutable scene: palette (256 x RGBX u32), texel index plane + opacity plane (u8, column-major
@@ -31,6 +31,21 @@ struct DevSpanAux {           // setup-kernel output
     float factor;             // WALL: light_level/255 - z/4096 clamped at 0 (diminish_color, bitmap_render.rs:190-201)
 };
 static_assert(sizeof(DevSpanAux) == 8, "DevSpanAux must be 8 bytes");
+
+// What the raster kernel actually walks: one self-contained 32-byte record per span, written by the setup kernel
+// from DevSpan + its wall/plane record, so that a wavefront needs ONE coalesced load for up to 64 spans of a column
+// and no dependent record loads afterwards (all eight words are broadcast with v_readlane).
+//   word   WALL (bitmap_render.rs:241-263)                    FLAT (visplanes.rs:103-126)           SKY (visplanes.rs:65-72)
+//   w0     ctop | cbot << 16                                  same                                   same
+//   w1     d = (bottom_y - top_y) as f32                      wz * vx (f32)                          -
+//   w2     texel offset of the texture column                 byte offset of the 64x64 flat          texel offset of the sky column (or ~0)
+//   w3     light factor (f32, clamped >= 0)                   -                                      -
+//   w4     uy1 = top_height - bottom_height (NaN if d == 0)   gwz = GCFX * wz (f32)                  -
+//   w5     top_y | off_y << 16                                light_level / 255 (f32)                -
+//   w6     kind | has_holes << 8 | h << 16                    kind | fast-divide-ok << 8             kind
+//   w7     prepared reciprocal of d (raster_core.h)           -                                      -
+struct DevRSpan { uint32_t w[8]; };
+static_assert(sizeof(DevRSpan) == 32, "DevRSpan must be 32 bytes");
 
 struct DevWallRec {           // bitmap_render.rs:233-251 hoisted per record
     float A, B, C, D;         // ux0/uz0 (= 0.0/uz0), ux1/uz1 (= len/uz1), 1.0/uz0, 1.0/uz1

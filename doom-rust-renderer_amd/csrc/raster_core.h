@@ -14,86 +14,223 @@
 
 namespace dg {
 
+DG_HD uint32_t f32_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    union { float f; uint32_t u; } v; v.f = f; return v.u;
+#endif
+}
+DG_HD float bits_f32(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    union { float f; uint32_t u; } v; v.u = u; return v.f;
+#endif
+}
+DG_HD int32_t lo_i16(uint32_t w) { return (int32_t)(int16_t)(w & 0xffffu); }
+DG_HD int32_t hi_i16(uint32_t w) { return (int32_t)(int16_t)(w >> 16); }
+
+// ---- instruction-level shortcuts (each one is verified exhaustively on the GPU by tests/gpu_numerics) ----------------
+//
+// `f as u8` in two instructions: v_cvt_pk_u8_f32 saturates to 0..255 and maps NaN to 0 but ROUNDS (measured: 41.9 M
+// of the 2^32 patterns differ from truncation), so the value is truncated first (v_trunc_f32 is exact).
+DG_HD uint32_t f32_as_u8_pk(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    float t = __builtin_truncf(f);
+    asm("v_cvt_pk_u8_f32 %0, %1, 0, 0" : "=v"(r) : "v"(t));
+    return r;
+#else
+    return (uint32_t)f32_as_u8(f);
+#endif
+}
+
+// IEEE-exact n / d with the denominator-only part of the divide hoisted.  hipcc expands `n / d` to
+//   v_div_scale x2, v_rcp, fma, fma | mul, fma, fma, fma, v_div_fmas, v_div_fixup
+// and the two v_div_scale are identities (and v_div_fmas a plain fma) unless an operand is denormal / huge / tiny.
+// prepare_rcp() is the part left of the bar, div_prepared() the part right of it — the same instructions in the same
+// order, so the result is the correctly rounded quotient whenever div_guard_ok(n) holds and d is a normal number of
+// moderate size (the kernel only uses it for d = integer row differences and d = CFY - y).  v_div_fixup supplies the
+// IEEE results for d == 0, n == 0, infinities and NaN.  On the host the plain quotient is the same value.
+DG_HD float prepare_rcp(float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r0 = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+#else
+    (void)d;
+    return 0.0f;
+#endif
+}
+DG_HD float div_prepared(float n, float d, float r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    return __builtin_amdgcn_div_fixupf(q, d, n);
+#else
+    (void)r;
+    return n / d;
+#endif
+}
+// Numerators for which div_prepared is used: zero, or 2^-64 <= |n| <= 2^64 (NaN / Inf / tiny / huge take the plain divide).
+DG_HD bool div_guard_ok(float n) {
+    uint32_t e = (f32_bits(n) >> 23) & 0xffu;
+    return (f32_bits(n) & 0x7fffffffu) == 0u || (e >= 127u - 64u && e <= 127u + 64u);
+}
+
 // diminish_color's factor for a sector light (already divided by 255) and an i16 distance.
 DG_HD float light_factor(float lightf, int32_t distance_i16) {
     float factor = lightf - (float)distance_i16 * (1.0f / (16.0f * 256.0f));
-    return factor < 0.0f ? 0.0f : factor;
+    // `if factor < 0.0 { factor = 0.0 }`: factor is never NaN here and -0.0 vs +0.0 cannot change a `as u8` result,
+    // so a single max does it.
+    return __builtin_fmaxf(factor, 0.0f);
 }
 
 // palette entry (r | g<<8 | b<<16) times factor, each channel `as u8`; returns r | g<<8 | b<<16.
 DG_HD uint32_t shade(uint32_t rgbx, float factor) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // 4 instructions per channel: v_cvt_f32_ubyteN, v_mul_f32, v_trunc_f32, v_cvt_pk_u8_f32 (packs in place)
+    float r = __builtin_truncf((float)(rgbx & 255u) * factor);
+    float g = __builtin_truncf((float)((rgbx >> 8) & 255u) * factor);
+    float b = __builtin_truncf((float)((rgbx >> 16) & 255u) * factor);
+    uint32_t o;
+    asm("v_cvt_pk_u8_f32 %0, %1, 0, 0" : "=v"(o) : "v"(r));
+    asm("v_cvt_pk_u8_f32 %0, %1, 1, %2" : "=v"(o) : "v"(g), "v"(o));
+    asm("v_cvt_pk_u8_f32 %0, %1, 2, %2" : "=v"(o) : "v"(b), "v"(o));
+    return o;
+#else
     int32_t r = f32_as_u8((float)(rgbx & 255u) * factor);
     int32_t g = f32_as_u8((float)((rgbx >> 8) & 255u) * factor);
     int32_t b = f32_as_u8((float)((rgbx >> 16) & 255u) * factor);
     return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
+#endif
 }
 
+// Approximate reciprocal for the modulus helper only (any value within 2^-22 of 1/n works, see floor_mod_fast).
+DG_HD float approx_rcp(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(v);
+#else
+    return 1.0f / v;
+#endif
+}
+
+// Floor modulus of an i16 value by a bitmap dimension 0 < n <= 32767 without an integer divide:
+// power-of-two sizes mask; otherwise q = floor(t * rcp) is within 1 of the true quotient
+// (|t| <= 32768 and a 2^-22 relative error give an absolute error < 0.01), and one fix-up step repairs it.
+DG_HD int32_t floor_mod_fast(int32_t t, int32_t n, int32_t pow2_mask, float rcp_n) {
+    if (pow2_mask) return t & pow2_mask;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t q = (int32_t)__builtin_floorf((float)t * rcp_n);
+#else
+    float qf = (float)t * rcp_n;
+    int32_t q = (int32_t)qf;
+    if ((float)q > qf) q -= 1;
+#endif
+    int32_t r = t - q * n;
+    if (r < 0) r += n;
+    if (r >= n) r -= n;
+    return r;
+}
+
+// ---- setup: DevSpan + record -> self-contained DevRSpan (one lane per span) ------------------------------------
+
 // Column-invariant part of render_vertical_bitmap_line (bitmap_render.rs:241-251): texture column + light factor.
-DG_HD DevSpanAux wall_column_setup(const DevWallRec &r, int32_t x) {
-    float ax = (float)(x - r.start_x) / r.dxf;
+DG_HD DevRSpan resolve_wall_span(const DevSpan &sp, const DevWallRec &r) {
+    float ax = (float)((int32_t)sp.x - r.start_x) / r.dxf;
     float oma = 1.0f - ax;
     float den = oma * r.C + ax * r.D;
     int32_t tx = f32_as_i16((oma * r.A + ax * r.B) / den);
     tx = wrap_i16(tx + r.off_x);
     tx = floor_mod_i16(tx, r.w);
     int32_t z = f32_as_i16((oma + ax) / den);
-    DevSpanAux a;
-    a.texcol = r.texel_off + (uint32_t)tx * (uint32_t)r.h;
-    a.factor = light_factor(r.lightf, z);
-    return a;
+    const int32_t h = r.h;
+    // ay = (y - top_y) / (bottom_y - top_y): the denominator is a span constant.  When it is 0 the reference's
+    // `h + (1.0 - ay) * 0.0 + ay * uy1` is NaN for every row (ay is +-Inf or NaN); a NaN uy1 reproduces exactly that,
+    // and for a finite ay the middle term is +-0.0 and drops out (h >= 1), so the kernel evaluates h + ay * uy1.
+    const float d = (float)((int32_t)sp.bot_y - (int32_t)sp.top_y);
+    DevRSpan o;
+    o.w[0] = (uint32_t)(uint16_t)sp.ctop | ((uint32_t)(uint16_t)sp.cbot << 16);
+    o.w[1] = f32_bits(d);
+    o.w[2] = r.texel_off + (uint32_t)tx * (uint32_t)h;
+    o.w[3] = f32_bits(light_factor(r.lightf, z));
+    o.w[4] = d == 0.0f ? 0x7fc00000u : f32_bits(r.uy1);
+    o.w[5] = (uint32_t)(uint16_t)sp.top_y | ((uint32_t)(uint16_t)r.off_y << 16);
+    o.w[6] = (uint32_t)SPAN_WALL | (r.has_holes ? 0x100u : 0u) | ((uint32_t)(uint16_t)h << 16);
+    o.w[7] = f32_bits(prepare_rcp(d));
+    return o;
+}
+DG_HD DevRSpan resolve_flat_span(const DevSpan &sp, const DevPlaneRec &p, const DevConsts &k) {
+    const float vx = (k.CFX - (float)sp.x) / k.ARC;                      // visplanes.rs:108
+    const float wzvx = p.wz * vx;                                        // numerator of wy = wz * vx / vy (visplanes.rs:114)
+    DevRSpan o;
+    o.w[0] = (uint32_t)(uint16_t)sp.ctop | ((uint32_t)(uint16_t)sp.cbot << 16);
+    o.w[1] = f32_bits(wzvx);
+    o.w[2] = p.flat_off;
+    o.w[3] = 0;
+    o.w[4] = f32_bits(p.gwz);                                            // numerator of wx = GCFX * wz / vy (visplanes.rs:113)
+    o.w[5] = f32_bits(p.lightf);
+    o.w[6] = (uint32_t)SPAN_FLAT | ((div_guard_ok(wzvx) && div_guard_ok(p.gwz)) ? 0x100u : 0u);
+    o.w[7] = 0;
+    return o;
+}
+// draw_sky's texture column (visplanes.rs:65-66); ~0 when the reference would index outside the sky bitmap.
+DG_HD DevRSpan resolve_sky_span(const DevSpan &sp, const DevScene &sc, const DevConsts &k, const DevFrame &f) {
+    int32_t tx = f32_as_i16((float)sp.x * 256.0f / (float)k.W);
+    tx = wrap_i16(tx + f.sky_tx_offset) % 256;
+    DevRSpan o;
+    o.w[0] = (uint32_t)(uint16_t)sp.ctop | ((uint32_t)(uint16_t)sp.cbot << 16);
+    o.w[1] = 0;
+    o.w[2] = (tx < 0 || tx >= sc.sky_w) ? 0xffffffffu : sc.sky_texel_off + (uint32_t)tx * (uint32_t)sc.sky_h;
+    o.w[3] = o.w[4] = o.w[5] = 0;
+    o.w[6] = (uint32_t)SPAN_SKY;
+    o.w[7] = 0;
+    return o;
 }
 
-// Texture row of one wall pixel (bitmap_render.rs:256-263).
-DG_HD int32_t wall_texture_row(const DevWallRec &r, int32_t top_y, int32_t bot_y, int32_t y) {
-    float ay = (float)(y - top_y) / (float)(bot_y - top_y);
-    int32_t ty = f32_as_i16((float)r.h + (1.0f - ay) * 0.0f + ay * r.uy1);
-    ty = wrap_i16(ty + r.off_y);
-    return floor_mod_i16(ty, r.h);
+// ---- per pixel (all span words are wave-uniform on the GPU) ----------------------------------------------------------
+
+// Texel offset of one wall pixel (bitmap_render.rs:256-263).  fy = y as f32.
+DG_HD uint32_t wall_texel_offset(uint32_t w1, uint32_t w2, uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7, int32_t y) {
+    const int32_t top_y = lo_i16(w5), off_y = hi_i16(w5), h = (int32_t)(w6 >> 16);
+    const float ay = div_prepared((float)(y - top_y), bits_f32(w1), bits_f32(w7));
+    int32_t ty = f32_as_i16((float)h + ay * bits_f32(w4));
+    ty = wrap_i16(ty + off_y);
+    const int32_t mask = (h & (h - 1)) == 0 ? h - 1 : 0;
+    return w2 + (uint32_t)floor_mod_fast(ty, h, mask, mask ? 0.0f : approx_rcp((float)h));
 }
 
-// One wall / masked / sprite pixel.  Returns false for a transparent texel (`None`, bitmap_render.rs:265).
-DG_HD bool wall_pixel(const DevScene &sc, const DevWallRec &r, const DevSpanAux &a, int32_t top_y, int32_t bot_y, int32_t y, uint32_t &rgb) {
-    uint32_t o = a.texcol + (uint32_t)wall_texture_row(r, top_y, bot_y, y);
-    if (r.has_holes && !sc.texel_opq[o]) return false;
-    rgb = shade(sc.palette[sc.texel_idx[o]], a.factor);
-    return true;
-}
-
-// Per-column part of draw_visplane: vx (visplanes.rs:108).
-DG_HD float flat_column_vx(const DevConsts &k, int32_t x) { return (k.CFX - (float)x) / k.ARC; }
-
-// One floor / ceiling pixel (visplanes.rs:108-128).
-DG_HD uint32_t flat_pixel(const DevScene &sc, const DevConsts &k, const DevFrame &f, const DevPlaneRec &p, float vx, int32_t y) {
-    float vy = k.CFY - (float)y;
-    float wx = p.gwz / vy;
-    float wy = p.wz * vx / vy;
+// Texture coordinates of one floor / ceiling pixel and its light factor (visplanes.rs:108-126).
+// vy = CFY - y and r_vy = prepare_rcp(vy) are per-row constants.
+DG_HD uint32_t flat_texel_offset(const DevFrame &f, uint32_t w1, uint32_t w2, uint32_t w4, uint32_t w5, uint32_t w6,
+                                 float vy, float r_vy, float &factor) {
+    float wx, wy;
+    if (w6 & 0x100u) {
+        wx = div_prepared(bits_f32(w4), vy, r_vy);
+        wy = div_prepared(bits_f32(w1), vy, r_vy);
+    } else {
+        wx = bits_f32(w4) / vy;
+        wy = bits_f32(w1) / vy;
+    }
     float rx = wx * f.cos_a - wy * f.sin_a;
     float ry = wy * f.cos_a + wx * f.sin_a;
-    int32_t tx = wrap_i16(f32_as_i16(rx) + f.pos_x_i16) & 63;
-    int32_t ty = wrap_i16(f32_as_i16(ry) + f.pos_y_i16) & 63;
-    uint32_t idx = sc.flats[p.flat_off + (uint32_t)(ty * 64 + tx)];
-    return shade(sc.palette[idx], light_factor(p.lightf, f32_as_i16(wx)));
+    int32_t tx = (f32_as_i16(rx) + f.pos_x_i16) & 63;       // wrapping i16 add, then & 63: the low 6 bits are unaffected by the wrap
+    int32_t ty = (f32_as_i16(ry) + f.pos_y_i16) & 63;
+    factor = light_factor(bits_f32(w5), f32_as_i16(wx));
+    return w2 + (uint32_t)(ty * 64 + tx);
 }
 
-// Per-column part of draw_sky: texture column (visplanes.rs:65-66).  Returns the texel offset of the column,
-// or 0xffffffff when the reference would index outside the sky bitmap.
-DG_HD uint32_t sky_column_setup(const DevScene &sc, const DevConsts &k, const DevFrame &f, int32_t x) {
-    int32_t tx = f32_as_i16((float)x * 256.0f / (float)k.W);
-    tx = wrap_i16(tx + f.sky_tx_offset) % 256;
-    if (tx < 0 || tx >= sc.sky_w) return 0xffffffffu;
-    return sc.sky_texel_off + (uint32_t)tx * (uint32_t)sc.sky_h;
-}
-
-// One sky pixel (visplanes.rs:68-77): no lighting; transparent texels are skipped.
-DG_HD bool sky_pixel(const DevScene &sc, const DevConsts &k, uint32_t texcol, int32_t y, uint32_t &rgb) {
+// Texture row of one sky pixel (visplanes.rs:68-72); returns ~0 when outside the sky bitmap.
+DG_HD uint32_t sky_texel_offset(const DevScene &sc, const DevConsts &k, uint32_t w2, int32_t y) {
     int32_t ty = f32_as_i16((float)y * 128.0f * 2.0f / (float)k.H);
     if (ty < 0) ty = wrap_i16(ty + 128);
     ty %= 128;
-    if (texcol == 0xffffffffu || ty < 0 || ty >= sc.sky_h) return false;
-    uint32_t o = texcol + (uint32_t)ty;
-    if (!sc.texel_opq[o]) return false;
-    rgb = sc.palette[sc.texel_idx[o]];
-    return true;
+    if (w2 == 0xffffffffu || ty < 0 || ty >= sc.sky_h) return 0xffffffffu;
+    return w2 + (uint32_t)ty;
 }
 
 }  // namespace dg

@@ -50,18 +50,30 @@ int emul_render(void *scene, int W, int H, const dg_view *view_in, uint8_t *rgb,
 
     std::memset(rgb, 0, (size_t)3 * W * H);
     for (int x = 0; x < W; x++) {
-        float vx = flat_column_vx(k, x);
-        uint32_t skycol = sky_column_setup(ds, k, bf.hdr, x);
         for (uint32_t i = bf.col_off[x]; i < bf.col_off[x + 1]; i++) {
             const DevSpan &s = bf.spans[i];
-            DevSpanAux aux{0, 0.0f};
-            if (s.kind == SPAN_WALL) aux = wall_column_setup(bf.walls[s.rec], x);
-            for (int y = s.ctop; y <= s.cbot; y++) {
+            // what dg_setup_spans does (one lane per span) ...
+            DevRSpan r = s.kind == SPAN_WALL ? resolve_wall_span(s, bf.walls[s.rec])
+                       : s.kind == SPAN_FLAT ? resolve_flat_span(s, bf.planes[s.rec], k)
+                                             : resolve_sky_span(s, ds, k, bf.hdr);
+            const uint32_t *w = r.w;
+            // ... and what dg_raster_tiles does for every row of the span (lane = row)
+            for (int y = lo_i16(w[0]); y <= hi_i16(w[0]); y++) {
                 uint32_t c = 0;
-                bool wr = true;
-                if (s.kind == SPAN_WALL) wr = wall_pixel(ds, bf.walls[s.rec], aux, s.top_y, s.bot_y, y, c);
-                else if (s.kind == SPAN_FLAT) c = flat_pixel(ds, k, bf.hdr, bf.planes[s.rec], vx, y);
-                else wr = sky_pixel(ds, k, skycol, y, c);
+                bool wr = false;
+                const uint32_t kind = w[6] & 0xffu;
+                if (kind == SPAN_WALL) {
+                    uint32_t o = wall_texel_offset(w[1], w[2], w[4], w[5], w[6], w[7], y);
+                    if (!(w[6] & 0x100u) || ds.texel_opq[o]) { c = shade(pal[ds.texel_idx[o]], bits_f32(w[3])); wr = true; }
+                } else if (kind == SPAN_FLAT) {
+                    float factor;
+                    const float vy = k.CFY - (float)y;
+                    uint32_t o = flat_texel_offset(bf.hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), factor);
+                    c = shade(pal[ds.flats[o]], factor); wr = true;
+                } else {
+                    uint32_t o = sky_texel_offset(ds, k, w[2], y);
+                    if (o != 0xffffffffu && ds.texel_opq[o]) { c = pal[ds.texel_idx[o]]; wr = true; }
+                }
                 if (wr) {
                     uint8_t *p = rgb + 3 * ((size_t)y * W + x);
                     p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;

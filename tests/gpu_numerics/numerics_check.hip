@@ -1,0 +1,123 @@
+// tests/gpu_numerics/numerics_check.hip — exhaustive on-device checks of the instruction-level shortcuts the raster
+// kernel relies on.  Each check enumerates its whole input domain on the GPU and counts mismatches against the plain
+// IEEE / Rust-`as` formulation; the kernel may only use a shortcut whose count is 0.
+//
+//   A  v_cvt_pk_u8_f32      == `f as u8` (truncate, saturate to 0..255, NaN -> 0) for ALL 2^32 f32 bit patterns
+//   B  hoisted-reciprocal divide == IEEE n / d for every integer pair the wall mapper can form:
+//      d = bottom_y - top_y in [-65535, 65535], n = y - top_y in [-32767, 49151]   (bitmap_render.rs:256)
+//   C  hoisted-reciprocal divide == IEEE n / vy for vy = CFY - y (all multiples of 0.5 with |vy| <= 8192)
+//      and numerators: every f32 bit pattern for 48 sampled vy, plus 2^22 hashed patterns for every vy; patterns outside
+//      the guard band (0 or 2^-64 <= |n| <= 2^64) are skipped exactly as the kernel skips them
+//   D  float floor-modulus helper == i16 reference fix-up for all t in [-32768, 32767], n in [1, 2048] and a sample above
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../doom-rust-renderer_amd/csrc/raster_core.h"
+
+using namespace dg;
+
+__global__ void check_pk_u8(unsigned long long *bad) {
+    const uint64_t total = 1ull << 32;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        float f = __uint_as_float((uint32_t)i);
+        int32_t ref = f32_as_u8(f);
+        uint32_t got = f32_as_u8_pk(f);
+        if ((uint32_t)ref != got) atomicAdd(bad, 1ull);
+    }
+}
+
+__global__ void check_div_wall(unsigned long long *bad) {
+    // blockIdx.x enumerates d, threads enumerate n
+    const int d_i = (int)blockIdx.x - 65535;
+    const float d = (float)d_i;
+    const float r = prepare_rcp(d);
+    for (int n_i = -32767 + (int)threadIdx.x; n_i <= 49151; n_i += blockDim.x) {
+        const float n = (float)n_i;
+        float ref = n / d;
+        float got = div_prepared(n, d, r);
+        if (__float_as_uint(ref) != __float_as_uint(got) && !(ref != ref && got != got)) atomicAdd(bad, 1ull);
+    }
+}
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+__global__ void check_div_flat(unsigned long long *bad, unsigned long long *tested, int vy_half_lo, int vy_half_hi, int exhaustive) {
+    // blockIdx.y enumerates vy (in half units), x-dimension enumerates numerator patterns
+    const int vh = vy_half_lo + (int)blockIdx.y;
+    if (vh > vy_half_hi) return;
+    const float d = (float)vh * 0.5f;
+    const float r = prepare_rcp(d);
+    const uint64_t total = exhaustive ? (1ull << 32) : (1ull << 22);
+    unsigned long long local_bad = 0, local_n = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t bits = exhaustive ? (uint32_t)i : hash32((uint32_t)i * 2654435761u + (uint32_t)vh);
+        float n = __uint_as_float(bits);
+        if (!div_guard_ok(n)) continue;
+        float ref = n / d;
+        float got = div_prepared(n, d, r);
+        local_n++;
+        if (__float_as_uint(ref) != __float_as_uint(got) && !(ref != ref && got != got)) local_bad++;
+    }
+    if (local_bad) atomicAdd(bad, local_bad);
+    atomicAdd(tested, local_n);
+}
+
+__global__ void check_floor_mod(unsigned long long *bad) {
+    const int n = (int)blockIdx.x + 1;
+    int nn = n <= 2048 ? n : 2048 + (n - 2048) * 15;     // 1..2048 dense, then every 15th up to 32767
+    if (nn > 32767) return;
+    const int mask = (nn & (nn - 1)) == 0 ? nn - 1 : 0;
+    const float rcp = approx_rcp((float)nn);
+    for (int t = -32768 + (int)threadIdx.x; t <= 32767; t += blockDim.x) {
+        if (floor_mod_fast(t, nn, mask, rcp) != floor_mod_i16(t, nn)) atomicAdd(bad, 1ull);
+    }
+}
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::printf("HIP error %s at %s\n", hipGetErrorString(e), #x); return 2; } } while (0)
+
+int main() {
+    unsigned long long *d_bad, *d_n, h[2];
+    CK(hipMalloc(&d_bad, 16));
+    d_n = d_bad + 1;
+    int fails = 0;
+
+    CK(hipMemset(d_bad, 0, 16));
+    hipLaunchKernelGGL(check_pk_u8, dim3(4096), dim3(256), 0, 0, d_bad);
+    CK(hipMemcpy(h, d_bad, 16, hipMemcpyDeviceToHost));
+    std::printf("A cvt_pk_u8 vs `as u8`, 2^32 patterns: mismatches %llu\n", h[0]);
+    fails += h[0] != 0;
+
+    CK(hipMemset(d_bad, 0, 16));
+    hipLaunchKernelGGL(check_div_wall, dim3(131071), dim3(256), 0, 0, d_bad);
+    CK(hipMemcpy(h, d_bad, 16, hipMemcpyDeviceToHost));
+    std::printf("B wall ay divide, 131071 x 81919 pairs: mismatches %llu\n", h[0]);
+    fails += h[0] != 0;
+
+    CK(hipMemset(d_bad, 0, 16));
+    hipLaunchKernelGGL(check_div_flat, dim3(64, 32769), dim3(256), 0, 0, d_bad, d_n, -16384, 16384, 0);
+    CK(hipMemcpy(h, d_bad, 16, hipMemcpyDeviceToHost));
+    std::printf("C flat divide, all vy in [-8192, 8192] step 0.5, hashed numerators: tested %llu mismatches %llu\n", h[1], h[0]);
+    fails += h[0] != 0;
+    const int sample_vh[48] = {1, 2, 3, 5, 7, 11, 13, 199, 200, 201, 383, 399, 401, 767, 769, 799, 800, 801, 1023, 1025, 1599, 1601, 3199, 3201,
+                               -1, -2, -3, -5, -7, -11, -13, -199, -200, -201, -383, -399, -401, -767, -769, -799, -800, -801, -1023, -1025, -1599, -1601, -3199, -16384};
+    unsigned long long tot_bad = 0, tot_n = 0;
+    for (int k = 0; k < 48; k++) {
+        CK(hipMemset(d_bad, 0, 16));
+        hipLaunchKernelGGL(check_div_flat, dim3(8192, 1), dim3(256), 0, 0, d_bad, d_n, sample_vh[k], sample_vh[k], 1);
+        CK(hipMemcpy(h, d_bad, 16, hipMemcpyDeviceToHost));
+        tot_bad += h[0]; tot_n += h[1];
+    }
+    std::printf("C flat divide, every f32 numerator for 48 vy values: tested %llu mismatches %llu\n", tot_n, tot_bad);
+    fails += tot_bad != 0;
+
+    CK(hipMemset(d_bad, 0, 16));
+    hipLaunchKernelGGL(check_floor_mod, dim3(4096), dim3(256), 0, 0, d_bad);
+    CK(hipMemcpy(h, d_bad, 16, hipMemcpyDeviceToHost));
+    std::printf("D floor modulus helper: mismatches %llu\n", h[0]);
+    fails += h[0] != 0;
+
+    std::printf(fails ? "NUMERICS FAIL\n" : "NUMERICS OK\n");
+    return fails ? 1 : 0;
+}
