@@ -27,11 +27,12 @@
 
 namespace dg {
 
-constexpr int TILE_W = 128;       // columns per workgroup
+constexpr int TILE_W = 64;        // columns per workgroup
 constexpr int TILE_H = 64;        // rows per workgroup = lanes per wave
-constexpr int TILE_STRIDE = 132;  // dwords per LDS tile row: 16-B aligned rows, breaks the power-of-two stride
+constexpr int TILE_STRIDE = 68;   // dwords per LDS tile row (16-B aligned rows for the b128 read-out)
 constexpr int WAVES = 8;
 constexpr int THREADS = WAVES * 64;
+constexpr int SPAN_CAP = 512;     // spans of one tile's 64 columns staged in LDS (16 KB); typical tiles hold 100-400
 
 __global__ __launch_bounds__(256) void dg_setup_spans(RasterParams P) {
     const int f = blockIdx.y;
@@ -50,9 +51,53 @@ __global__ __launch_bounds__(256) void dg_setup_spans(RasterParams P) {
 
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 
+// One screen column (64 rows of it) for one wavefront: walk the column's spans in draw order, keep the last opaque
+// writer per row.  `src` points at the column's first DevRSpan — in LDS when the tile's spans were staged, else in HBM.
+template <typename SpanPtr>
+__device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const DevFrame &fr, const uint32_t *pal, SpanPtr src, uint32_t n,
+                                                  int lane, int y, int y0, float vy, float r_vy) {
+    const uint8_t *texel_idx = P.scene.texel_idx, *texel_opq = P.scene.texel_opq, *flats = P.scene.flats;
+    uint32_t color = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + (uint32_t)lane;
+        uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+        bool hit = false;
+        if (i < n) {
+            ra = src[2 * i];
+            rb = src[2 * i + 1];
+            hit = hi_i16(ra.x) >= y0 && lo_i16(ra.x) <= y0 + (TILE_H - 1);
+        }
+        unsigned long long m = __ballot(hit);
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t w0 = bcast(ra.x, j), w1 = bcast(ra.y, j), w2 = bcast(ra.z, j), w3 = bcast(ra.w, j);
+            const uint32_t w4 = bcast(rb.x, j), w5 = bcast(rb.y, j), w6 = bcast(rb.z, j), w7 = bcast(rb.w, j);
+            if (y >= lo_i16(w0) && y <= hi_i16(w0)) {
+                const uint32_t kind = w6 & 0xffu;
+                if (kind == SPAN_WALL) {
+                    const uint32_t o = wall_texel_offset(w1, w2, w4, w5, w6, w7, y);
+                    const bool opaque = (w6 & 0x100u) ? texel_opq[o] != 0 : true;
+                    if (opaque) color = shade(pal[texel_idx[o]], bits_f32(w3));
+                } else if (kind == SPAN_FLAT) {
+                    float factor;
+                    const uint32_t o = flat_texel_offset(fr, w1, w2, w4, w5, w6, vy, r_vy, factor);
+                    color = shade(pal[flats[o]], factor);
+                } else {
+                    const uint32_t o = sky_texel_offset(P.scene, P.k, w2, y);
+                    if (o != 0xffffffffu && texel_opq[o]) color = pal[texel_idx[o]];
+                }
+            }
+        }
+    }
+    return color;
+}
+
 __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[TILE_H * TILE_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint4 lspans[SPAN_CAP * 2];
     __shared__ uint32_t pal[256];
+    __shared__ uint32_t lcoff[TILE_W + 1];
 
     const int f = blockIdx.z;
     const DevFrame fr = P.frames[f];
@@ -64,60 +109,38 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
     const float vy = P.k.CFY - (float)y;      // visplanes.rs:109, a per-row constant
     const float r_vy = prepare_rcp(vy);
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
-    const DevRSpan *rspans = P.rspans + fr.span_base;
-    const uint8_t *texel_idx = P.scene.texel_idx, *texel_opq = P.scene.texel_opq, *flats = P.scene.flats;
+    const uint4 *gspans = reinterpret_cast<const uint4 *>(P.rspans + fr.span_base);
 
+    // Stage: palette, the tile's 65 column offsets, then the tile's spans.  The spans of 64 adjacent columns are one
+    // contiguous range of the column-major span array, so this is a single fully coalesced burst with every load of the
+    // workgroup in flight at once — the dependent chain col_off -> spans is paid once per tile instead of once per column.
     if (threadIdx.x < 256) pal[threadIdx.x] = P.scene.palette[threadIdx.x];
+    if (threadIdx.x <= TILE_W) {
+        const int xc = x0 + (int)threadIdx.x;
+        lcoff[threadIdx.x] = coff[xc < W ? xc : W];
+    }
     __syncthreads();
+    const uint32_t t0 = lcoff[0], n_tile = lcoff[TILE_W] - t0;
+    const bool staged = n_tile <= SPAN_CAP;
+    if (staged) {
+        for (uint32_t i = threadIdx.x; i < 2 * n_tile; i += THREADS) lspans[i] = gspans[2 * t0 + i];
+        __syncthreads();
+    }
 
     for (int c = wave; c < TILE_W; c += WAVES) {
-        const int x = x0 + c;
-        uint32_t color = 0;
-        if (x < W) {
-            const uint32_t n0 = coff[x], n1 = coff[x + 1];
-            for (uint32_t base = n0; base < n1; base += 64) {
-                const uint32_t i = base + (uint32_t)lane;
-                uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
-                bool hit = false;
-                if (i < n1) {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(&rspans[i]);
-                    ra = src[0];
-                    rb = src[1];
-                    hit = hi_i16(ra.x) >= y0 && lo_i16(ra.x) <= y0 + (TILE_H - 1);
-                }
-                unsigned long long m = __ballot(hit);
-                while (m) {
-                    const int j = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const uint32_t w0 = bcast(ra.x, j), w1 = bcast(ra.y, j), w2 = bcast(ra.z, j), w3 = bcast(ra.w, j);
-                    const uint32_t w4 = bcast(rb.x, j), w5 = bcast(rb.y, j), w6 = bcast(rb.z, j), w7 = bcast(rb.w, j);
-                    if (y >= lo_i16(w0) && y <= hi_i16(w0)) {
-                        const uint32_t kind = w6 & 0xffu;
-                        if (kind == SPAN_WALL) {
-                            const uint32_t o = wall_texel_offset(w1, w2, w4, w5, w6, w7, y);
-                            const bool opaque = (w6 & 0x100u) ? texel_opq[o] != 0 : true;
-                            if (opaque) color = shade(pal[texel_idx[o]], bits_f32(w3));
-                        } else if (kind == SPAN_FLAT) {
-                            float factor;
-                            const uint32_t o = flat_texel_offset(fr, w1, w2, w4, w5, w6, vy, r_vy, factor);
-                            color = shade(pal[flats[o]], factor);
-                        } else {
-                            const uint32_t o = sky_texel_offset(P.scene, P.k, w2, y);
-                            if (o != 0xffffffffu && texel_opq[o]) color = pal[texel_idx[o]];
-                        }
-                    }
-                }
-            }
-        }
+        const uint32_t n0 = lcoff[c], n = lcoff[c + 1] - n0;
+        uint32_t color;
+        if (staged) color = raster_column(P, fr, pal, &lspans[2 * (n0 - t0)], n, lane, y, y0, vy, r_vy);
+        else color = raster_column(P, fr, pal, gspans + 2 * (size_t)n0, n, lane, y, y0, vy, r_vy);
         tile[lane * TILE_STRIDE + c] = color;
     }
     __syncthreads();
 
-    // Read-out: groups of 4 pixels (16 B of RGBX in LDS -> 12 B of RGB24 in HBM); 32 groups per tile row, the lanes
-    // of a wave cover two full tile rows = 2 x 384 contiguous bytes.
+    // Read-out: groups of 4 pixels (16 B of RGBX in LDS -> 12 B of RGB24 in HBM); 16 groups per tile row, so the lanes of
+    // a wave cover four tile rows = 4 x 192 contiguous bytes.
     uint8_t *fb = P.fb + (size_t)f * (size_t)3 * (size_t)W * (size_t)H;
     for (int g = threadIdx.x; g < TILE_H * (TILE_W / 4); g += THREADS) {
-        const int row = g >> 5, gc = g & 31;
+        const int row = g >> 4, gc = g & 15;
         const int yy = y0 + row, xx = x0 + 4 * gc;
         if (yy < H && xx < W) {   // W % 4 == 0 (checked at dg_create), so a group never straddles the right edge
             const uint4 p = *reinterpret_cast<const uint4 *>(&tile[row * TILE_STRIDE + 4 * gc]);
