@@ -14,6 +14,7 @@ namespace dg {
 
 namespace {
 const float kPi = 3.14159265358979323846f;
+const uint32_t kMaxSpansPerColumn = 512;   // = SPAN_CAP of dg_raster_tiles (kernels.hip)
 }
 
 int bin_frame(const Scene &sc, const FrameConsts &k, const dg_frame_lists &fl, BinnedFrame &out, std::string &err) {
@@ -120,7 +121,10 @@ int bin_frame(const Scene &sc, const FrameConsts &k, const dg_frame_lists &fl, B
     // stable counting sort of the events by column
     out.col_off.assign((size_t)W + 1, 0);
     for (const DevSpan &s : out.events) out.col_off[(size_t)s.x + 1]++;
-    for (int x = 0; x < W; x++) out.col_off[(size_t)x + 1] += out.col_off[(size_t)x];
+    for (int x = 0; x < W; x++) {
+        if (out.col_off[(size_t)x + 1] > kMaxSpansPerColumn) { err = "more than 512 spans in one screen column (raster kernel staging limit)"; return DG_ERR_CAPACITY; }
+        out.col_off[(size_t)x + 1] += out.col_off[(size_t)x];
+    }
     out.cursor.assign(out.col_off.begin(), out.col_off.end() - 1);
     out.spans.resize(out.events.size());
     for (const DevSpan &s : out.events) out.spans[out.cursor[(size_t)s.x]++] = s;

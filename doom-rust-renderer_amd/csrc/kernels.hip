@@ -5,16 +5,17 @@
 //                            (bitmap_render.rs:241-251: 3 f32 divides -> texture column + light factor),
 //                            sky texture column, floor/ceiling vx; merges the span with its record into one
 //                            self-contained 32-byte DevRSpan.
-// Kernel 2  dg_raster_tiles  one workgroup (8 wavefronts) per (frame, 128-column x 64-row tile); a wavefront
-//                            takes one screen column at a time with lane = row, so that
-//                              * the span list of the column is wave-uniform: ONE coalesced load brings in up to 64
-//                                spans (lane i = span i, 2 x 16 B), a ballot picks the ones touching these 64 rows
-//                                and v_readlane broadcasts their 8 words — no dependent record loads; spans are
-//                                applied in draw order so the last writer wins exactly as in the reference,
-//                              * a wall column reads one texture column ([x][y] texel layout => consecutive bytes),
-//                              * the palette lives in LDS (1 KB),
+// Kernel 2  dg_raster_tiles  one workgroup (8 wavefronts) per (frame, 64-column x 64-row tile):
+//                              * the spans of the tile's 64 columns are ONE contiguous range of the column-major span
+//                                array; they are staged in LDS with a single coalesced burst (16 KB), together with the
+//                                palette (1 KB) and the tile's column offsets;
+//                              * a wavefront takes one screen column at a time with lane = row.  Pass 1 walks the column's
+//                                spans in draw order and records per row the last span covering it (one v_readlane per
+//                                span); pass 2 evaluates every row ONCE with its winner's parameters fetched from LDS —
+//                                exact last-writer-wins, no overdraw evaluation, one pass per span kind;
+//                              * a wall column reads one texture column ([x][y] texel layout => consecutive bytes);
 //                              * finished pixels go to an LDS tile [row][col] and leave the CU as fully
-//                                coalesced 12-byte-per-lane RGB24 row segments (384 B contiguous per tile row).
+//                                coalesced 12-byte-per-lane RGB24 row segments (192 B contiguous per tile row).
 //                            Every pixel of the tile is stored (uncovered = 0,0,0) which fuses the reference's
 //                            per-frame `Pixels::new()` clear (pixels.rs:10-14) into the one write pass.
 //
@@ -51,43 +52,65 @@ __global__ __launch_bounds__(256) void dg_setup_spans(RasterParams P) {
 
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 
-// One screen column (64 rows of it) for one wavefront: walk the column's spans in draw order, keep the last opaque
-// writer per row.  `src` points at the column's first DevRSpan — in LDS when the tile's spans were staged, else in HBM.
-template <typename SpanPtr>
-__device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const DevFrame &fr, const uint32_t *pal, SpanPtr src, uint32_t n,
-                                                  int lane, int y, int y0, float vy, float r_vy) {
-    const uint8_t *texel_idx = P.scene.texel_idx, *texel_opq = P.scene.texel_opq, *flats = P.scene.flats;
+// Per-pixel evaluation with per-lane span words (the lanes of one wave may own pixels of different spans).
+__device__ __forceinline__ uint32_t eval_wall(const RasterParams &P, const uint32_t *pal, const uint4 a, const uint4 b, int y, bool &opaque) {
+    const uint32_t o = wall_texel_offset(a.y, a.z, b.x, b.y, b.z, b.w, y);
+    opaque = (b.z & 0x100u) ? P.scene.texel_opq[o] != 0 : true;
+    return shade(pal[P.scene.texel_idx[o]], bits_f32(a.w));
+}
+__device__ __forceinline__ uint32_t eval_flat(const RasterParams &P, const DevFrame &fr, const uint32_t *pal, const uint4 a, const uint4 b,
+                                              float vy, float r_vy) {
+    float factor;
+    const uint32_t o = flat_texel_offset(fr, a.y, a.z, b.x, b.y, b.z, vy, r_vy, factor);
+    return shade(pal[P.scene.flats[o]], factor);
+}
+
+// One screen column (64 rows of it) for one wavefront, spans staged in LDS (lw0 = word 0 of every span, lsp = all 8 words).
+//   Pass 1  walk the column's spans in draw order; every row remembers the LAST span that covers it ("winner").  Spans
+//           that may be transparent (masked walls, sprites, sky: the immediate flag) are evaluated on the spot because
+//           whether they overwrite depends on the texel.  Cost per span: one v_readlane and a handful of scalar ops.
+//   Pass 2  each row fetches its winner's 8 words from LDS and is evaluated once — one pass per span KIND present, with
+//           per-lane parameters, instead of one pass per span; overdrawn pixels are never evaluated.
+__device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const DevFrame &fr, const uint32_t *pal, const uint32_t *lw0,
+                                                  const uint4 *lsp, uint32_t n, int lane, int y, int y0, float vy, float r_vy) {
     uint32_t color = 0;
+    uint32_t winner = 0xffffffffu;            // index (within the column) of the opaque span owning this row
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + (uint32_t)lane;
-        uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+        uint32_t w0v = 0;
         bool hit = false;
         if (i < n) {
-            ra = src[2 * i];
-            rb = src[2 * i + 1];
-            hit = hi_i16(ra.x) >= y0 && lo_i16(ra.x) <= y0 + (TILE_H - 1);
+            w0v = lw0[i];
+            hit = w0_cbot(w0v) >= y0 && w0_ctop(w0v) <= y0 + (TILE_H - 1);
         }
         unsigned long long m = __ballot(hit);
         while (m) {
             const int j = __builtin_ctzll(m);
             m &= m - 1;
-            const uint32_t w0 = bcast(ra.x, j), w1 = bcast(ra.y, j), w2 = bcast(ra.z, j), w3 = bcast(ra.w, j);
-            const uint32_t w4 = bcast(rb.x, j), w5 = bcast(rb.y, j), w6 = bcast(rb.z, j), w7 = bcast(rb.w, j);
-            if (y >= lo_i16(w0) && y <= hi_i16(w0)) {
-                const uint32_t kind = w6 & 0xffu;
-                if (kind == SPAN_WALL) {
-                    const uint32_t o = wall_texel_offset(w1, w2, w4, w5, w6, w7, y);
-                    const bool opaque = (w6 & 0x100u) ? texel_opq[o] != 0 : true;
-                    if (opaque) color = shade(pal[texel_idx[o]], bits_f32(w3));
-                } else if (kind == SPAN_FLAT) {
-                    float factor;
-                    const uint32_t o = flat_texel_offset(fr, w1, w2, w4, w5, w6, vy, r_vy, factor);
-                    color = shade(pal[flats[o]], factor);
+            const uint32_t w0 = bcast(w0v, j);
+            const bool in = (uint32_t)(y - w0_ctop(w0)) <= (uint32_t)(w0_cbot(w0) - w0_ctop(w0));
+            if (!w0_immediate(w0)) {
+                if (in) winner = base + (uint32_t)j;
+            } else if (in) {
+                const uint4 a = lsp[2 * (base + (uint32_t)j)], b = lsp[2 * (base + (uint32_t)j) + 1];   // same address in every lane: LDS broadcast
+                if (w0_kind(w0) == SPAN_WALL) {
+                    bool opaque;
+                    const uint32_t c = eval_wall(P, pal, a, b, y, opaque);
+                    if (opaque) { color = c; winner = 0xffffffffu; }
                 } else {
-                    const uint32_t o = sky_texel_offset(P.scene, P.k, w2, y);
-                    if (o != 0xffffffffu && texel_opq[o]) color = pal[texel_idx[o]];
+                    const uint32_t o = sky_texel_offset(P.scene, P.k, a.z, y);
+                    if (o != 0xffffffffu && P.scene.texel_opq[o]) { color = pal[P.scene.texel_idx[o]]; winner = 0xffffffffu; }
                 }
             }
+        }
+    }
+    if (winner != 0xffffffffu) {
+        const uint4 a = lsp[2 * winner], b = lsp[2 * winner + 1];
+        if (w0_kind(a.x) == SPAN_FLAT) {
+            color = eval_flat(P, fr, pal, a, b, vy, r_vy);
+        } else {
+            bool opaque;
+            color = eval_wall(P, pal, a, b, y, opaque);
         }
     }
     return color;
@@ -96,6 +119,7 @@ __device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const D
 __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[TILE_H * TILE_STRIDE];
     __shared__ __attribute__((aligned(16))) uint4 lspans[SPAN_CAP * 2];
+    __shared__ uint32_t lw0[SPAN_CAP];
     __shared__ uint32_t pal[256];
     __shared__ uint32_t lcoff[TILE_W + 1];
 
@@ -111,28 +135,37 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
     const uint4 *gspans = reinterpret_cast<const uint4 *>(P.rspans + fr.span_base);
 
-    // Stage: palette, the tile's 65 column offsets, then the tile's spans.  The spans of 64 adjacent columns are one
-    // contiguous range of the column-major span array, so this is a single fully coalesced burst with every load of the
-    // workgroup in flight at once — the dependent chain col_off -> spans is paid once per tile instead of once per column.
     if (threadIdx.x < 256) pal[threadIdx.x] = P.scene.palette[threadIdx.x];
     if (threadIdx.x <= TILE_W) {
         const int xc = x0 + (int)threadIdx.x;
         lcoff[threadIdx.x] = coff[xc < W ? xc : W];
     }
     __syncthreads();
-    const uint32_t t0 = lcoff[0], n_tile = lcoff[TILE_W] - t0;
-    const bool staged = n_tile <= SPAN_CAP;
-    if (staged) {
-        for (uint32_t i = threadIdx.x; i < 2 * n_tile; i += THREADS) lspans[i] = gspans[2 * t0 + i];
-        __syncthreads();
-    }
 
-    for (int c = wave; c < TILE_W; c += WAVES) {
-        const uint32_t n0 = lcoff[c], n = lcoff[c + 1] - n0;
-        uint32_t color;
-        if (staged) color = raster_column(P, fr, pal, &lspans[2 * (n0 - t0)], n, lane, y, y0, vy, r_vy);
-        else color = raster_column(P, fr, pal, gspans + 2 * (size_t)n0, n, lane, y, y0, vy, r_vy);
-        tile[lane * TILE_STRIDE + c] = color;
+    // The spans of adjacent columns are one contiguous range of the column-major span array.  Stage as many whole columns
+    // as fit in LDS (normally the whole tile) with one coalesced burst — every load of the workgroup in flight at once, so
+    // the dependent chain col_off -> spans is paid once per tile — then rasterise those columns; repeat if needed.
+    int c_lo = 0;
+    while (c_lo < TILE_W) {
+        const uint32_t t0 = lcoff[c_lo];
+        int c_hi = TILE_W;
+        if (lcoff[TILE_W] - t0 > SPAN_CAP) {
+            c_hi = c_lo + 1;                  // a single column always fits: the binner caps a column at SPAN_CAP spans
+            while (c_hi < TILE_W && lcoff[c_hi + 1] - t0 <= SPAN_CAP) c_hi++;
+        }
+        const uint32_t n_stage = lcoff[c_hi] - t0;
+        for (uint32_t i = threadIdx.x; i < 2 * n_stage; i += THREADS) {
+            const uint4 v = gspans[2 * (size_t)t0 + i];
+            lspans[i] = v;
+            if ((i & 1u) == 0) lw0[i >> 1] = v.x;
+        }
+        __syncthreads();
+        for (int c = c_lo + wave; c < c_hi; c += WAVES) {
+            const uint32_t n0 = lcoff[c] - t0, n = lcoff[c + 1] - lcoff[c];
+            tile[lane * TILE_STRIDE + c] = raster_column(P, fr, pal, lw0 + n0, lspans + 2 * n0, n, lane, y, y0, vy, r_vy);
+        }
+        c_lo = c_hi;
+        if (c_lo < TILE_W) __syncthreads();   // before the staging area is reused
     }
     __syncthreads();
 

@@ -36,7 +36,7 @@ static_assert(sizeof(DevSpanAux) == 8, "DevSpanAux must be 8 bytes");
 // from DevSpan + its wall/plane record, so that a wavefront needs ONE coalesced load for up to 64 spans of a column
 // and no dependent record loads afterwards (all eight words are broadcast with v_readlane).
 //   word   WALL (bitmap_render.rs:241-263)                    FLAT (visplanes.rs:103-126)           SKY (visplanes.rs:65-72)
-//   w0     ctop | cbot << 16                                  same                                   same
+//   w0     ctop | imm << 15 | cbot << 16 | kind << 30          same                                   same      (imm: may be transparent)
 //   w1     d = (bottom_y - top_y) as f32                      wz * vx (f32)                          -
 //   w2     texel offset of the texture column                 byte offset of the 64x64 flat          texel offset of the sky column (or ~0)
 //   w3     light factor (f32, clamped >= 0)                   -                                      -

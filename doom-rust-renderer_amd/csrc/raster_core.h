@@ -29,6 +29,14 @@ DG_HD float bits_f32(uint32_t u) {
 #endif
 }
 DG_HD int32_t lo_i16(uint32_t w) { return (int32_t)(int16_t)(w & 0xffffu); }
+// DevRSpan word 0: ctop (bits 0-13) | immediate-flag (bit 15) | cbot (bits 16-29) | kind (bits 30-31); rows are < 16384.
+DG_HD uint32_t pack_w0(int32_t ctop, int32_t cbot, uint32_t kind, bool immediate) {
+    return (uint32_t)(ctop & 0x3fff) | (immediate ? 0x8000u : 0u) | ((uint32_t)(cbot & 0x3fff) << 16) | (kind << 30);
+}
+DG_HD int32_t w0_ctop(uint32_t w0) { return (int32_t)(w0 & 0x3fffu); }
+DG_HD int32_t w0_cbot(uint32_t w0) { return (int32_t)((w0 >> 16) & 0x3fffu); }
+DG_HD uint32_t w0_kind(uint32_t w0) { return w0 >> 30; }
+DG_HD bool w0_immediate(uint32_t w0) { return (w0 & 0x8000u) != 0; }
 DG_HD int32_t hi_i16(uint32_t w) { return (int32_t)(int16_t)(w >> 16); }
 
 // ---- instruction-level shortcuts (each one is verified exhaustively on the GPU by tests/gpu_numerics) ----------------
@@ -154,7 +162,7 @@ DG_HD DevRSpan resolve_wall_span(const DevSpan &sp, const DevWallRec &r) {
     // and for a finite ay the middle term is +-0.0 and drops out (h >= 1), so the kernel evaluates h + ay * uy1.
     const float d = (float)((int32_t)sp.bot_y - (int32_t)sp.top_y);
     DevRSpan o;
-    o.w[0] = (uint32_t)(uint16_t)sp.ctop | ((uint32_t)(uint16_t)sp.cbot << 16);
+    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_WALL, r.has_holes != 0);
     o.w[1] = f32_bits(d);
     o.w[2] = r.texel_off + (uint32_t)tx * (uint32_t)h;
     o.w[3] = f32_bits(light_factor(r.lightf, z));
@@ -168,7 +176,7 @@ DG_HD DevRSpan resolve_flat_span(const DevSpan &sp, const DevPlaneRec &p, const 
     const float vx = (k.CFX - (float)sp.x) / k.ARC;                      // visplanes.rs:108
     const float wzvx = p.wz * vx;                                        // numerator of wy = wz * vx / vy (visplanes.rs:114)
     DevRSpan o;
-    o.w[0] = (uint32_t)(uint16_t)sp.ctop | ((uint32_t)(uint16_t)sp.cbot << 16);
+    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_FLAT, false);
     o.w[1] = f32_bits(wzvx);
     o.w[2] = p.flat_off;
     o.w[3] = 0;
@@ -183,7 +191,7 @@ DG_HD DevRSpan resolve_sky_span(const DevSpan &sp, const DevScene &sc, const Dev
     int32_t tx = f32_as_i16((float)sp.x * 256.0f / (float)k.W);
     tx = wrap_i16(tx + f.sky_tx_offset) % 256;
     DevRSpan o;
-    o.w[0] = (uint32_t)(uint16_t)sp.ctop | ((uint32_t)(uint16_t)sp.cbot << 16);
+    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_SKY, true);   // sky textures may have holes: evaluated immediately
     o.w[1] = 0;
     o.w[2] = (tx < 0 || tx >= sc.sky_w) ? 0xffffffffu : sc.sky_texel_off + (uint32_t)tx * (uint32_t)sc.sky_h;
     o.w[3] = o.w[4] = o.w[5] = 0;

@@ -58,10 +58,10 @@ int emul_render(void *scene, int W, int H, const dg_view *view_in, uint8_t *rgb,
                                              : resolve_sky_span(s, ds, k, bf.hdr);
             const uint32_t *w = r.w;
             // ... and what dg_raster_tiles does for every row of the span (lane = row)
-            for (int y = lo_i16(w[0]); y <= hi_i16(w[0]); y++) {
+            for (int y = w0_ctop(w[0]); y <= w0_cbot(w[0]); y++) {
                 uint32_t c = 0;
                 bool wr = false;
-                const uint32_t kind = w[6] & 0xffu;
+                const uint32_t kind = w0_kind(w[0]);
                 if (kind == SPAN_WALL) {
                     uint32_t o = wall_texel_offset(w[1], w[2], w[4], w[5], w[6], w[7], y);
                     if (!(w[6] & 0x100u) || ds.texel_opq[o]) { c = shade(pal[ds.texel_idx[o]], bits_f32(w[3])); wr = true; }
