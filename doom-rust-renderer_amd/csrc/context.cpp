@@ -405,7 +405,7 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     }
     if (!sc.flat_pool.empty()) HIP_TRY(hipMemcpy(c->d_flats, sc.flat_pool.data(), sc.flat_pool.size(), hipMemcpyHostToDevice));
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
-    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, sky.texel_off, sky.w, sky.h};
+    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
     c->scene = &sc;
     return DG_OK;
 }

@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t eval_flat(const RasterParams &P, const DevFr
 //   Pass 2  each row fetches its winner's 8 words from LDS and is evaluated once — one pass per span KIND present, with
 //           per-lane parameters, instead of one pass per span; overdrawn pixels are never evaluated.
 __device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const DevFrame &fr, const uint32_t *pal, const uint32_t *lw0,
-                                                  const uint4 *lsp, uint32_t n, int lane, int y, int y0, float vy, float r_vy) {
+                                                  const uint4 *lsp, uint32_t n, int lane, int y, int y0, float vy, float r_vy, int srow) {
     uint32_t color = 0;
     uint32_t winner = 0xffffffffu;            // index (within the column) of the opaque span owning this row
     for (uint32_t base = 0; base < n; base += 64) {
@@ -98,7 +98,7 @@ __device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const D
                     const uint32_t c = eval_wall(P, pal, a, b, y, opaque);
                     if (opaque) { color = c; winner = 0xffffffffu; }
                 } else {
-                    const uint32_t o = sky_texel_offset(P.scene, P.k, a.z, y);
+                    const uint32_t o = sky_texel_offset(a.z, srow);
                     if (o != 0xffffffffu && P.scene.texel_opq[o]) { color = pal[P.scene.texel_idx[o]]; winner = 0xffffffffu; }
                 }
             }
@@ -106,11 +106,15 @@ __device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const D
     }
     if (winner != 0xffffffffu) {
         const uint4 a = lsp[2 * winner], b = lsp[2 * winner + 1];
-        if (w0_kind(a.x) == SPAN_FLAT) {
+        const uint32_t kind = w0_kind(a.x);
+        if (kind == SPAN_FLAT) {
             color = eval_flat(P, fr, pal, a, b, vy, r_vy);
-        } else {
+        } else if (kind == SPAN_WALL) {
             bool opaque;
             color = eval_wall(P, pal, a, b, y, opaque);
+        } else {                                  // sky bitmap without holes: plain lookup, no lighting
+            const uint32_t o = sky_texel_offset(a.z, srow);
+            if (o != 0xffffffffu) color = pal[P.scene.texel_idx[o]];
         }
     }
     return color;
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
     const int y = y0 + lane;
     const float vy = P.k.CFY - (float)y;      // visplanes.rs:109, a per-row constant
     const float r_vy = prepare_rcp(vy);
+    const int srow = sky_row(P.scene, P.k, y);    // visplanes.rs:68-72, a per-row constant
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
     const uint4 *gspans = reinterpret_cast<const uint4 *>(P.rspans + fr.span_base);
 
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
         __syncthreads();
         for (int c = c_lo + wave; c < c_hi; c += WAVES) {
             const uint32_t n0 = lcoff[c] - t0, n = lcoff[c + 1] - lcoff[c];
-            tile[lane * TILE_STRIDE + c] = raster_column(P, fr, pal, lw0 + n0, lspans + 2 * n0, n, lane, y, y0, vy, r_vy);
+            tile[lane * TILE_STRIDE + c] = raster_column(P, fr, pal, lw0 + n0, lspans + 2 * n0, n, lane, y, y0, vy, r_vy, srow);
         }
         c_lo = c_hi;
         if (c_lo < TILE_W) __syncthreads();   // before the staging area is reused

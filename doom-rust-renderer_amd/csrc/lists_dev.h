@@ -86,6 +86,7 @@ struct DevScene {             // immutable, uploaded once per map
     const uint8_t *flats;
     uint32_t sky_texel_off;   // sky bitmap (256 x 128 expected)
     int32_t sky_w, sky_h;
+    uint32_t sky_has_holes;   // any transparent texel in the sky bitmap (then sky spans are evaluated in draw order)
 };
 
 struct DevConsts {            // src/renderer/constants.rs, as f32 bit patterns computed on the host

@@ -191,7 +191,7 @@ DG_HD DevRSpan resolve_sky_span(const DevSpan &sp, const DevScene &sc, const Dev
     int32_t tx = f32_as_i16((float)sp.x * 256.0f / (float)k.W);
     tx = wrap_i16(tx + f.sky_tx_offset) % 256;
     DevRSpan o;
-    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_SKY, true);   // sky textures may have holes: evaluated immediately
+    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_SKY, sc.sky_has_holes != 0);   // a sky bitmap with holes is evaluated in draw order
     o.w[1] = 0;
     o.w[2] = (tx < 0 || tx >= sc.sky_w) ? 0xffffffffu : sc.sky_texel_off + (uint32_t)tx * (uint32_t)sc.sky_h;
     o.w[3] = o.w[4] = o.w[5] = 0;
@@ -232,13 +232,16 @@ DG_HD uint32_t flat_texel_offset(const DevFrame &f, uint32_t w1, uint32_t w2, ui
     return w2 + (uint32_t)(ty * 64 + tx);
 }
 
-// Texture row of one sky pixel (visplanes.rs:68-72); returns ~0 when outside the sky bitmap.
-DG_HD uint32_t sky_texel_offset(const DevScene &sc, const DevConsts &k, uint32_t w2, int32_t y) {
+// Texture row of a sky pixel (visplanes.rs:68-72): depends on the screen row only; -1 when outside the sky bitmap.
+DG_HD int32_t sky_row(const DevScene &sc, const DevConsts &k, int32_t y) {
     int32_t ty = f32_as_i16((float)y * 128.0f * 2.0f / (float)k.H);
     if (ty < 0) ty = wrap_i16(ty + 128);
     ty %= 128;
-    if (w2 == 0xffffffffu || ty < 0 || ty >= sc.sky_h) return 0xffffffffu;
-    return w2 + (uint32_t)ty;
+    return (ty < 0 || ty >= sc.sky_h) ? -1 : ty;
+}
+// Texel offset of one sky pixel; ~0 when the reference would index outside the sky bitmap.
+DG_HD uint32_t sky_texel_offset(uint32_t w2, int32_t row) {
+    return (w2 == 0xffffffffu || row < 0) ? 0xffffffffu : w2 + (uint32_t)row;
 }
 
 }  // namespace dg

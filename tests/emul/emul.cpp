@@ -45,7 +45,7 @@ int emul_render(void *scene, int W, int H, const dg_view *view_in, uint8_t *rgb,
     DevScene ds;
     ds.palette = pal.data(); ds.texel_idx = sc.texel_idx.data(); ds.texel_opq = sc.texel_opq.data(); ds.flats = sc.flat_pool.data();
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
-    ds.sky_texel_off = sky.texel_off; ds.sky_w = sky.w; ds.sky_h = sky.h;
+    ds.sky_texel_off = sky.texel_off; ds.sky_w = sky.w; ds.sky_h = sky.h; ds.sky_has_holes = sky.has_holes;
     DevConsts k{fk.ARC, fk.GCFX, fk.CFX, fk.CFY, W, H};
 
     std::memset(rgb, 0, (size_t)3 * W * H);
@@ -71,7 +71,7 @@ int emul_render(void *scene, int W, int H, const dg_view *view_in, uint8_t *rgb,
                     uint32_t o = flat_texel_offset(bf.hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), factor);
                     c = shade(pal[ds.flats[o]], factor); wr = true;
                 } else {
-                    uint32_t o = sky_texel_offset(ds, k, w[2], y);
+                    uint32_t o = sky_texel_offset(w[2], sky_row(ds, k, y));
                     if (o != 0xffffffffu && ds.texel_opq[o]) { c = pal[ds.texel_idx[o]]; wr = true; }
                 }
                 if (wr) {
