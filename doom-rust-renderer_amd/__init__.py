@@ -170,6 +170,18 @@ class Scene:
         _check(lib().dg_scene_floor_height_at(self._h, x, y, h))
         return h.value
 
+    def sector_count(self) -> int:
+        return lib().dg_scene_sector_count(self._h)
+
+    def set_sector_light(self, sector: int, light: int):
+        _check(lib().dg_scene_set_sector_light(self._h, sector, light))
+
+    def mobj_count(self) -> int:
+        return lib().dg_scene_mobj_count(self._h)
+
+    def set_mobj_state(self, mobj: int, sprite, frame: int = 0, full_bright: bool = False):
+        _check(lib().dg_scene_set_mobj_state(self._h, mobj, sprite.encode() if sprite else None, frame, int(full_bright)))
+
     def build_lists(self, W: int, H: int, view: DgView) -> DgFrameLists:
         fl = DgFrameLists()
         _check(lib().dg_build_lists(self._h, W, H, ctypes.byref(view), ctypes.byref(fl)))

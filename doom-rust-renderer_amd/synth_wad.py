@@ -355,7 +355,7 @@ SPRITE_DEFS = [(2035, "BAR1", False, 23, 32), (2028, "COLU", False, 19, 47), (48
                (3004, "POSS", True, 41, 56), (3001, "TROO", True, 43, 57)]
 
 
-def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M1") -> bytes:
+def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M1", quirks: bool = False) -> bytes:
     rng = XorShift32(seed)
     gx, gy = (16, 12) if heavy else (8, 6)
     sky_pct = 50 if heavy else 25
@@ -637,6 +637,9 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
               ("SEGS", bytes(seg_bytes)), ("SSECTORS", ssectors), ("NODES", nodes), ("SECTORS", sectors), ("REJECT", b""),
               ("BLOCKMAP", b"")]
 
+    if quirks:
+        lumps = _apply_quirks(lumps, p, patches, map_name.upper())
+
     # ---- container ----
     body = bytearray()
     directory = bytearray()
@@ -645,6 +648,49 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
         body += data
     hdr = b"IWAD" + struct.pack("<II", len(lumps), 12 + len(body))
     return hdr + bytes(body) + bytes(directory)
+
+
+def _apply_quirks(lumps, p, patches, map_marker):
+    """Loader edge cases on top of a finished lump list (default WADs stay byte-identical):
+      * a decoy FLOOR0 lump earlier in the file (the directory HashMap keeps the LAST lump of a name, src/wad.rs:153-154)
+      * a second map marker + empty lumps at the end (map lumps come from the FIRST marker, src/wad.rs:175-183)
+      * TEXTURE2 that redefines BRICK2 (the later definition wins, textures.rs:252-253) and adds EXTRA1 and the 8-character
+        name LONGNAME (not NUL-terminated, src/wad.rs:112-126)
+      * sidedef texture names in lower case (Textures::get upper-cases, textures.rs:155), sector flats in lower case
+        (found through the upper-cased directory but not "SKY" / not animated: flats.rs:103-111, visplanes.rs:89)."""
+    out = []
+    for name, data in lumps:
+        if name == "F_START":
+            out.append(("FLOOR0", bytes((i * 7 + 3) & 0xFF for i in range(4096))))   # decoy, must lose
+        if name == "P_END":
+            pass
+        if name == "TEXTURE1":
+            out.append((name, data))
+            defs = [("BRICK2", 128, 128, [(0, 0, p["STN2"])]), ("EXTRA1", 64, 128, [(0, 0, p["PNL2"]), (8, 24, p["MTL2"])]),
+                    ("LONGNAME", 64, 64, [(0, 0, p["MTL2"]), (32, 0, p["MTL2"])]),
+                    ("SKY2", 256, 128, [(64 * i, 0, p["SKY%d" % (3 - i)]) for i in range(4)]),       # episode 2 / MAP12-20 (game.rs:199-227)
+                    ("SKY3", 256, 128, [(64 * i, 0, p["SKY%d" % ((i + 2) % 4)]) for i in range(4)])]  # episode 3 / MAP21+
+            blobs = []
+            for tn, w, h, pl in defs:
+                b = _name8(tn) + struct.pack("<IhhIh", 0, w, h, 0, len(pl))
+                for ox, oy, pi in pl:
+                    b += struct.pack("<hhhhh", ox, oy, pi, 1, 0)
+                blobs.append(b)
+            off = 4 + 4 * len(blobs)
+            t2 = struct.pack("<I", len(blobs))
+            for b in blobs:
+                t2 += struct.pack("<I", off)
+                off += len(b)
+            out.append(("TEXTURE2", t2 + b"".join(blobs)))
+            continue
+        if name == "SIDEDEFS":
+            data = data.replace(b"BRICK3\0\0", b"EXTRA1\0\0").replace(b"PANEL1\0\0", b"panel1\0\0").replace(b"STONE1\0\0", b"LONGNAME")
+        if name == "SECTORS":
+            data = data.replace(b"FLOOR5\0\0", b"floor5\0\0").replace(b"NUKAGE1\0", b"nukage1\0", 2).replace(b"F_SKY1\0\0", b"f_sky1\0\0", 1)
+        out.append((name, data))
+    out.append((map_marker, b""))
+    out += [(n, b"") for n in ("THINGS", "LINEDEFS", "SIDEDEFS", "VERTEXES", "SEGS", "SSECTORS", "NODES", "SECTORS", "REJECT", "BLOCKMAP")]
+    return out
 
 
 def synth_route(seed: int = 1993, heavy: bool = False):

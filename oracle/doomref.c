@@ -594,6 +594,23 @@ bad:
     return NULL;
 }
 
+int dr_sector_count(const dr_scene *s) { return s->nsectors; }
+int dr_set_sector_light(dr_scene *s, int sector, int16_t light_level) {
+    if (sector < 0 || sector >= s->nsectors) return fail("bad sector");
+    s->sectors[sector].light = light_level;
+    return 0;
+}
+int dr_mobj_count(const dr_scene *s) { return s->nmobjs; }
+int dr_set_mobj_state(dr_scene *s, int mobj, const char *sprite, uint8_t frame, int full_bright) {
+    if (mobj < 0 || mobj >= s->nmobjs) return fail("bad map object");
+    MapObject *mo = &s->mobjs[mobj];
+    if (!sprite) { mo->is_null = 1; return 0; }
+    memset(mo->sprite, 0, sizeof mo->sprite);
+    strncpy(mo->sprite, sprite, 4);
+    mo->frame = frame; mo->full_bright = full_bright; mo->is_null = 0;
+    return 0;
+}
+
 int dr_player_start(const dr_scene *s, float *x, float *y, float *angle) {    /* game.rs:151-156, things.rs:46-55 */
     for (int i = 0; i < s->nthings; i++)
         if (s->things[i].type == 1) { *x = s->things[i].x; *y = s->things[i].y; *angle = s->things[i].angle; return 0; }

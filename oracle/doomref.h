@@ -40,6 +40,13 @@ int dr_player_start(const dr_scene *s, float *x, float *y, float *angle);
  * Returns 0 and writes *h if a sector was found, 1 otherwise (caller keeps the old height). */
 int dr_floor_height_at(const dr_scene *s, float x, float y, float *h);
 
+/* Game-state inputs the renderer reads and the reference mutates between frames: sector.light_level
+ * (src/lights.rs) and a map object's current State (src/map_objects.rs:63-121).  sprite == NULL means StateId::S_NULL. */
+int dr_sector_count(const dr_scene *s);
+int dr_set_sector_light(dr_scene *s, int sector, int16_t light_level);
+int dr_mobj_count(const dr_scene *s);
+int dr_set_mobj_state(dr_scene *s, int mobj, const char *sprite, uint8_t frame, int full_bright);
+
 /* Pixels::new() + Renderer::new(..).render() (src/game.rs:505-519) at a runtime W x H.
  * rgb must hold 3*W*H bytes; it is zeroed first (fresh Vec, src/renderer/pixels.rs:10-14).
  * flags bit0: evaluate cosf/sinf per floor/ceiling pixel exactly where the source does

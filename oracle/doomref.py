@@ -50,6 +50,10 @@ def lib():
         L.dr_f32_as_u8.argtypes = [ctypes.c_float]
         L.dr_constants.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.dr_last_stats.argtypes = [ctypes.POINTER(Stats)]
+        L.dr_sector_count.argtypes = [ctypes.c_void_p]
+        L.dr_set_sector_light.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int16]
+        L.dr_mobj_count.argtypes = [ctypes.c_void_p]
+        L.dr_set_mobj_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint8, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -87,6 +91,20 @@ class Scene:
         if lib().dr_render(self._h, W, H, ctypes.byref(v), ptr, flags):
             raise OracleError(lib().dr_last_error().decode())
         return buf.raw if out is None else None
+
+    def sector_count(self) -> int:
+        return lib().dr_sector_count(self._h)
+
+    def set_sector_light(self, sector: int, light: int):
+        if lib().dr_set_sector_light(self._h, sector, light):
+            raise OracleError(lib().dr_last_error().decode())
+
+    def mobj_count(self) -> int:
+        return lib().dr_mobj_count(self._h)
+
+    def set_mobj_state(self, mobj: int, sprite, frame: int = 0, full_bright: bool = False):
+        if lib().dr_set_mobj_state(self._h, mobj, sprite.encode() if sprite else None, frame, int(full_bright)):
+            raise OracleError(lib().dr_last_error().decode())
 
     def stats(self) -> dict:
         st = Stats()

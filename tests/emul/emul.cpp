@@ -25,6 +25,16 @@ void *emul_load(const uint8_t *wad, size_t len, const char *map_name) {
     return load_scene_from_wad(wad, len, map_name, g_err);
 }
 void emul_free(void *s) { delete (Scene *)s; }
+int emul_set_sector_light(void *s, int sector, int16_t light) { ((Scene *)s)->sectors[(size_t)sector].light = light; return 0; }
+int emul_set_mobj_state(void *s, int mobj, const char *sprite, uint8_t frame, int full_bright) {
+    Scene *sc = (Scene *)s;
+    MapObjectRec &m = sc->mobjs[(size_t)mobj];
+    if (!sprite) { m.sprite_frame = -1; return 0; }
+    int sf = sc->find_or_add_sprite_frame(sprite, frame, g_err);
+    if (sf < 0) return -1;
+    m.sprite_frame = sf; m.full_bright = full_bright;
+    return 0;
+}
 
 // stats[0..3] = spans, walls, planes, covered pixels
 int emul_render(void *scene, int W, int H, const dg_view *view_in, uint8_t *rgb, uint64_t *stats) {

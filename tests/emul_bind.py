@@ -25,6 +25,8 @@ def lib():
         L.emul_free.argtypes = [ctypes.c_void_p]
         L.emul_last_error.restype = ctypes.c_char_p
         L.emul_render.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(DgView), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.emul_set_sector_light.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int16]
+        L.emul_set_mobj_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint8, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -33,6 +35,13 @@ class EmulScene:
     def __init__(self, wad: bytes, map_name="e1m1"):
         self._h = lib().emul_load(wad, len(wad), map_name.encode())
         if not self._h:
+            raise RuntimeError(lib().emul_last_error().decode())
+
+    def set_sector_light(self, sector, light):
+        lib().emul_set_sector_light(self._h, sector, light)
+
+    def set_mobj_state(self, mobj, sprite, frame=0, full_bright=False):
+        if lib().emul_set_mobj_state(self._h, mobj, sprite.encode() if sprite else None, frame, int(full_bright)):
             raise RuntimeError(lib().emul_last_error().decode())
 
     def render(self, W, H, rec, timestamp=0.0):

@@ -133,3 +133,29 @@ def test_animated_flats_and_off_path_views(oracle_scene1993, wad1993, path1993, 
                 es.render(320, 200, rec)
             continue
         assert es.render(320, 200, rec)[0] == ref
+
+
+def test_game_state_snapshots_match_oracle(oracle, wad1993, path1993):
+    """F4: per-frame inputs the reference mutates between frames — sector light levels (src/lights.rs, may leave
+    [0,255]: diminish_color has no upper clamp) and map-object states (S_NULL = not drawn, other sprite/frame,
+    full_bright) — applied identically to the oracle and to the product's scene."""
+    osc = oracle.Scene(wad1993, "e1m1")
+    es = emul_bind.EmulScene(wad1993)
+    rng = np.random.default_rng(21)
+    for s in range(osc.sector_count()):
+        light = int(rng.choice([-20, 0, 40, 96, 200, 255, 300]))
+        osc.set_sector_light(s, light)
+        es.set_sector_light(s, light)
+    sprites = [("BAR1", 0), ("POSS", 0), ("TROO", 0), ("COLU", 0), (None, 0), ("TRED", 0)]
+    for m in range(osc.mobj_count()):
+        spr, fr = sprites[int(rng.integers(len(sprites)))]
+        fb = bool(rng.integers(2))
+        osc.set_mobj_state(m, spr, fr, fb)
+        es.set_mobj_state(m, spr, fr, fb)
+    changed = 0
+    plain = oracle.Scene(wad1993, "e1m1")
+    for i in range(0, 1000, 25):
+        ref = osc.render(320, 200, path1993[i])
+        assert es.render(320, 200, path1993[i])[0] == ref, f"frame {i}"
+        changed += ref != plain.render(320, 200, path1993[i])
+    assert changed > 20
