@@ -1,6 +1,6 @@
 """First GPU contact: parity of the HIP path vs the oracle on sampled path frames + kernel timings."""
 import importlib, sys, time, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import doomref

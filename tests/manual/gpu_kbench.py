@@ -1,6 +1,6 @@
 """Kernel tuning loop: parity on sampled frames, then median replay time of 250 resident frames at 1280x800 (and 320x200)."""
 import importlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import doomref

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Render one viewpoint of a WAD map to raw RGB24 (and optionally PNG) through the GPU library or the CPU oracle.
 
-    python tools/render_views.py --wad doom1.wad --map e1m1 --size 1024x768 --out frame.rgb [--view x,y,angle] [--oracle] [--png f.png]
-    python tools/render_views.py --wad synth:1993 --map e1m1 --size 320x200 --out /tmp/f.rgb --oracle
+    python tests/manual/render_views.py --wad doom1.wad --map e1m1 --size 1024x768 --out frame.rgb [--view x,y,angle] [--oracle] [--png f.png]
+    python tests/manual/render_views.py --wad synth:1993 --map e1m1 --size 320x200 --out /tmp/f.rgb --oracle
 
 Without --view the Player 1 start is used (src/game.rs:151-156); floor_height comes from the sector under the eye
 (src/game.rs:386-388).  This is the tool for the external true-reference comparison described in INTEGRATION.md §5."""
 import argparse, importlib, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
