@@ -74,6 +74,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = int(os.environ.get("DOOMGPU_BENCH_DEVICE", local_rank))   # override only to rehearse N > 1 on a 1-GPU box
 
     # torch first: its bundled HIP runtime must be the one libdoomgpu.so binds to (same soname, loaded once).
     import torch
@@ -81,7 +82,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend="gloo")     # timing barrier / MAX only; the data path has no collective
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(device)
 
     import numpy as np
     dg = importlib.import_module("doom-rust-renderer_amd")
@@ -94,7 +95,7 @@ def main():
     route = rank_route(sw.synth_route(1993), rank, world)
     path = cp.make_camera_path(route, lambda x, y, d: scene.floor_height_at(x, y, d), 1000)
     n_slots = max(1, min(args.slots, (1000 + B - 1) // B))
-    ctx = dg.Context(W, H, max_batch=B, slots=n_slots, device=local_rank, host_threads=args.host_threads)
+    ctx = dg.Context(W, H, max_batch=B, slots=n_slots, device=device, host_threads=args.host_threads)
     ctx.upload_scene(scene)
 
     batches = [np.concatenate([path, path])[b0:b0 + B] for b0 in range(0, n_slots * B, B)]
