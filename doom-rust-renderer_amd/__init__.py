@@ -107,6 +107,8 @@ _SIGNATURES = {
     "dg_wait": (ctypes.c_int, [_P, ctypes.c_int]),
     "dg_slot_framebuffer": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(_P)]),
     "dg_readback": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "dg_alloc_host": (_P, [ctypes.c_size_t]),
+    "dg_free_host": (None, [_P]),
     "dg_prepare_views": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(DgView), ctypes.c_int]),
     "dg_replay_slot": (ctypes.c_int, [_P, ctypes.c_int]),
     "dg_scene_texture_id": (ctypes.c_int, [_P, ctypes.c_char_p]),
@@ -234,6 +236,9 @@ class Context:
         out = np.empty((count, self.height, self.width, 3), dtype=np.uint8)
         _check(lib().dg_readback(self._h, slot, first, count, out.ctypes.data_as(_P)))
         return out
+
+    def readback_into(self, slot: int, first: int, count: int, host_ptr: int):
+        _check(lib().dg_readback(self._h, slot, first, count, _P(host_ptr)))
 
     def framebuffer_ptr(self, slot: int) -> int:
         p = _P()

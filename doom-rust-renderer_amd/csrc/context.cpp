@@ -121,6 +121,7 @@ struct dg_ctx {
     FrameConsts fk{};
     DevConsts dk{};
     const Scene *scene = nullptr;
+    size_t uploaded_texels = 0;         // texel pool size at dg_upload_scene time (grows when new sprite bitmaps are decoded)
     // device scene
     uint32_t *d_palette = nullptr;
     uint8_t *d_texel_idx = nullptr, *d_texel_opq = nullptr, *d_flats = nullptr;
@@ -166,6 +167,7 @@ int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *
     if (!c->scene) return set_err(DG_ERR_INVALID, "no scene uploaded (dg_upload_scene)");
     if (n <= 0 || n > c->cfg.max_batch) return set_err(DG_ERR_CAPACITY, "batch size outside [1, max_batch]");
     const Scene &sc = *c->scene;
+    if (sc.texel_idx.size() != c->uploaded_texels) return set_err(DG_ERR_INVALID, "the scene decoded new bitmaps since dg_upload_scene: upload it again");
     const int W = c->cfg.width, H = c->cfg.height;
     std::vector<int> rc((size_t)n, 0);
     std::vector<std::string> errs((size_t)n);
@@ -407,6 +409,7 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
     c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
     c->scene = &sc;
+    c->uploaded_texels = sc.texel_idx.size();
     return DG_OK;
 }
 
@@ -452,6 +455,13 @@ int dg_readback(dg_ctx *c, int slot, int first, int count, uint8_t *out) {
     s.busy = false;
     return DG_OK;
 }
+
+void *dg_alloc_host(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void dg_free_host(void *p) { if (p) (void)hipHostFree(p); }
 
 int dg_render_views(dg_ctx *c, const dg_view *views, int n, uint8_t *out) {
     int rc = dg_submit_views(c, 0, views, n);

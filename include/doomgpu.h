@@ -60,6 +60,8 @@ int dg_scene_set_sector_light(dg_scene *s, int sector, int16_t light_level);
 int dg_scene_mobj_count(const dg_scene *s);
 /* state: sprite name (4 chars), frame (0 = 'A'), full_bright, or sprite == NULL for StateId::S_NULL (not drawn). */
 int dg_scene_set_mobj_state(dg_scene *s, int mobj, const char *sprite, uint8_t frame, int full_bright);
+/* A state change may decode sprite bitmaps the GPU copy does not hold yet: submissions then fail with DG_ERR_INVALID until
+ * dg_upload_scene is called again (light levels never need a re-upload). */
 
 /* ---- viewpoint (reference: `Player`, src/game.rs:40-45, + Renderer::new's timestamp) ------------------------ */
 typedef struct dg_view {
@@ -96,6 +98,9 @@ int dg_submit_views(dg_ctx *ctx, int slot, const dg_view *views, int n);
 int dg_wait(dg_ctx *ctx, int slot);
 /* Device address of the slot's framebuffer slab (frame i at + i*3*W*H). Valid until the slot is re-submitted. */
 int dg_slot_framebuffer(dg_ctx *ctx, int slot, void **device_ptr);
+/* Page-locked host memory for dg_readback / dg_render_views targets (a pageable buffer works too, at a lower PCIe rate). */
+void *dg_alloc_host(size_t bytes);
+void dg_free_host(void *p);
 /* D2H copy of frames [first, first+count) of a completed slot. */
 int dg_readback(dg_ctx *ctx, int slot, int first, int count, uint8_t *rgb24_out);
 

@@ -270,3 +270,42 @@ def test_animated_flats_timestamp_on_gpu(dg, scene1993, oracle_scene1993, path19
             ref = np.frombuffer(oracle_scene1993.render(320, 200, list(path1993[i]) + [ts]), dtype=np.uint8).reshape(200, 320, 3)
             assert np.array_equal(out[k], ref), f"frame {i} t={ts}"
     ctx.close()
+
+
+def test_new_sprite_bitmaps_require_reupload(dg, wad1993, path1993):
+    """dg_scene_set_mobj_state may decode bitmaps the GPU does not hold; the library refuses to render with a stale
+    device copy instead of sampling garbage."""
+    sc = dg.Scene(wad1993, "e1m1")
+    ctx = make_ctx(dg, sc, 320, 200, 1, slots=1)
+    v = dg.make_views(path1993[100:101])
+    ctx.render(v)
+    changed = False
+    for frame in range(1, 8):           # a frame letter the map does not use yet does not exist in the synthetic WAD: expect DG_ERR_WAD
+        try:
+            sc.set_mobj_state(0, "POSS", frame)
+            changed = True
+            break
+        except dg.DoomGpuError as e:
+            assert e.code == dg.DG_ERR_WAD
+    sc.set_mobj_state(0, "ELEC", 0)     # ELEC A0 exists; whether it is already decoded depends on the map's things
+    try:
+        ctx.render(v)
+    except dg.DoomGpuError as e:
+        assert e.code == dg.DG_ERR_INVALID
+        ctx.upload_scene(sc)
+    ctx.render(v)
+    ctx.close()
+
+
+def test_pinned_host_readback(dg, scene1993, path1993):
+    ctx = make_ctx(dg, scene1993, 320, 200, 4, slots=1)
+    views = dg.make_views(path1993[0:4])
+    ref = ctx.render(views)
+    p = dg.lib().dg_alloc_host(4 * ctx.frame_bytes)
+    assert p
+    ctx.submit(0, views)
+    ctx.readback_into(0, 0, 4, p)
+    got = np.ctypeslib.as_array((ctypes.c_uint8 * (4 * ctx.frame_bytes)).from_address(p)).reshape(4, 200, 320, 3)
+    assert np.array_equal(got, ref)
+    dg.lib().dg_free_host(p)
+    ctx.close()
