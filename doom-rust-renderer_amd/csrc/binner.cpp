@@ -44,23 +44,8 @@ int bin_frame(const Scene &sc, const FrameConsts &k, const dg_frame_lists &fl, B
             const BitmapInfo &bi = sc.bitmaps[(size_t)r.bitmap];
             if (bi.w <= 0 || bi.h <= 0) { err = "zero-sized bitmap (reference divides by zero)"; return DG_ERR_RENDER; }
             if (out.walls.size() >= 65535) { err = "more than 65535 drawn records in a frame"; return DG_ERR_CAPACITY; }
-            DevWallRec d;
-            float dx = r.line_start_x - r.line_end_x, dy = r.line_start_y - r.line_end_y;
-            float len = std::sqrt(dx * dx + dy * dy);                  // Line::length, geometry.rs:84-86
-            float uz0 = r.line_start_x, uz1 = r.line_end_x;
-            d.A = 0.0f / uz0;
-            d.B = len / uz1;
-            d.C = 1.0f / uz0;
-            d.D = 1.0f / uz1;
-            d.uy1 = r.top_height - r.bottom_height;
-            d.lightf = (float)r.light_level / 255.0f;
-            d.dxf = (float)(r.end_x - r.start_x);
-            d.start_x = r.start_x;
-            d.texel_off = bi.texel_off;
-            d.w = (int16_t)bi.w; d.h = (int16_t)bi.h;
-            d.off_x = (int16_t)wrap_i16(f32_as_i16(r.start_offset) + r.offset_x);
-            d.off_y = r.offset_y;
-            d.has_holes = bi.has_holes;
+            const DevWallRec d = make_wall_rec(bi, r.line_start_x, r.line_start_y, r.line_end_x, r.line_end_y, r.start_offset, r.start_x, r.end_x,
+                                               r.bottom_height, r.top_height, r.offset_x, r.offset_y, r.light_level);
             uint16_t rec = (uint16_t)out.walls.size();
             out.walls.push_back(d);
             const dg_bitmap_column *c = fl.columns + r.first_column;

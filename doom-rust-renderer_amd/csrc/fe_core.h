@@ -1,0 +1,219 @@
+// fe_core.h — the per-column half of the reference's front end as host/device inline functions (one call = one screen
+// column of one record).  fe_kernels.hip runs them with one lane per column; tests/emul compiles the same bodies for
+// the CPU.  They restate, column for column:
+//
+//   fe_part_column    the body of the `for x in start.x..=end.x` loop of Segs::process_sidedef      src/renderer/segs.rs:202-345
+//                     and SidedefVisPlanes::add_*/flush (as span emission + event bits)             src/renderer/sidedef_visplanes.rs:60-118
+//   fe_sprite_column  the clip arrays and the column push of draw_map_objects                       src/renderer/map_objects.rs:130-209
+//   fe_gap            the zero-filled Visplane entries between two adds of one visplane             src/renderer/visplanes.rs:28-38
+//
+// Spans are resolved on the spot into the raster kernel's DevRSpan (raster_core.h) and appended to the column's scratch
+// list with a sort key that encodes the reference's draw order (frontend.hpp: walls in BSP order, visplanes in push
+// order, then the sprite / masked-wall sequence).
+#pragma once
+#include <stddef.h>
+
+#include "fe_dev.h"
+#include "raster_core.h"
+
+namespace dg {
+
+struct alignas(16) FeU4 { uint32_t x, y, z, w; };
+
+struct FeParams {
+    DevScene scene;
+    DevConsts k;
+    const DevFrame *frames;       // [n_frames] view constants + span_base (= f * span_stride)
+    const FeFrame *fframes;       // [n_frames]
+    const FePart *parts;
+    const FeSprite *sprites;
+    const uint32_t *behind;
+    // per-column scratch, [frame][slot][W] so that neighbouring lanes touch neighbouring addresses
+    uint32_t *keys;               // FE_MAX_SPANS_PER_COL slots
+    FeU4 *sspans;                 // 2 x FeU4 per slot
+    FeColRec *recs;               // FE_MAX_RECS_PER_COL slots
+    uint32_t *cnt;                // [frame][W] spans emitted per column
+    uint64_t *events;             // [frame][FE_MAX_SKY_SLOTS][3][W64] add-floor / add-ceiling / flush bits per column
+    uint32_t *flags;              // [frame] FE_OVF_*
+    // outputs consumed by dg_raster_tiles
+    uint32_t *col_off;            // [frame][W + 1]
+    DevRSpan *rspans;
+    int32_t n_frames;
+    uint32_t span_stride;         // rspans reserved per frame
+    uint32_t w64;                 // (W + 63) / 64
+};
+
+struct FeColumn {                 // what one lane carries through the walk
+    int32_t x;
+    int32_t hor, fo, co;          // horizontal_ocl / floor_ver_ocl / ceiling_ver_ocl of this column (segs.rs:70-74)
+    uint32_t nsp, nrec, ovf;
+};
+
+DG_HD int32_t fe_min(int32_t a, int32_t b) { return a < b ? a : b; }
+DG_HD int32_t fe_max(int32_t a, int32_t b) { return a > b ? a : b; }
+
+DG_HD void fe_emit(const FeParams &P, int f, FeColumn &c, uint32_t key, const DevRSpan &r) {
+    if (c.nsp >= FE_MAX_SPANS_PER_COL) { c.ovf |= FE_OVF_SPANS; return; }
+    const size_t i = ((size_t)f * FE_MAX_SPANS_PER_COL + c.nsp) * (size_t)P.k.W + (size_t)c.x;
+    P.keys[i] = key;
+    P.sspans[2 * i] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
+    P.sspans[2 * i + 1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};
+    c.nsp++;
+}
+
+DG_HD DevSpan fe_span(int32_t ctop, int32_t cbot, int32_t top_y, int32_t bot_y, uint8_t kind, int32_t x) {
+    DevSpan s;
+    s.ctop = (int16_t)ctop; s.cbot = (int16_t)cbot; s.top_y = (int16_t)top_y; s.bot_y = (int16_t)bot_y;
+    s.rec = 0; s.kind = kind; s.pad0 = 0; s.x = (int16_t)x; s.pad1 = 0;
+    return s;
+}
+
+// One Visplane::add_point (visplanes.rs:28-38) as draw_visplane / draw_sky will see it (visplanes.rs:61-62,95-101).
+DG_HD void fe_plane(const FeParams &P, int f, const DevFrame &fr, FeColumn &c, uint32_t key, bool sky, const DevPlaneRec &pr, int32_t top, int32_t bottom) {
+    const int32_t t = fe_max(top, 0), b = fe_min(bottom, P.k.H - 1);
+    if (sky) {
+        if (t > b) return;
+        fe_emit(P, f, c, key, resolve_sky_span(fe_span(t, b, 0, 0, SPAN_SKY, c.x), P.scene, P.k, fr));
+    } else {
+        if (wrap_i16(b - t) <= 1) return;
+        fe_emit(P, f, c, key, resolve_flat_span(fe_span(t, b, 0, 0, SPAN_FLAT, c.x), pr, P.k));
+    }
+}
+
+DG_HD void fe_occlude(const FeParams &P, FeColumn &c) {                        // segs.rs:113-117
+    c.hor = 1;
+    c.fo = c.co = (int32_t)(int16_t)((int16_t)P.k.H / 2);
+}
+
+// Column c.x of part `pi` (sx <= x <= ex).  Returns FE_EV_* bits.
+DG_HD uint32_t fe_part_column(const FeParams &P, int f, const DevFrame &fr, const FePart &p, uint32_t pi, FeColumn &c) {
+    const int32_t hm1 = P.k.H - 1, x = c.x;
+    const uint32_t fl = p.flags;
+    const bool two = (fl & FEP_TWO_SIDED_MID) != 0, only = (fl & FEP_ONLY_OCCL) != 0, lower = (fl & FEP_LOWER) != 0, upper = (fl & FEP_UPPER) != 0;
+    const bool drawc = (fl & FEP_DRAW_CEILING) != 0;
+    const bool full = !lower && !upper && !only;
+    const bool planes_here = !two && (full || only);
+    uint32_t ev = 0;
+    if (!c.hor) {
+        const int32_t bottom_y = f32_as_i16(p.bsy + ((float)x - p.bsx) * p.bdelta);
+        const int32_t top_y = f32_as_i16(p.tsy + ((float)x - p.tsx) * p.tdelta);
+        const int32_t fo = c.fo, co = c.co;
+        const int32_t cb = fe_min(hm1, fe_min(fo, bottom_y));
+        const int32_t ct = fe_max(0, fe_max(co, top_y));
+        const bool vis = cb >= ct;
+        if (vis) {
+            const bool ext_b = lower || (!two && full), ext_t = upper || (!two && full);
+            if (two || ext_b || ext_t) {                                       // the records draw_map_objects clips against
+                if (c.nrec >= FE_MAX_RECS_PER_COL) c.ovf |= FE_OVF_RECS;
+                else {
+                    FeColRec r;
+                    r.part = (uint16_t)pi;
+                    r.kind = (uint16_t)((two ? FEC_TWO_SIDED : 0) | (ext_b ? FEC_EXT_BOTTOM : 0) | (ext_t ? FEC_EXT_TOP : 0) | (drawc ? FEC_DRAW_CEILING : 0));
+                    r.ctop = (int16_t)ct; r.cbot = (int16_t)cb; r.bot_y = (int16_t)bottom_y; r.top_y = (int16_t)top_y; r.pad = 0;
+                    P.recs[((size_t)f * FE_MAX_RECS_PER_COL + c.nrec) * (size_t)P.k.W + (size_t)x] = r;
+                    c.nrec++;
+                }
+            }
+            if ((fl & FEP_HAS_BITMAP) && (two || !only)) {                     // inline draw (segs.rs:231-258) or masked replay (segs.rs:593-597)
+                const uint32_t key = two ? (FE_KEY_LATE | (p.seq << 2)) : (FE_KEY_WALL | (pi << 2));
+                fe_emit(P, f, c, key, resolve_wall_span(fe_span(ct, cb, top_y, bottom_y, SPAN_WALL, x), p.wall));
+            }
+        }
+        if (planes_here && vis) {
+            bool added = false;
+            if (cb < fo && cb != hm1) {
+                fe_plane(P, f, fr, c, FE_KEY_PLANE | (pi << 2), (fl & FEP_FLOOR_SKY) != 0, p.floor_plane, cb, fo);
+                added = true; ev |= FE_EV_FADD;
+            }
+            if (drawc && ct > co && ct != -1) {
+                fe_plane(P, f, fr, c, FE_KEY_PLANE | (pi << 2) | 1u, (fl & FEP_CEIL_SKY) != 0, p.ceil_plane, co, ct);
+                added = true; ev |= FE_EV_CADD;
+            }
+            if (!added) ev |= FE_EV_FLUSH;
+        } else if (planes_here && !vis && fo > co) {                           // occluded wall, open vertical gap (segs.rs:293-318)
+            if (bottom_y <= co) {
+                fe_plane(P, f, fr, c, FE_KEY_PLANE | (pi << 2), (fl & FEP_FLOOR_SKY) != 0, p.floor_plane, co, fo);
+                ev |= FE_EV_FADD;
+                fe_occlude(P, c);
+            }
+            if (drawc && top_y >= fo) {
+                fe_plane(P, f, fr, c, FE_KEY_PLANE | (pi << 2) | 1u, (fl & FEP_CEIL_SKY) != 0, p.ceil_plane, co, fo);
+                ev |= FE_EV_CADD;
+                fe_occlude(P, c);
+            }
+        }
+        if (!two && vis) {
+            if (only) {
+                c.fo = cb;
+                if (drawc) c.co = ct;
+            }
+            if (lower) c.fo = ct;
+            if (upper) c.co = cb;
+        }
+    } else {
+        ev |= FE_EV_FLUSH;
+    }
+    if (!two && full) fe_occlude(P, c);
+    return ev;
+}
+
+// Column c.x of one sprite (x0 <= x < x1): clip arrays from the wall records of this column that are not behind the
+// sprite's centre, then the clipped column (map_objects.rs:130-209).
+DG_HD void fe_sprite_column(const FeParams &P, int f, const FeFrame &ff, const FeSprite &s, FeColumn &c) {
+    const int32_t H = P.k.H, x = c.x;
+    int32_t top_clip = -1, bottom_clip = H;
+    const uint32_t *row = P.behind + ff.behind_base + s.behind_off;
+    for (uint32_t i = 0; i < c.nrec; i++) {
+        const FeColRec r = P.recs[((size_t)f * FE_MAX_RECS_PER_COL + i) * (size_t)P.k.W + (size_t)x];
+        if ((row[r.part >> 5] >> (r.part & 31)) & 1u) continue;
+        if (r.kind & FEC_TWO_SIDED) {
+            if (r.kind & FEC_DRAW_CEILING) top_clip = fe_max(top_clip, r.top_y);
+            bottom_clip = fe_min(bottom_clip, r.bot_y);
+        } else {
+            if (r.kind & FEC_EXT_BOTTOM) bottom_clip = fe_min(bottom_clip, r.ctop);
+            if (r.kind & FEC_EXT_TOP) top_clip = fe_max(top_clip, r.cbot);
+        }
+    }
+    const int32_t bottom_y = f32_as_i16(s.bsy + ((float)x - s.bsx) * s.bdelta);
+    const int32_t top_y = f32_as_i16(s.tsy + ((float)x - s.tsx) * s.tdelta);
+    const int32_t ct = fe_max(0, fe_max(top_y, top_clip));
+    const int32_t cb = fe_min(H - 1, fe_min(bottom_y, bottom_clip));
+    if (ct > cb) return;
+    fe_emit(P, f, c, FE_KEY_LATE | (s.seq << 2), resolve_wall_span(fe_span(ct, cb, top_y, bottom_y, SPAN_WALL, x), s.wall));
+}
+
+// Is column x a zero-filled entry of a visplane of this part: no add and no flush at x, and the nearest event on
+// either side inside [sx, ex] is an add (the visplane was opened before x and extended after it).
+DG_HD bool fe_gap(const uint64_t *add, const uint64_t *flush, int32_t x, int32_t sx, int32_t ex) {
+    const int32_t w0 = x >> 6, b0 = x & 63;
+    if (((add[w0] | flush[w0]) >> b0) & 1ull) return false;
+    {   // nearest event to the left
+        int32_t w = w0;
+        uint64_t m = (add[w] | flush[w]) & ((1ull << b0) - 1ull);
+        while (!m) {
+            if (w * 64 <= sx) return false;
+            w--;
+            m = add[w] | flush[w];
+        }
+        const int32_t b = 63 - __builtin_clzll(m);
+        if (w * 64 + b < sx || !((add[w] >> b) & 1ull)) return false;
+    }
+    {   // nearest event to the right
+        int32_t w = w0;
+        uint64_t m = (add[w] | flush[w]) & (b0 == 63 ? 0ull : ~0ull << (b0 + 1));
+        while (!m) {
+            if (w * 64 + 63 >= ex) return false;
+            w++;
+            m = add[w] | flush[w];
+        }
+        const int32_t b = __builtin_ctzll(m);
+        if (w * 64 + b > ex || !((add[w] >> b) & 1ull)) return false;
+    }
+    return true;
+}
+
+DG_HD const uint64_t *fe_event_words(const FeParams &P, int f, int32_t sky_slot, int kind) {
+    return P.events + (((size_t)f * FE_MAX_SKY_SLOTS + (size_t)sky_slot) * 3 + (size_t)kind) * (size_t)P.w64;
+}
+
+}  // namespace dg

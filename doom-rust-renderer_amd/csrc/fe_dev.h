@@ -1,0 +1,83 @@
+// fe_dev.h — formats of the device column walk ("device front end"): the per-column half of the reference's
+// Segs::process_sidedef (src/renderer/segs.rs:202-345), the visplane column entries of SidedefVisPlanes
+// (src/renderer/sidedef_visplanes.rs) and the per-column half of draw_map_objects (src/renderer/map_objects.rs:130-209)
+// run on the GPU with one lane per screen column.  The host keeps the per-seg half (BSP order, view transform, frustum
+// clip, projection, texture pegging — segs.rs:353-590 up to the column loop) and the per-sprite half (projection, sorting,
+// the sprite/masked-wall interleave), which are tiny and independent of the frame width, and ships them as FePart /
+// FeSprite records instead of finished span lists.
+#pragma once
+#include <stdint.h>
+
+#include "lists_dev.h"
+
+namespace dg {
+
+enum : uint32_t {
+    FEP_ONLY_OCCL = 1u << 0,     // Flags.only_occlusions
+    FEP_LOWER = 1u << 1,         // Flags.is_lower_wall
+    FEP_UPPER = 1u << 2,         // Flags.is_upper_wall
+    FEP_DRAW_CEILING = 1u << 3,  // Flags.draw_ceiling
+    FEP_TWO_SIDED_MID = 1u << 4, // Flags.is_two_sided_middle_wall
+    FEP_HAS_BITMAP = 1u << 5,    // texture != "-"
+    FEP_FLOOR_SKY = 1u << 6,     // floor flat name contains "SKY"
+    FEP_CEIL_SKY = 1u << 7,      // ceiling flat name contains "SKY"
+};
+
+// One process_sidedef call that reached its column loop, in BSP order (index = position in Segs.segs).
+struct FePart {
+    int32_t sx, ex;               // bottom.start.x / bottom.end.x (== top's)
+    float bsy, bsx, bdelta;       // bottom.start.y as f32, bottom.start.x as f32, bottom_delta  (segs.rs:158-161,205-209)
+    float tsy, tsx, tdelta;       // same for the top edge
+    uint32_t flags;
+    int32_t sky_slot;             // index into the per-frame event bit arrays when a sky flat is involved, else -1
+    uint32_t seq;                 // two-sided middle walls: position in the phase-3/4 draw sequence
+    uint32_t pad;
+    DevWallRec wall;              // constants of render_vertical_bitmap_line for this record (valid with FEP_HAS_BITMAP)
+    DevPlaneRec floor_plane;      // constants of draw_visplane for the floor / ceiling plane of this call
+    DevPlaneRec ceil_plane;
+};
+static_assert(sizeof(FePart) == 48 + 48 + 32, "FePart layout");
+
+// One visible map object (src/renderer/map_objects.rs:168-209), any order; `seq` is its place in the draw sequence.
+struct FeSprite {
+    int32_t x0, x1;               // columns [x0, x1)
+    float bsy, bsx, bdelta;
+    float tsy, tsx, tdelta;
+    uint32_t seq;
+    uint32_t behind_off;          // word offset of this sprite's "wall record is behind me" bit row (is_behind_vertex)
+    uint32_t pad[2];
+    DevWallRec wall;
+};
+static_assert(sizeof(FeSprite) == 48 + 48, "FeSprite layout");
+
+struct FeFrame {
+    uint32_t part_base, n_parts;
+    uint32_t sprite_base, n_sprites;
+    uint32_t behind_base;         // uint32 words
+    uint32_t behind_words;        // words per sprite row = ceil(n_parts / 32)
+    uint32_t n_sky_slots;
+    uint32_t pad;
+};
+static_assert(sizeof(FeFrame) == 32, "FeFrame layout");
+
+// Per-column scratch written by the walk and read back by the same lane when it clips the sprites.
+enum : uint16_t { FEC_TWO_SIDED = 1, FEC_EXT_BOTTOM = 2, FEC_EXT_TOP = 4, FEC_DRAW_CEILING = 8 };
+struct FeColRec {                 // BitmapColumn of one wall record at this screen column (bitmap_render.rs:19-25)
+    uint16_t part;
+    uint16_t kind;                // FEC_* : how draw_map_objects uses it (map_objects.rs:141-163)
+    int16_t ctop, cbot, bot_y, top_y;
+    uint32_t pad;
+};
+static_assert(sizeof(FeColRec) == 16, "FeColRec layout");
+
+enum : uint32_t { FE_EV_FADD = 1, FE_EV_CADD = 2, FE_EV_FLUSH = 4 };          // SidedefVisPlanes events of one column of one part
+enum : uint32_t { FE_OVF_SPANS = 1, FE_OVF_RECS = 2, FE_OVF_FRAME = 4 };      // per-frame overflow flags (the batch is redone on the host)
+
+constexpr uint32_t FE_MAX_SPANS_PER_COL = 48;    // spans a column may emit before the frame is flagged as overflowing
+constexpr uint32_t FE_MAX_RECS_PER_COL = 48;    // wall-record columns kept per screen column
+constexpr uint32_t FE_KEY_WALL = 1u << 30;  // sort key = phase << 30 | major << 2 | minor
+constexpr uint32_t FE_KEY_PLANE = 2u << 30;
+constexpr uint32_t FE_KEY_LATE = 3u << 30;
+constexpr uint32_t FE_MAX_SKY_SLOTS = 512;   // parts per frame that may produce sky visplanes
+
+}  // namespace dg

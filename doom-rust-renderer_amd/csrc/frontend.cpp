@@ -120,6 +120,28 @@ FrameConsts make_consts(int W, int H) {
     return k;
 }
 
+DevWallRec make_wall_rec(const BitmapInfo &bi, float lsx, float lsy, float lex, float ley, float start_offset, int32_t start_x, int32_t end_x,
+                         float bottom_height, float top_height, int16_t offset_x, int16_t offset_y, int16_t light_level) {
+    DevWallRec d;
+    float dx = lsx - lex, dy = lsy - ley;
+    float len = std::sqrt(dx * dx + dy * dy);                  // Line::length, geometry.rs:84-86
+    float uz0 = lsx, uz1 = lex;
+    d.A = 0.0f / uz0;
+    d.B = len / uz1;
+    d.C = 1.0f / uz0;
+    d.D = 1.0f / uz1;
+    d.uy1 = top_height - bottom_height;
+    d.lightf = (float)light_level / 255.0f;
+    d.dxf = (float)(end_x - start_x);
+    d.start_x = start_x;
+    d.texel_off = bi.texel_off;
+    d.w = (int16_t)bi.w; d.h = (int16_t)bi.h;
+    d.off_x = (int16_t)wrap_i16(f32_as_i16(start_offset) + offset_x);
+    d.off_y = offset_y;
+    d.has_holes = bi.has_holes;
+    return d;
+}
+
 void fill_view_trig(dg_view &v) {
     if (v.trig_valid) return;
     v.cos_a = cosf(v.angle);
@@ -149,6 +171,7 @@ struct Walker {
     V2 ppos;
     float player_height;
     int status = DG_OK;
+    bool parts_mode = false;      // record FePart / FeSprite instead of walking columns
     uint32_t n_floor_planes_marker = 0;
     // visplanes carry a pool tag in the top bit of first_entry until finalisation
     static constexpr uint32_t kCeilPool = 0x80000000u;
@@ -256,6 +279,38 @@ struct Walker {
         r.sort_key = 0;
 
         const bool planes_here = !f.two_sided_mid && (full_height || f.only_occlusions);
+        if (parts_mode) {
+            if (tex >= 0) {
+                const BitmapInfo &bi = sc.bitmaps[(size_t)tex];
+                if (bi.w <= 0 || bi.h <= 0) { fail("zero-sized bitmap (reference divides by zero)"); return; }
+            }
+            FePart p;
+            std::memset(&p, 0, sizeof p);
+            p.sx = bot.sx; p.ex = bot.ex;
+            p.bsy = (float)bot.sy; p.bsx = (float)bot.sx; p.bdelta = bottom_delta;
+            p.tsy = (float)top.sy; p.tsx = (float)top.sx; p.tdelta = top_delta;
+            const bool fsky = sc.flat_sky[(size_t)s.floor_flat] != 0, csky = sc.flat_sky[(size_t)s.ceil_flat] != 0;
+            p.flags = (f.only_occlusions ? FEP_ONLY_OCCL : 0u) | (f.lower ? FEP_LOWER : 0u) | (f.upper ? FEP_UPPER : 0u) |
+                      (f.draw_ceiling ? FEP_DRAW_CEILING : 0u) | (f.two_sided_mid ? FEP_TWO_SIDED_MID : 0u) | (tex >= 0 ? FEP_HAS_BITMAP : 0u) |
+                      (fsky ? FEP_FLOOR_SKY : 0u) | (csky ? FEP_CEIL_SKY : 0u);
+            p.sky_slot = (planes_here && (fsky || (csky && f.draw_ceiling))) ? (int32_t)A.n_sky_slots++ : -1;
+            if (tex >= 0)
+                p.wall = make_wall_rec(sc.bitmaps[(size_t)tex], r.line.a.x, r.line.a.y, r.line.b.x, r.line.b.y, r.start_offset, r.start_x, r.end_x,
+                                       bottom_height, top_height, r.offset_x, r.offset_y, r.light);
+            const float lightf = (float)s.light / 255.0f;
+            p.floor_plane.wz = (float)s.floor_h - view.floor_height - 41.0f;      // visplanes.rs:112
+            p.floor_plane.gwz = k.GCFX * p.floor_plane.wz;
+            p.floor_plane.lightf = lightf;
+            p.floor_plane.flat_off = (uint32_t)s.floor_flat * 4096u;
+            p.ceil_plane.wz = (float)s.ceil_h - view.floor_height - 41.0f;
+            p.ceil_plane.gwz = k.GCFX * p.ceil_plane.wz;
+            p.ceil_plane.lightf = lightf;
+            p.ceil_plane.flat_off = (uint32_t)s.ceil_flat * 4096u;
+            if (A.parts.size() >= 65535) { fail("more than 65535 wall records in a frame"); return; }
+            A.parts.push_back(p);
+            recs.push_back(r);
+            return;
+        }
         const int16_t hm1 = (int16_t)(H - 1);
         for (int x = bot.sx; x <= bot.ex; x++) {
             if (!A.hor_ocl[(size_t)x]) {
@@ -401,6 +456,7 @@ struct Walker {
     void map_objects() {
         const int W = k.W, H = k.H;
         const size_t n_wall_recs = recs.size();
+        if (parts_mode) A.behind_words = (uint32_t)((n_wall_recs + 31) / 32);
         std::vector<uint32_t> mo;   // indices of map-object records in recs
         for (const MapObjectRec &m : sc.mobjs) {
             if (m.sprite_frame < 0) continue;                         // S_NULL
@@ -436,6 +492,37 @@ struct Walker {
 
             int x0 = wrap_i16(bot.sx), x1 = wrap_i16(bot.ex);        // columns [x0, x1)
             if (x0 < x1 && (x0 < 0 || x1 > W)) { fail("map object column out of range (index panic)"); return; }
+            if (parts_mode) {
+                if (bi.w <= 0 || bi.h <= 0) { if (x0 < x1) { fail("zero-sized bitmap (reference divides by zero)"); return; } continue; }
+                FeSprite sp;
+                std::memset(&sp, 0, sizeof sp);
+                sp.x0 = x0; sp.x1 = x1;
+                sp.bsy = (float)bot.sy; sp.bsx = (float)bot.sx;
+                sp.bdelta = ((float)bot.sy - (float)bot.ey) / ((float)bot.sx - (float)bot.ex);
+                sp.tsy = (float)top.sy; sp.tsx = (float)top.sx;
+                sp.tdelta = ((float)top.sy - (float)top.ey) / ((float)top.sx - (float)top.ex);
+                sp.wall = make_wall_rec(bi, cl.line.a.x, cl.line.a.y, cl.line.b.x, cl.line.b.y, cl.start_offset, bot.sx, bot.ex,
+                                        bottom_height, top_height, 0, 0, light);
+                Rec r;
+                r.line = cl.line; r.start_offset = cl.start_offset;
+                r.bottom_height = bottom_height; r.top_height = top_height;
+                r.min_x = std::fmin(r.line.a.x, r.line.b.x); r.max_x = std::fmax(r.line.a.x, r.line.b.x);
+                r.start_x = bot.sx; r.end_x = bot.ex; r.bitmap = bitmap;
+                r.first_col = (uint32_t)A.sprites.size(); r.n_cols = 0; r.out_index = -1;   // first_col: index into A.sprites
+                r.light = light; r.offset_x = 0; r.offset_y = 0;
+                r.state = ST_MAPOBJECT; r.ext_bottom = r.ext_top = r.draw_ceiling = 0;
+                r.sort_key = (int16_t)f32_as_i16(cl.line.a.x);
+                // which wall records clip this sprite (the ones NOT behind its centre, map_objects.rs:138-140)
+                const size_t row = A.behind.size();
+                A.behind.resize(row + A.behind_words, 0u);
+                for (size_t ri = 0; ri < n_wall_recs; ri++)
+                    if (behind(recs[ri], vpv)) A.behind[row + (ri >> 5)] |= 1u << (ri & 31);
+                sp.behind_off = (uint32_t)row;
+                A.sprites.push_back(sp);
+                mo.push_back((uint32_t)recs.size());
+                recs.push_back(r);
+                continue;
+            }
             for (int x = x0; x < x1; x++) { A.top_clip[(size_t)x] = -1; A.bottom_clip[(size_t)x] = (int16_t)H; }
             if (x0 < x1) {
                 for (size_t ri = 0; ri < n_wall_recs; ri++) {         // :135-166 (only x in [x0,x1) is ever read back)
@@ -483,6 +570,27 @@ struct Walker {
         std::stable_sort(mo.begin(), mo.end(), [&](uint32_t p, uint32_t q) { return recs[p].sort_key < recs[q].sort_key; });
         std::reverse(mo.begin(), mo.end());
 
+        if (parts_mode) {                                            // same interleave, recorded as sequence numbers
+            uint32_t seq = 0;
+            for (uint32_t mi : mo) {
+                const Rec &m = recs[mi];
+                V2 v{(m.line.a.x + m.line.b.x) / 2.0f, (m.line.a.y + m.line.b.y) / 2.0f};
+                for (size_t ri = n_wall_recs; ri-- > 0;) {
+                    Rec &r = recs[ri];
+                    if (r.state != ST_TWOSIDED || !behind(r, v)) continue;
+                    A.parts[ri].seq = seq++;
+                    r.state = ST_DRAWN;
+                }
+                A.sprites[m.first_col].seq = seq++;
+            }
+            for (size_t ri = n_wall_recs; ri-- > 0;) {
+                Rec &r = recs[ri];
+                if (r.state != ST_TWOSIDED) continue;
+                A.parts[ri].seq = seq++;
+                r.state = ST_DRAWN;
+            }
+            return;
+        }
         // `segs` was reversed before this call (mod.rs:124): iterate wall records back to front
         for (uint32_t mi : mo) {
             const Rec &m = recs[mi];
@@ -539,6 +647,18 @@ int build_frame_lists(const Scene &sc, int W, int H, const dg_view &view, FrameA
     out.plane_tb = A.plane_tb.data(); out.n_plane_tb = (uint32_t)A.plane_tb.size();
     out.order = A.order.data(); out.n_order = (uint32_t)A.order.size();
     return DG_OK;
+}
+
+int build_frame_parts(const Scene &sc, int W, int H, const dg_view &view, FrameArena &A, std::string &err) {
+    if (W <= 0 || H <= 0 || W > 16384 || H > 16384) { err = "bad frame size"; return DG_ERR_INVALID; }
+    A.parts.clear(); A.sprites.clear(); A.behind.clear(); A.behind_words = 0; A.n_sky_slots = 0;
+    A.recs->clear();
+    Walker wk(sc, W, H, view, A, err);
+    wk.parts_mode = true;
+    wk.walk_bsp();
+    if (wk.status) return wk.status;
+    wk.map_objects();
+    return wk.status;
 }
 
 }  // namespace dg

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/doomgpu.h"
+#include "fe_dev.h"
 #include "scene.hpp"
 
 namespace dg {
@@ -30,6 +31,11 @@ struct FrameArena {
     std::vector<dg_visplane> visplanes;
     std::vector<int16_t> plane_tb;
     std::vector<dg_draw_cmd> order;
+    // parts mode (device column walk): per-seg / per-sprite records instead of finished columns
+    std::vector<FePart> parts;
+    std::vector<FeSprite> sprites;
+    std::vector<uint32_t> behind;       // n_sprites rows of behind_words bits: wall record p is behind sprite s
+    uint32_t behind_words = 0, n_sky_slots = 0;
     // scratch
     struct Rec;
     std::vector<Rec> *recs = nullptr;   // opaque (defined in frontend.cpp)
@@ -47,5 +53,13 @@ struct FrameArena {
 int build_frame_lists(const Scene &sc, int W, int H, const dg_view &view, FrameArena &arena, dg_frame_lists &out, std::string &err);
 
 void fill_view_trig(dg_view &v);
+
+// Parts mode: the per-seg and per-sprite half only (BSP order, transform, clip, projection, pegging, sprite sorting and the
+// sprite / masked-wall draw sequence); fills arena.parts / sprites / behind.  The per-column half runs on the GPU (frontend.hip).
+int build_frame_parts(const Scene &sc, int W, int H, const dg_view &view, FrameArena &arena, std::string &err);
+
+// Per-record constants of render_vertical_bitmap_line (bitmap_render.rs:233-251), shared by the binner and the parts builder.
+DevWallRec make_wall_rec(const BitmapInfo &bi, float lsx, float lsy, float lex, float ley, float start_offset, int32_t start_x, int32_t end_x,
+                         float bottom_height, float top_height, int16_t offset_x, int16_t offset_y, int16_t light_level);
 
 }  // namespace dg

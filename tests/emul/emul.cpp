@@ -5,10 +5,12 @@
 // kernel does (per column, spans in order, later span overwrites).  It lets the CPU-only test tier check the
 // host logic and the list format against the oracle in a container without a GPU.  The GPU tier repeats the
 // same comparison through the real HIP kernels and the C-ABI.
+#include <algorithm>
 #include <cstring>
 #include <string>
 
 #include "../../doom-rust-renderer_amd/csrc/binner.hpp"
+#include "../../doom-rust-renderer_amd/csrc/fe_core.h"
 #include "../../doom-rust-renderer_amd/csrc/frontend.hpp"
 #include "../../doom-rust-renderer_amd/csrc/raster_core.h"
 #include "../../doom-rust-renderer_amd/csrc/scene.hpp"
@@ -16,6 +18,38 @@
 using namespace dg;
 
 static std::string g_err;
+
+// What dg_raster_tiles does for every column: spans in order, every row of the span (lane = row), later span overwrites.
+static void raster_spans(const DevScene &ds, const DevConsts &k, const DevFrame &hdr, const uint32_t *pal, const uint32_t *col_off,
+                         const DevRSpan *rs, int W, int H, uint8_t *rgb) {
+    std::memset(rgb, 0, (size_t)3 * W * H);
+    for (int x = 0; x < W; x++) {
+        for (uint32_t i = col_off[x]; i < col_off[x + 1]; i++) {
+            const uint32_t *w = rs[i].w;
+            for (int y = w0_ctop(w[0]); y <= w0_cbot(w[0]); y++) {
+                uint32_t c = 0;
+                bool wr = false;
+                const uint32_t kind = w0_kind(w[0]);
+                if (kind == SPAN_WALL) {
+                    uint32_t o = wall_texel_offset(w[1], w[2], w[4], w[5], w[6], w[7], y);
+                    if (!(w[6] & 0x100u) || ds.texel_opq[o]) { c = shade(pal[ds.texel_idx[o]], bits_f32(w[3])); wr = true; }
+                } else if (kind == SPAN_FLAT) {
+                    float factor;
+                    const float vy = k.CFY - (float)y;
+                    uint32_t o = flat_texel_offset(hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), factor);
+                    c = shade(pal[ds.flats[o]], factor); wr = true;
+                } else {
+                    uint32_t o = sky_texel_offset(w[2], sky_row(ds, k, y));
+                    if (o != 0xffffffffu && ds.texel_opq[o]) { c = pal[ds.texel_idx[o]]; wr = true; }
+                }
+                if (wr) {
+                    uint8_t *p = rgb + 3 * ((size_t)y * W + x);
+                    p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
+                }
+            }
+        }
+    }
+}
 
 extern "C" {
 
@@ -58,40 +92,133 @@ int emul_render(void *scene, int W, int H, const dg_view *view_in, uint8_t *rgb,
     ds.sky_texel_off = sky.texel_off; ds.sky_w = sky.w; ds.sky_h = sky.h; ds.sky_has_holes = sky.has_holes;
     DevConsts k{fk.ARC, fk.GCFX, fk.CFX, fk.CFY, W, H};
 
-    std::memset(rgb, 0, (size_t)3 * W * H);
+    std::vector<DevRSpan> rs(bf.spans.size());
+    for (size_t i = 0; i < bf.spans.size(); i++) {                       // what dg_setup_spans does (one lane per span)
+        const DevSpan &sp = bf.spans[i];
+        rs[i] = sp.kind == SPAN_WALL ? resolve_wall_span(sp, bf.walls[sp.rec])
+              : sp.kind == SPAN_FLAT ? resolve_flat_span(sp, bf.planes[sp.rec], k)
+                                     : resolve_sky_span(sp, ds, k, bf.hdr);
+    }
+    raster_spans(ds, k, bf.hdr, pal.data(), bf.col_off.data(), rs.data(), W, H, rgb);
+    if (stats) { stats[0] = bf.spans.size(); stats[1] = bf.walls.size(); stats[2] = bf.planes.size(); stats[3] = bf.covered_pixels; }
+    return 0;
+}
+// The device column walk (fe_core.h bodies, the loops of fe_kernels.hip restated serially) on the CPU, compared span for
+// span with the host list path.  stats[0..3] = spans, parts, sprites, overflow flags; stats[4] = 1 when the column-major
+// DevRSpan list is byte-identical to the host path's; stats[5] = zero-filled sky visplane entries found by fe_gap.
+int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *rgb, uint64_t *stats) {
+    const Scene &sc = *(const Scene *)scene;
+    dg_view view = *view_in;
+    fill_view_trig(view);
+    static thread_local FrameArena arena, arena2;
+    static thread_local BinnedFrame bf;
+    FrameConsts fk = make_consts(W, H);
+    // host path (the comparison target)
+    dg_frame_lists fl;
+    int rc = build_frame_lists(sc, W, H, view, arena2, fl, g_err);
+    if (rc) return rc;
+    rc = bin_frame(sc, fk, fl, bf, g_err);
+    if (rc) return rc;
+    rc = build_frame_parts(sc, W, H, view, arena, g_err);
+    if (rc) return rc;
+    if (arena.n_sky_slots > FE_MAX_SKY_SLOTS) { g_err = "too many sky slots"; return DG_ERR_CAPACITY; }
+
+    std::vector<uint32_t> pal(256);
+    for (int i = 0; i < 256; i++) pal[i] = sc.palette[3 * i] | (sc.palette[3 * i + 1] << 8) | (sc.palette[3 * i + 2] << 16);
+    DevScene ds;
+    ds.palette = pal.data(); ds.texel_idx = sc.texel_idx.data(); ds.texel_opq = sc.texel_opq.data(); ds.flats = sc.flat_pool.data();
+    const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
+    ds.sky_texel_off = sky.texel_off; ds.sky_w = sky.w; ds.sky_h = sky.h; ds.sky_has_holes = sky.has_holes;
+    DevConsts k{fk.ARC, fk.GCFX, fk.CFX, fk.CFY, W, H};
+
+    DevFrame fr = bf.hdr;            // view constants (same helper as the product: bin_frame fills them)
+    fr.span_base = 0;
+    FeFrame ff{0, (uint32_t)arena.parts.size(), 0, (uint32_t)arena.sprites.size(), 0, arena.behind_words, arena.n_sky_slots, 0};
+    const uint32_t w64 = (uint32_t)((W + 63) / 64);
+    std::vector<uint32_t> keys((size_t)FE_MAX_SPANS_PER_COL * W), cnt((size_t)W), col_off((size_t)W + 1), flags(1, 0);
+    std::vector<FeU4> sspans((size_t)2 * FE_MAX_SPANS_PER_COL * W);
+    std::vector<FeColRec> recs((size_t)FE_MAX_RECS_PER_COL * W);
+    std::vector<uint64_t> events((size_t)FE_MAX_SKY_SLOTS * 3 * w64, 0);
+    std::vector<DevRSpan> rspans((size_t)W * FE_MAX_SPANS_PER_COL);
+    FeParams P;
+    P.scene = ds; P.k = k; P.frames = &fr; P.fframes = &ff; P.parts = arena.parts.data(); P.sprites = arena.sprites.data();
+    P.behind = arena.behind.data(); P.keys = keys.data(); P.sspans = sspans.data(); P.recs = recs.data(); P.cnt = cnt.data();
+    P.events = events.data(); P.flags = flags.data(); P.col_off = col_off.data(); P.rspans = rspans.data();
+    P.n_frames = 1; P.span_stride = (uint32_t)rspans.size(); P.w64 = w64;
+
+    // dg_fe_columns, one "lane" at a time
     for (int x = 0; x < W; x++) {
-        for (uint32_t i = bf.col_off[x]; i < bf.col_off[x + 1]; i++) {
-            const DevSpan &s = bf.spans[i];
-            // what dg_setup_spans does (one lane per span) ...
-            DevRSpan r = s.kind == SPAN_WALL ? resolve_wall_span(s, bf.walls[s.rec])
-                       : s.kind == SPAN_FLAT ? resolve_flat_span(s, bf.planes[s.rec], k)
-                                             : resolve_sky_span(s, ds, k, bf.hdr);
-            const uint32_t *w = r.w;
-            // ... and what dg_raster_tiles does for every row of the span (lane = row)
-            for (int y = w0_ctop(w[0]); y <= w0_cbot(w[0]); y++) {
-                uint32_t c = 0;
-                bool wr = false;
-                const uint32_t kind = w0_kind(w[0]);
-                if (kind == SPAN_WALL) {
-                    uint32_t o = wall_texel_offset(w[1], w[2], w[4], w[5], w[6], w[7], y);
-                    if (!(w[6] & 0x100u) || ds.texel_opq[o]) { c = shade(pal[ds.texel_idx[o]], bits_f32(w[3])); wr = true; }
-                } else if (kind == SPAN_FLAT) {
-                    float factor;
-                    const float vy = k.CFY - (float)y;
-                    uint32_t o = flat_texel_offset(bf.hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), factor);
-                    c = shade(pal[ds.flats[o]], factor); wr = true;
-                } else {
-                    uint32_t o = sky_texel_offset(w[2], sky_row(ds, k, y));
-                    if (o != 0xffffffffu && ds.texel_opq[o]) { c = pal[ds.texel_idx[o]]; wr = true; }
-                }
-                if (wr) {
-                    uint8_t *p = rgb + 3 * ((size_t)y * W + x);
-                    p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
-                }
+        FeColumn c;
+        c.x = x; c.hor = 0; c.fo = H; c.co = -1; c.nsp = 0; c.nrec = 0; c.ovf = 0;
+        for (uint32_t pi = 0; pi < ff.n_parts; pi++) {
+            const FePart &p = P.parts[pi];
+            if (x < p.sx || x > p.ex) continue;
+            uint32_t ev = fe_part_column(P, 0, fr, p, pi, c);
+            if (p.sky_slot >= 0) {
+                uint64_t *e = events.data() + (size_t)p.sky_slot * 3 * w64 + (size_t)(x >> 6);
+                if (ev & FE_EV_FADD) e[0] |= 1ull << (x & 63);
+                if (ev & FE_EV_CADD) e[w64] |= 1ull << (x & 63);
+                if (ev & FE_EV_FLUSH) e[2 * (size_t)w64] |= 1ull << (x & 63);
+            }
+        }
+        for (uint32_t si = 0; si < ff.n_sprites; si++) {
+            const FeSprite &s = P.sprites[si];
+            if (x >= s.x0 && x < s.x1) fe_sprite_column(P, 0, ff, s, c);
+        }
+        cnt[(size_t)x] = c.nsp;
+        flags[0] |= c.ovf;
+    }
+    // dg_fe_finalize
+    uint64_t n_gaps = 0;
+    for (uint32_t pi = 0; pi < ff.n_parts; pi++) {
+        const FePart &p = P.parts[pi];
+        if (p.sky_slot < 0) continue;
+        for (int kind = 0; kind < 2; kind++) {
+            if (!(p.flags & (kind ? FEP_CEIL_SKY : FEP_FLOOR_SKY))) continue;
+            const uint64_t *add = fe_event_words(P, 0, p.sky_slot, kind), *flush = fe_event_words(P, 0, p.sky_slot, 2);
+            for (int x = p.sx; x <= p.ex; x++) {
+                if (!fe_gap(add, flush, x, p.sx, p.ex)) continue;
+                n_gaps++;
+                const uint32_t slot = cnt[(size_t)x]++;
+                if (slot >= FE_MAX_SPANS_PER_COL) { flags[0] |= FE_OVF_SPANS; continue; }
+                const DevRSpan r = resolve_sky_span(fe_span(0, 0, 0, 0, SPAN_SKY, x), ds, k, fr);
+                const size_t i = (size_t)slot * W + (size_t)x;
+                keys[i] = FE_KEY_PLANE | (pi << 2) | (uint32_t)kind;
+                sspans[2 * i] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
+                sspans[2 * i + 1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};
             }
         }
     }
-    if (stats) { stats[0] = bf.spans.size(); stats[1] = bf.walls.size(); stats[2] = bf.planes.size(); stats[3] = bf.covered_pixels; }
+    uint32_t off = 0;
+    for (int x = 0; x < W; x++) {
+        const uint32_t n = std::min<uint32_t>(cnt[(size_t)x], FE_MAX_SPANS_PER_COL);
+        col_off[(size_t)x] = off;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t key = keys[(size_t)i * W + x];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t kj = keys[(size_t)j * W + x];
+                rank += (kj < key || (kj == key && j < i)) ? 1u : 0u;
+            }
+            std::memcpy(&rspans[off + rank].w[0], &sspans[2 * ((size_t)i * W + x)], 16);
+            std::memcpy(&rspans[off + rank].w[4], &sspans[2 * ((size_t)i * W + x) + 1], 16);
+        }
+        off += n;
+    }
+    col_off[(size_t)W] = off;
+
+    // span-for-span comparison with the host path
+    bool same = off == bf.spans.size() && !flags[0];
+    for (int x = 0; same && x <= W; x++) same = col_off[(size_t)x] == bf.col_off[(size_t)x];
+    for (size_t i = 0; same && i < bf.spans.size(); i++) {
+        const DevSpan &sp = bf.spans[i];
+        DevRSpan r = sp.kind == SPAN_WALL ? resolve_wall_span(sp, bf.walls[sp.rec])
+                   : sp.kind == SPAN_FLAT ? resolve_flat_span(sp, bf.planes[sp.rec], k)
+                                          : resolve_sky_span(sp, ds, k, bf.hdr);
+        same = std::memcmp(&r, &rspans[i], sizeof r) == 0;
+    }
+    raster_spans(ds, k, fr, pal.data(), col_off.data(), rspans.data(), W, H, rgb);
+    if (stats) { stats[0] = off; stats[1] = ff.n_parts; stats[2] = ff.n_sprites; stats[3] = flags[0]; stats[4] = same ? 1 : 0; stats[5] = n_gaps; }
     return 0;
 }
 }

@@ -25,6 +25,7 @@ def lib():
         L.emul_free.argtypes = [ctypes.c_void_p]
         L.emul_last_error.restype = ctypes.c_char_p
         L.emul_render.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(DgView), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.emul_render_fe.argtypes = L.emul_render.argtypes
         L.emul_set_sector_light.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int16]
         L.emul_set_mobj_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint8, ctypes.c_int]
         _lib = L
@@ -50,6 +51,18 @@ class EmulScene:
         buf = np.empty(3 * W * H, dtype=np.uint8)
         st = (ctypes.c_uint64 * 4)()
         rc = lib().emul_render(self._h, W, H, ctypes.byref(v), buf.ctypes.data_as(ctypes.c_void_p), st)
+        if rc:
+            raise RuntimeError(f"emul rc {rc}: {lib().emul_last_error().decode()}")
+        return buf.tobytes(), list(st)
+
+    def render_fe(self, W, H, rec, timestamp=0.0):
+        """Same frame through the device column walk's bodies (fe_core.h) on the CPU.  stats = [spans, parts, sprites, overflow
+        flags, span-list-identical-to-host-path, sky gap entries]."""
+        v = DgView(float(rec[0]), float(rec[1]), float(rec[2]), float(rec[7]), float(rec[3]), float(rec[4]), float(rec[5]), float(rec[6]),
+                   float(timestamp), 1)
+        buf = np.empty(3 * W * H, dtype=np.uint8)
+        st = (ctypes.c_uint64 * 6)()
+        rc = lib().emul_render_fe(self._h, W, H, ctypes.byref(v), buf.ctypes.data_as(ctypes.c_void_p), st)
         if rc:
             raise RuntimeError(f"emul rc {rc}: {lib().emul_last_error().decode()}")
         return buf.tobytes(), list(st)

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import emul_bind
+from conftest import load_path
 
 
 def test_library_exports_every_declared_symbol(dg):
@@ -159,3 +160,40 @@ def test_game_state_snapshots_match_oracle(oracle, wad1993, path1993):
         assert es.render(320, 200, path1993[i])[0] == ref, f"frame {i}"
         changed += ref != plain.render(320, 200, path1993[i])
     assert changed > 20
+
+
+@pytest.mark.parametrize("seed,heavy,W,H,stride", [(1993, False, 320, 200, 3), (1994, True, 320, 200, 3), (1993, False, 1280, 800, 83),
+                                                   (1994, True, 644, 400, 61)])
+def test_device_column_walk_bodies_match_host_lists(synth, seed, heavy, W, H, stride):
+    """fe_core.h (the bodies of dg_fe_columns / dg_fe_finalize) on the CPU: the column-major DevRSpan list built from the
+    per-seg / per-sprite records must be byte-identical to the host list path's, frame by frame."""
+    es = emul_bind.EmulScene(synth.build_synth_iwad(seed=seed, heavy=heavy), "e1m1")
+    path = load_path(seed)
+    frames = sorted(set(range(0, len(path), stride)) | ({277} if heavy else set()))
+    gaps = 0
+    for i in frames:
+        ref, _ = es.render(W, H, path[i])
+        got, st = es.render_fe(W, H, path[i])
+        assert st[3] == 0 and st[4] == 1, f"frame {i}: span list differs from the host path {st}"
+        assert got == ref, f"frame {i}"
+        gaps += st[5]
+    if heavy and W == 320:
+        assert gaps > 0          # frame 277 has zero-filled sky visplane columns (fe_gap)
+
+
+def test_device_column_walk_edge_views(synth, campath_mod):
+    es = emul_bind.EmulScene(synth.build_synth_iwad(seed=1993, quirks=True), "e1m1")
+    rng = np.random.default_rng(5)
+    sizes = [(320, 200), (64, 40), (8, 200), (4, 4), (1000, 30), (2560, 1600)]
+    for j in range(120):
+        x, y = float(rng.uniform(-100, 4200)), float(rng.uniform(-100, 3200))
+        rec = campath_mod.view_record(x, y, float(rng.uniform(-7, 7)), float(rng.choice([-64, -8, 0, 24, 200])))
+        W, H = sizes[j % 6] if j % 6 != 5 or j % 30 == 5 else (320, 200)
+        try:
+            ref, _ = es.render(W, H, rec, 0.4)
+        except RuntimeError:
+            with pytest.raises(RuntimeError):
+                es.render_fe(W, H, rec, 0.4)
+            continue
+        got, st = es.render_fe(W, H, rec, 0.4)
+        assert st[3] == 0 and st[4] == 1 and got == ref, (j, W, H, st)
