@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("DOOMGPU_LIB") or os.path.join(_HERE, "libdoomgpu.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "doomgpu.h")
 
 DG_OK, DG_ERR_INVALID, DG_ERR_NO_DEVICE, DG_ERR_HIP, DG_ERR_WAD, DG_ERR_RENDER, DG_ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
+DG_FE_AUTO, DG_FE_HOST, DG_FE_DEVICE = 0, 1, 2
 
 
 class DoomGpuError(RuntimeError):
@@ -35,14 +36,15 @@ class DgView(ctypes.Structure):
 
 
 class DgConfig(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in "device width height max_batch slots host_threads".split()]
+    _fields_ = [(n, ctypes.c_int32) for n in "device width height max_batch slots host_threads front_end".split()]
 
 
 class DgTiming(ctypes.Structure):
     _fields_ = [("setup_ms", ctypes.c_float), ("raster_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
                 ("host_ms", ctypes.c_float),
                 ("n_spans", ctypes.c_uint64), ("n_frames", ctypes.c_uint64), ("covered_pixels", ctypes.c_uint64),
-                ("n_walls", ctypes.c_uint64), ("n_planes", ctypes.c_uint64), ("list_bytes", ctypes.c_uint64)]
+                ("n_walls", ctypes.c_uint64), ("n_planes", ctypes.c_uint64), ("list_bytes", ctypes.c_uint64),
+                ("front_end", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class DgBitmapColumn(ctypes.Structure):
@@ -199,8 +201,9 @@ class Context:
     """dg_ctx on one GPU.  Mirrors the reference call shape: for every view, `Pixels::new()` +
     `Renderer::new(..).render()` -> `pixels.pixels` (src/game.rs:505-525), batched."""
 
-    def __init__(self, width: int, height: int, max_batch: int = 64, slots: int = 2, device: int = 0, host_threads: int = 0):
-        cfg = DgConfig(device, width, height, max_batch, slots, host_threads)
+    def __init__(self, width: int, height: int, max_batch: int = 64, slots: int = 2, device: int = 0, host_threads: int = 0,
+                 front_end: int = 0):
+        cfg = DgConfig(device, width, height, max_batch, slots, host_threads, front_end)
         h = _P()
         _check(lib().dg_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h

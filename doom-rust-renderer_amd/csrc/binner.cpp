@@ -17,21 +17,26 @@ const float kPi = 3.14159265358979323846f;
 const uint32_t kMaxSpansPerColumn = 512;   // = SPAN_CAP of dg_raster_tiles (kernels.hip)
 }
 
+DevFrame make_frame_header(const dg_view &v) {
+    DevFrame h;
+    std::memset(&h, 0, sizeof h);
+    h.cos_a = v.cos_a;
+    h.sin_a = v.sin_a;
+    h.pos_x_i16 = f32_as_i16(v.x);
+    h.pos_y_i16 = f32_as_i16(v.y);
+    // draw_sky's tx_offset, visplanes.rs:51-58
+    int32_t t = wrap_i16(f32_as_i16(-256.0f * v.angle / (kPi / 2.0f)) + 256);
+    if (t < 0) t = wrap_i16(t + wrap_i16(256 * wrap_i16(1 - t / 256)));
+    h.sky_tx_offset = t;
+    return h;
+}
+
 int bin_frame(const Scene &sc, const FrameConsts &k, const dg_frame_lists &fl, BinnedFrame &out, std::string &err) {
     const int W = k.W, H = k.H;
     out.events.clear(); out.walls.clear(); out.planes.clear(); out.covered_pixels = 0;
     const dg_view &v = fl.view;
 
-    std::memset(&out.hdr, 0, sizeof out.hdr);
-    out.hdr.cos_a = v.cos_a;
-    out.hdr.sin_a = v.sin_a;
-    out.hdr.pos_x_i16 = f32_as_i16(v.x);
-    out.hdr.pos_y_i16 = f32_as_i16(v.y);
-    {   // draw_sky's tx_offset, visplanes.rs:51-58
-        int32_t t = wrap_i16(f32_as_i16(-256.0f * v.angle / (kPi / 2.0f)) + 256);
-        if (t < 0) t = wrap_i16(t + wrap_i16(256 * wrap_i16(1 - t / 256)));
-        out.hdr.sky_tx_offset = t;
-    }
+    out.hdr = make_frame_header(v);
     const float wz_base = v.floor_height;
 
     for (uint32_t oi = 0; oi < fl.n_order; oi++) {

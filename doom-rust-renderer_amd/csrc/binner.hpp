@@ -22,6 +22,9 @@ struct BinnedFrame {
     std::vector<uint32_t> cursor;
 };
 
+// Per-frame view constants of the texture mappers (rotation, position as i16, draw_sky's tx_offset); bases left 0.
+DevFrame make_frame_header(const dg_view &v);
+
 // Returns DG_OK / DG_ERR_INVALID (malformed caller lists) / DG_ERR_RENDER (reference would panic).
 int bin_frame(const Scene &sc, const FrameConsts &k, const dg_frame_lists &fl, BinnedFrame &out, std::string &err);
 

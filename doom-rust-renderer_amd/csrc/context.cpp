@@ -6,12 +6,17 @@
 //   per slot: list slab  [DevFrame x F | col_off x F*(W+1) | DevWallRec.. | DevPlaneRec.. | DevSpan..]  one H2D copy
 //             rspan slab DevRSpan 32 B per span (device-only, written by dg_setup_spans, walked by dg_raster_tiles)
 //             framebuffer slab  F x 3*W*H bytes RGB24 (the reference's Pixels.pixels, one per frame)
+//             DG_FE_DEVICE: record slab [DevFrame x F | FeFrame x F | FePart.. | FeSprite.. | behind bits..] (one H2D copy),
+//             col_off F*(W+1) written by dg_fe_finalize, 2F status words (overflow flags, span totals)
+//   per ctx : DG_FE_DEVICE column scratch [F][slot][W]: keys 4 B, spans 32 B (48 slots), wall-record columns 16 B (48 slots),
+//             counts, sky event bits — shared by the slots because their kernels run back to back
 #include <hip/hip_runtime_api.h>
 #include <sched.h>
 
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <chrono>
 #include <functional>
@@ -23,6 +28,7 @@
 
 #include "../../include/doomgpu.h"
 #include "binner.hpp"
+#include "fe_kernels.hpp"
 #include "frontend.hpp"
 #include "kernels.hpp"
 #include "scene.hpp"
@@ -112,6 +118,22 @@ struct Slot {
     int n_frames = 0;
     float host_ms = 0.0f;         // list generation + binning + packing of the last submission
     bool busy = false, timed = false;
+    // device column walk (DG_FE_DEVICE)
+    uint8_t *h_fe = nullptr, *d_fe = nullptr;   // record slab: pinned staging / HBM
+    uint32_t *d_fe_coloff = nullptr;
+    uint32_t *d_status = nullptr, *h_status = nullptr;   // [F] overflow flags, [F] spans per frame
+    FeParams FP{};
+    bool fe_mode = false;         // the last submission went through the device column walk
+    bool fe_check = false;        // ... and its overflow flags have not been looked at yet
+    std::vector<dg_view> views;   // the views of that submission (to redo it on the host if a capacity overflowed)
+};
+
+struct FeFrameOut {               // parts-mode output of one frame, owned per batch index
+    std::vector<FePart> parts;
+    std::vector<FeSprite> sprites;
+    std::vector<uint32_t> behind;
+    uint32_t behind_words = 0, n_sky_slots = 0;
+    DevFrame hdr{};
 };
 
 }  // namespace
@@ -133,6 +155,16 @@ struct dg_ctx {
     std::vector<BinnedFrame> binned;                   // one per frame of a batch
     size_t span_cap_per_batch = 0, wall_cap_per_batch = 0, plane_cap_per_batch = 0;
     int n_threads = 1;
+    // device column walk
+    bool fe_enabled = false;            // cfg.front_end asks for it
+    bool fe_scene_ok = false;           // ... and the uploaded scene allows it (sky bitmap >= 256x128, see bin_frame)
+    std::vector<FeFrameOut> fe_out;     // one per frame of a batch
+    uint32_t fe_col_slots = FE_DEFAULT_COL_SLOTS;
+    size_t fe_part_cap = 0, fe_sprite_cap = 0, fe_behind_cap = 0, fe_slab_cap = 0;
+    uint32_t *d_fe_keys = nullptr, *d_fe_cnt = nullptr;
+    FeU4 *d_fe_sspans = nullptr;
+    FeColRec *d_fe_recs = nullptr;
+    uint64_t *d_fe_events = nullptr;
 };
 
 namespace {
@@ -148,6 +180,11 @@ void free_ctx(dg_ctx *c) {
         if (s.d_lists) (void)hipFree(s.d_lists);
         if (s.d_rspans) (void)hipFree(s.d_rspans);
         if (s.d_fb) (void)hipFree(s.d_fb);
+        if (s.h_fe) (void)hipHostFree(s.h_fe);
+        if (s.d_fe) (void)hipFree(s.d_fe);
+        if (s.d_fe_coloff) (void)hipFree(s.d_fe_coloff);
+        if (s.d_status) (void)hipFree(s.d_status);
+        if (s.h_status) (void)hipHostFree(s.h_status);
         if (s.ev_start) (void)hipEventDestroy(s.ev_start);
         if (s.ev_setup) (void)hipEventDestroy(s.ev_setup);
         if (s.ev_raster) (void)hipEventDestroy(s.ev_raster);
@@ -158,11 +195,16 @@ void free_ctx(dg_ctx *c) {
     if (c->d_texel_idx) (void)hipFree(c->d_texel_idx);
     if (c->d_texel_opq) (void)hipFree(c->d_texel_opq);
     if (c->d_flats) (void)hipFree(c->d_flats);
+    if (c->d_fe_keys) (void)hipFree(c->d_fe_keys);
+    if (c->d_fe_cnt) (void)hipFree(c->d_fe_cnt);
+    if (c->d_fe_sspans) (void)hipFree(c->d_fe_sspans);
+    if (c->d_fe_recs) (void)hipFree(c->d_fe_recs);
+    if (c->d_fe_events) (void)hipFree(c->d_fe_events);
     delete c;
 }
 
 // Build + bin the lists of n views in parallel, pack them into the slot's pinned slab, fill slot.P.
-int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *given, int n) {
+int build_batch_host(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *given, int n) {
     const auto t0 = std::chrono::steady_clock::now();
     if (!c->scene) return set_err(DG_ERR_INVALID, "no scene uploaded (dg_upload_scene)");
     if (n <= 0 || n > c->cfg.max_batch) return set_err(DG_ERR_CAPACITY, "batch size outside [1, max_batch]");
@@ -227,9 +269,102 @@ int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *
     P.n_frames = n;
     s.max_spans = max_spans; s.n_spans = spans; s.covered = covered; s.n_frames = n; s.n_walls = walls; s.n_planes = planes;
     s.list_bytes = total;
+    s.fe_mode = false; s.fe_check = false;
     s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIP_TRY(hipMemcpyAsync(s.d_lists, s.h_lists, total, hipMemcpyHostToDevice, s.stream));
     return DG_OK;
+}
+
+// DG_FE_DEVICE: build the per-seg / per-sprite records of n views in parallel, pack them into the slot's record slab,
+// fill slot.FP / slot.P.  Returns kPartsUnsupported when the batch has to go through build_batch_host instead.
+int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!c->scene) return set_err(DG_ERR_INVALID, "no scene uploaded (dg_upload_scene)");
+    if (n <= 0 || n > c->cfg.max_batch) return set_err(DG_ERR_CAPACITY, "batch size outside [1, max_batch]");
+    const Scene &sc = *c->scene;
+    if (sc.texel_idx.size() != c->uploaded_texels) return set_err(DG_ERR_INVALID, "the scene decoded new bitmaps since dg_upload_scene: upload it again");
+    const int W = c->cfg.width, H = c->cfg.height;
+    std::vector<int> rc((size_t)n, 0);
+    std::vector<std::string> errs((size_t)n);
+    c->pool->parallel_for(n, [&](int i, int wid) {
+        FrameArena &A = *c->arenas[(size_t)wid];
+        FeFrameOut &o = c->fe_out[(size_t)i];
+        dg_view v = views[i];
+        fill_view_trig(v);
+        rc[(size_t)i] = build_frame_parts(sc, W, H, v, A, errs[(size_t)i]);
+        if (rc[(size_t)i]) return;
+        o.parts.swap(A.parts); o.sprites.swap(A.sprites); o.behind.swap(A.behind);
+        o.behind_words = A.behind_words; o.n_sky_slots = A.n_sky_slots;
+        o.hdr = make_frame_header(v);
+    });
+    for (int i = 0; i < n; i++) {
+        if (rc[(size_t)i] == kPartsUnsupported) return kPartsUnsupported;
+        if (rc[(size_t)i]) return set_err(rc[(size_t)i], "frame " + std::to_string(i) + ": " + errs[(size_t)i]);
+    }
+    uint64_t parts = 0, sprites = 0, behind = 0;
+    std::vector<FeFrame> ffs((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const FeFrameOut &o = c->fe_out[(size_t)i];
+        if (o.n_sky_slots > FE_MAX_SKY_SLOTS) return kPartsUnsupported;
+        ffs[(size_t)i] = FeFrame{(uint32_t)parts, (uint32_t)o.parts.size(), (uint32_t)sprites, (uint32_t)o.sprites.size(), (uint32_t)behind,
+                                 o.behind_words, o.n_sky_slots, 0u};
+        parts += o.parts.size(); sprites += o.sprites.size(); behind += o.behind.size();
+    }
+    if (parts > c->fe_part_cap || sprites > c->fe_sprite_cap || behind > c->fe_behind_cap) return kPartsUnsupported;
+    const uint32_t span_stride = (uint32_t)(c->span_cap_per_batch / (size_t)c->cfg.max_batch);
+    const size_t off_frames = 0;
+    const size_t off_ff = align_up(off_frames + (size_t)n * sizeof(DevFrame), 256);
+    const size_t off_parts = align_up(off_ff + (size_t)n * sizeof(FeFrame), 256);
+    const size_t off_sprites = align_up(off_parts + parts * sizeof(FePart), 256);
+    const size_t off_behind = align_up(off_sprites + sprites * sizeof(FeSprite), 256);
+    const size_t total = off_behind + behind * 4;
+    if (total > c->fe_slab_cap) return kPartsUnsupported;
+    c->pool->parallel_for(n, [&](int i, int) {
+        FeFrameOut &o = c->fe_out[(size_t)i];
+        const FeFrame &ff = ffs[(size_t)i];
+        o.hdr.span_base = (uint32_t)i * span_stride;
+        std::memcpy(s.h_fe + off_frames + (size_t)i * sizeof(DevFrame), &o.hdr, sizeof(DevFrame));
+        std::memcpy(s.h_fe + off_ff + (size_t)i * sizeof(FeFrame), &ff, sizeof(FeFrame));
+        if (!o.parts.empty()) std::memcpy(s.h_fe + off_parts + (size_t)ff.part_base * sizeof(FePart), o.parts.data(), o.parts.size() * sizeof(FePart));
+        if (!o.sprites.empty()) std::memcpy(s.h_fe + off_sprites + (size_t)ff.sprite_base * sizeof(FeSprite), o.sprites.data(), o.sprites.size() * sizeof(FeSprite));
+        if (!o.behind.empty()) std::memcpy(s.h_fe + off_behind + (size_t)ff.behind_base * 4, o.behind.data(), o.behind.size() * 4);
+    });
+    FeParams &F = s.FP;
+    F.scene = c->dscene;
+    F.k = c->dk;
+    F.frames = reinterpret_cast<const DevFrame *>(s.d_fe + off_frames);
+    F.fframes = reinterpret_cast<const FeFrame *>(s.d_fe + off_ff);
+    F.parts = reinterpret_cast<const FePart *>(s.d_fe + off_parts);
+    F.sprites = reinterpret_cast<const FeSprite *>(s.d_fe + off_sprites);
+    F.behind = reinterpret_cast<const uint32_t *>(s.d_fe + off_behind);
+    F.keys = c->d_fe_keys; F.sspans = c->d_fe_sspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt; F.events = c->d_fe_events;
+    F.flags = s.d_status; F.totals = s.d_status + c->cfg.max_batch;
+    F.col_off = s.d_fe_coloff; F.rspans = s.d_rspans;
+    F.n_frames = n; F.span_stride = span_stride; F.w64 = (uint32_t)((W + 63) / 64); F.col_slots = c->fe_col_slots;
+    RasterParams &P = s.P;
+    P.scene = c->dscene;
+    P.k = c->dk;
+    P.frames = F.frames;
+    P.col_off = s.d_fe_coloff;
+    P.walls = nullptr; P.planes = nullptr; P.spans = nullptr;
+    P.rspans = s.d_rspans;
+    P.fb = s.d_fb;
+    P.n_frames = n;
+    s.max_spans = 0; s.n_spans = 0; s.covered = 0; s.n_frames = n; s.n_walls = parts; s.n_planes = sprites;
+    s.list_bytes = total;
+    s.fe_mode = true; s.fe_check = false;
+    s.views.assign(views, views + n);
+    s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    HIP_TRY(hipMemcpyAsync(s.d_fe, s.h_fe, total, hipMemcpyHostToDevice, s.stream));
+    return DG_OK;
+}
+
+int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *given, int n) {
+    if (!given && c->fe_enabled && c->fe_scene_ok) {
+        const int rc = build_batch_fe(c, s, views, n);
+        if (rc != kPartsUnsupported) return rc;
+    }
+    return build_batch_host(c, s, views, given, n);
 }
 
 int enqueue_kernels(dg_ctx *c, Slot &s) {
@@ -237,12 +372,43 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
     // themselves are chained behind the previous submission's raster kernel (they fill the chip on their own).
     if (c->last_raster && c->last_raster != s.ev_raster) HIP_TRY(hipStreamWaitEvent(s.stream, c->last_raster, 0));
     HIP_TRY(hipEventRecord(s.ev_start, s.stream));
-    HIP_TRY(launch_setup(s.P, s.max_spans, s.stream));
+    if (s.fe_mode) {
+        HIP_TRY(hipMemsetAsync(s.d_status, 0, (size_t)2 * (size_t)c->cfg.max_batch * 4, s.stream));
+        HIP_TRY(launch_fe(s.FP, s.stream));
+    } else {
+        HIP_TRY(launch_setup(s.P, s.max_spans, s.stream));
+    }
     HIP_TRY(hipEventRecord(s.ev_setup, s.stream));
     HIP_TRY(launch_raster(s.P, s.stream));
     HIP_TRY(hipEventRecord(s.ev_raster, s.stream));
     c->last_raster = s.ev_raster;
+    if (s.fe_mode) {
+        HIP_TRY(hipMemcpyAsync(s.h_status, s.d_status, (size_t)2 * (size_t)c->cfg.max_batch * 4, hipMemcpyDeviceToHost, s.stream));
+        s.fe_check = true;
+    }
     s.busy = true; s.timed = true;
+    return DG_OK;
+}
+
+// After the slot's stream has been synchronised: look at the overflow flags of a device-column-walk submission; a batch
+// that overflowed a per-column / per-frame capacity is redone through the host list path (which has the larger limits).
+int settle_slot(dg_ctx *c, Slot &s) {
+    if (!s.fe_check) return DG_OK;
+    s.fe_check = false;
+    bool overflow = false;
+    uint64_t spans = 0;
+    for (int i = 0; i < s.n_frames; i++) {
+        overflow |= s.h_status[i] != 0;
+        spans += s.h_status[c->cfg.max_batch + i];
+    }
+    s.n_spans = spans;
+    if (!overflow) return DG_OK;
+    const std::vector<dg_view> views = s.views;
+    int rc = build_batch_host(c, s, views.data(), nullptr, (int)views.size());
+    if (rc) return rc;
+    rc = enqueue_kernels(c, s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s.stream));
     return DG_OK;
 }
 
@@ -327,6 +493,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         return set_err(DG_ERR_INVALID, "width/height must be positive, width % 4 == 0, both <= 16384");
     if (cfg->max_batch <= 0 || cfg->max_batch > 65535 || cfg->slots <= 0 || cfg->slots > 16)
         return set_err(DG_ERR_INVALID, "max_batch must be in [1, 65535], slots in [1, 16]");
+    if (cfg->front_end < DG_FE_AUTO || cfg->front_end > DG_FE_DEVICE) return set_err(DG_ERR_INVALID, "front_end must be DG_FE_AUTO, DG_FE_HOST or DG_FE_DEVICE");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(DG_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
     if (cfg->device < 0 || cfg->device >= ndev) return set_err(DG_ERR_NO_DEVICE, "device ordinal out of range");
@@ -361,10 +528,33 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     const size_t lists_cap = align_up(F * sizeof(DevFrame), 256) + align_up(F * (W + 1) * 4, 256) +
                              align_up(c->wall_cap_per_batch * sizeof(DevWallRec), 256) +
                              align_up(c->plane_cap_per_batch * sizeof(DevPlaneRec), 256) + c->span_cap_per_batch * sizeof(DevSpan) + 1024;
+    c->fe_enabled = cfg->front_end != DG_FE_HOST;
+    if (c->fe_enabled) {
+        // Scratch slots per screen column (spans and wall-record columns).  A column that needs more sends its batch through
+        // the host list path; DOOMGPU_FE_COLUMN_SLOTS trades scratch HBM (52 B x slots x width x max_batch) against that.
+        if (const char *e = std::getenv("DOOMGPU_FE_COLUMN_SLOTS")) {
+            const long v = std::strtol(e, nullptr, 10);
+            if (v >= 1 && v <= (long)FE_MAX_COL_SLOTS) c->fe_col_slots = (uint32_t)v;
+        }
+        c->fe_out.resize(F);
+        c->fe_part_cap = F * 2048;         // wall records per frame on average (e1m1-like maps: 20-600)
+        c->fe_sprite_cap = F * 256;
+        c->fe_behind_cap = F * 256 * 32;   // one bit per (sprite, wall record)
+        c->fe_slab_cap = align_up(F * sizeof(DevFrame), 256) + align_up(F * sizeof(FeFrame), 256) + align_up(c->fe_part_cap * sizeof(FePart), 256) +
+                         align_up(c->fe_sprite_cap * sizeof(FeSprite), 256) + c->fe_behind_cap * 4 + 1024;
+    }
     c->slots.resize((size_t)cfg->slots);
-    for (Slot &s : c->slots) {
-        hipError_t e;
+    hipError_t e;
 #define CTX_TRY(expr) if ((e = (expr)) != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(e); free_ctx(c); return set_err(DG_ERR_HIP, m); }
+    if (c->fe_enabled) {
+        const size_t w64 = (W + 63) / 64;
+        CTX_TRY(hipMalloc((void **)&c->d_fe_keys, F * c->fe_col_slots * W * 4));
+        CTX_TRY(hipMalloc((void **)&c->d_fe_sspans, F * c->fe_col_slots * W * 2 * sizeof(FeU4)));
+        CTX_TRY(hipMalloc((void **)&c->d_fe_recs, F * c->fe_col_slots * W * sizeof(FeColRec)));
+        CTX_TRY(hipMalloc((void **)&c->d_fe_cnt, F * W * 4));
+        CTX_TRY(hipMalloc((void **)&c->d_fe_events, F * FE_MAX_SKY_SLOTS * 3 * w64 * 8));
+    }
+    for (Slot &s : c->slots) {
         CTX_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         CTX_TRY(hipEventCreate(&s.ev_start));
         CTX_TRY(hipEventCreate(&s.ev_setup));
@@ -374,9 +564,16 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         CTX_TRY(hipMalloc((void **)&s.d_lists, lists_cap));
         CTX_TRY(hipMalloc((void **)&s.d_rspans, c->span_cap_per_batch * sizeof(DevRSpan)));
         CTX_TRY(hipMalloc((void **)&s.d_fb, F * 3 * W * H));
-#undef CTX_TRY
+        if (c->fe_enabled) {
+            CTX_TRY(hipHostMalloc((void **)&s.h_fe, c->fe_slab_cap, hipHostMallocDefault));
+            CTX_TRY(hipMalloc((void **)&s.d_fe, c->fe_slab_cap));
+            CTX_TRY(hipMalloc((void **)&s.d_fe_coloff, F * (W + 1) * 4));
+            CTX_TRY(hipMalloc((void **)&s.d_status, 2 * F * 4));
+            CTX_TRY(hipHostMalloc((void **)&s.h_status, 2 * F * 4, hipHostMallocDefault));
+        }
         s.lists_cap = lists_cap;
     }
+#undef CTX_TRY
     *out = c;
     return DG_OK;
 }
@@ -409,6 +606,7 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
     c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
     c->scene = &sc;
+    c->fe_scene_ok = sky.w >= 256 && sky.h >= 128;    // a smaller sky bitmap is an index panic only when a sky visplane is drawn: host path
     c->uploaded_texels = sc.texel_idx.size();
     return DG_OK;
 }
@@ -420,6 +618,7 @@ int dg_submit_views(dg_ctx *c, int slot, const dg_view *views, int n) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     Slot &s = c->slots[(size_t)slot];
     if (s.busy) { HIP_TRY(hipStreamSynchronize(s.stream)); s.busy = false; }
+    s.fe_check = false;
     rc = build_batch(c, s, views, nullptr, n);
     if (rc) return rc;
     return enqueue_kernels(c, s);
@@ -432,7 +631,7 @@ int dg_wait(dg_ctx *c, int slot) {
     Slot &s = c->slots[(size_t)slot];
     HIP_TRY(hipStreamSynchronize(s.stream));
     s.busy = false;
-    return DG_OK;
+    return settle_slot(c, s);
 }
 
 int dg_slot_framebuffer(dg_ctx *c, int slot, void **p) {
@@ -450,6 +649,11 @@ int dg_readback(dg_ctx *c, int slot, int first, int count, uint8_t *out) {
     if (!out || first < 0 || count < 0 || first + count > s.n_frames) return set_err(DG_ERR_INVALID, "bad readback range");
     HIP_TRY(hipSetDevice(c->cfg.device));
     const size_t fsz = (size_t)3 * (size_t)c->cfg.width * (size_t)c->cfg.height;
+    if (s.fe_check) {
+        HIP_TRY(hipStreamSynchronize(s.stream));
+        rc = settle_slot(c, s);
+        if (rc) return rc;
+    }
     HIP_TRY(hipMemcpyAsync(out, s.d_fb + (size_t)first * fsz, (size_t)count * fsz, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(hipStreamSynchronize(s.stream));
     s.busy = false;
@@ -477,11 +681,16 @@ int dg_prepare_views(dg_ctx *c, int slot, const dg_view *views, int n) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     Slot &s = c->slots[(size_t)slot];
     HIP_TRY(hipStreamSynchronize(s.stream));
-    s.busy = false;
+    s.busy = false; s.fe_check = false;
     rc = build_batch(c, s, views, nullptr, n);
     if (rc) return rc;
+    if (s.fe_mode) {              // run the column walk once so that a capacity overflow is found (and the slot re-prepared
+        rc = enqueue_kernels(c, s);   // through the host list path) now, not on a replay
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(s.stream));
-    return DG_OK;
+    s.busy = false;
+    return settle_slot(c, s);
 }
 
 int dg_replay_slot(dg_ctx *c, int slot) {
@@ -490,7 +699,14 @@ int dg_replay_slot(dg_ctx *c, int slot) {
     Slot &s = c->slots[(size_t)slot];
     if (s.n_frames <= 0) return set_err(DG_ERR_INVALID, "slot has no prepared lists");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    return enqueue_kernels(c, s);
+    if (s.fe_check) {             // a submission that was never waited for
+        HIP_TRY(hipStreamSynchronize(s.stream));
+        rc = settle_slot(c, s);
+        if (rc) return rc;
+    }
+    rc = enqueue_kernels(c, s);
+    s.fe_check = false;           // same records as the run that was checked: the flags cannot differ
+    return rc;
 }
 
 int dg_draw_lists(dg_ctx *c, int slot, const dg_frame_lists *frames, int n, uint8_t *out) {
@@ -500,6 +716,7 @@ int dg_draw_lists(dg_ctx *c, int slot, const dg_frame_lists *frames, int n, uint
     HIP_TRY(hipSetDevice(c->cfg.device));
     Slot &s = c->slots[(size_t)slot];
     if (s.busy) { HIP_TRY(hipStreamSynchronize(s.stream)); s.busy = false; }
+    s.fe_check = false;
     rc = build_batch(c, s, nullptr, frames, n);
     if (rc) return rc;
     rc = enqueue_kernels(c, s);
@@ -516,6 +733,11 @@ int dg_slot_timing(dg_ctx *c, int slot, dg_timing *out) {
     if (!s.timed) return set_err(DG_ERR_INVALID, "slot has not run yet");
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipEventSynchronize(s.ev_raster));
+    if (s.fe_check) {
+        HIP_TRY(hipStreamSynchronize(s.stream));
+        rc = settle_slot(c, s);
+        if (rc) return rc;
+    }
     std::memset(out, 0, sizeof *out);
     HIP_TRY(hipEventElapsedTime(&out->setup_ms, s.ev_start, s.ev_setup));
     HIP_TRY(hipEventElapsedTime(&out->raster_ms, s.ev_setup, s.ev_raster));
@@ -523,6 +745,7 @@ int dg_slot_timing(dg_ctx *c, int slot, dg_timing *out) {
     out->n_spans = s.n_spans; out->n_frames = (uint64_t)s.n_frames; out->covered_pixels = s.covered;
     out->host_ms = s.host_ms; out->list_bytes = s.list_bytes;
     out->n_walls = s.n_walls; out->n_planes = s.n_planes;
+    out->front_end = s.fe_mode ? DG_FE_DEVICE : DG_FE_HOST;
     return DG_OK;
 }
 

@@ -74,7 +74,7 @@ private:
 class Device {
 public:
     Device(int width, int height, int max_batch = 1, int device = 0) {
-        dg_config cfg{device, width, height, max_batch, 2, 0};
+        dg_config cfg{device, width, height, max_batch, 2, 0, DG_FE_AUTO};
         check(dg_create(&cfg, &h_));
     }
     ~Device() { dg_destroy(h_); }

@@ -29,18 +29,20 @@ struct FeParams {
     const FeSprite *sprites;
     const uint32_t *behind;
     // per-column scratch, [frame][slot][W] so that neighbouring lanes touch neighbouring addresses
-    uint32_t *keys;               // FE_MAX_SPANS_PER_COL slots
+    uint32_t *keys;               // col_slots slots
     FeU4 *sspans;                 // 2 x FeU4 per slot
-    FeColRec *recs;               // FE_MAX_RECS_PER_COL slots
+    FeColRec *recs;               // col_slots slots
     uint32_t *cnt;                // [frame][W] spans emitted per column
     uint64_t *events;             // [frame][FE_MAX_SKY_SLOTS][3][W64] add-floor / add-ceiling / flush bits per column
     uint32_t *flags;              // [frame] FE_OVF_*
+    uint32_t *totals;             // [frame] spans of the frame (written by dg_fe_finalize)
     // outputs consumed by dg_raster_tiles
     uint32_t *col_off;            // [frame][W + 1]
     DevRSpan *rspans;
     int32_t n_frames;
     uint32_t span_stride;         // rspans reserved per frame
     uint32_t w64;                 // (W + 63) / 64
+    uint32_t col_slots;           // span slots and wall-record slots per screen column in the scratch arrays (<= FE_MAX_COL_SLOTS)
 };
 
 struct FeColumn {                 // what one lane carries through the walk
@@ -53,8 +55,8 @@ DG_HD int32_t fe_min(int32_t a, int32_t b) { return a < b ? a : b; }
 DG_HD int32_t fe_max(int32_t a, int32_t b) { return a > b ? a : b; }
 
 DG_HD void fe_emit(const FeParams &P, int f, FeColumn &c, uint32_t key, const DevRSpan &r) {
-    if (c.nsp >= FE_MAX_SPANS_PER_COL) { c.ovf |= FE_OVF_SPANS; return; }
-    const size_t i = ((size_t)f * FE_MAX_SPANS_PER_COL + c.nsp) * (size_t)P.k.W + (size_t)c.x;
+    if (c.nsp >= P.col_slots) { c.ovf |= FE_OVF_SPANS; return; }
+    const size_t i = ((size_t)f * P.col_slots + c.nsp) * (size_t)P.k.W + (size_t)c.x;
     P.keys[i] = key;
     P.sspans[2 * i] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
     P.sspans[2 * i + 1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};
@@ -104,13 +106,13 @@ DG_HD uint32_t fe_part_column(const FeParams &P, int f, const DevFrame &fr, cons
         if (vis) {
             const bool ext_b = lower || (!two && full), ext_t = upper || (!two && full);
             if (two || ext_b || ext_t) {                                       // the records draw_map_objects clips against
-                if (c.nrec >= FE_MAX_RECS_PER_COL) c.ovf |= FE_OVF_RECS;
+                if (c.nrec >= P.col_slots) c.ovf |= FE_OVF_RECS;
                 else {
                     FeColRec r;
                     r.part = (uint16_t)pi;
                     r.kind = (uint16_t)((two ? FEC_TWO_SIDED : 0) | (ext_b ? FEC_EXT_BOTTOM : 0) | (ext_t ? FEC_EXT_TOP : 0) | (drawc ? FEC_DRAW_CEILING : 0));
                     r.ctop = (int16_t)ct; r.cbot = (int16_t)cb; r.bot_y = (int16_t)bottom_y; r.top_y = (int16_t)top_y; r.pad = 0;
-                    P.recs[((size_t)f * FE_MAX_RECS_PER_COL + c.nrec) * (size_t)P.k.W + (size_t)x] = r;
+                    P.recs[((size_t)f * P.col_slots + c.nrec) * (size_t)P.k.W + (size_t)x] = r;
                     c.nrec++;
                 }
             }
@@ -164,7 +166,7 @@ DG_HD void fe_sprite_column(const FeParams &P, int f, const FeFrame &ff, const F
     int32_t top_clip = -1, bottom_clip = H;
     const uint32_t *row = P.behind + ff.behind_base + s.behind_off;
     for (uint32_t i = 0; i < c.nrec; i++) {
-        const FeColRec r = P.recs[((size_t)f * FE_MAX_RECS_PER_COL + i) * (size_t)P.k.W + (size_t)x];
+        const FeColRec r = P.recs[((size_t)f * P.col_slots + i) * (size_t)P.k.W + (size_t)x];
         if ((row[r.part >> 5] >> (r.part & 31)) & 1u) continue;
         if (r.kind & FEC_TWO_SIDED) {
             if (r.kind & FEC_DRAW_CEILING) top_clip = fe_max(top_clip, r.top_y);

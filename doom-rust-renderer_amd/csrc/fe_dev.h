@@ -73,8 +73,8 @@ static_assert(sizeof(FeColRec) == 16, "FeColRec layout");
 enum : uint32_t { FE_EV_FADD = 1, FE_EV_CADD = 2, FE_EV_FLUSH = 4 };          // SidedefVisPlanes events of one column of one part
 enum : uint32_t { FE_OVF_SPANS = 1, FE_OVF_RECS = 2, FE_OVF_FRAME = 4 };      // per-frame overflow flags (the batch is redone on the host)
 
-constexpr uint32_t FE_MAX_SPANS_PER_COL = 48;    // spans a column may emit before the frame is flagged as overflowing
-constexpr uint32_t FE_MAX_RECS_PER_COL = 48;    // wall-record columns kept per screen column
+constexpr uint32_t FE_DEFAULT_COL_SLOTS = 48;  // spans / wall-record columns a screen column may hold before its frame is flagged as overflowing
+constexpr uint32_t FE_MAX_COL_SLOTS = 512;     // = SPAN_CAP of dg_raster_tiles
 constexpr uint32_t FE_KEY_WALL = 1u << 30;  // sort key = phase << 30 | major << 2 | minor
 constexpr uint32_t FE_KEY_PLANE = 2u << 30;
 constexpr uint32_t FE_KEY_LATE = 3u << 30;

@@ -85,9 +85,9 @@ __global__ __launch_bounds__(FE_FIN_THREADS) void dg_fe_finalize(FeParams P) {
             for (int x = p.sx + tid; x <= p.ex; x += FE_FIN_THREADS) {
                 if (!fe_gap(add, flush, x, p.sx, p.ex)) continue;
                 const uint32_t slot = atomicAdd(&cnt[x], 1u);
-                if (slot >= FE_MAX_SPANS_PER_COL) { atomicOr(&P.flags[f], (uint32_t)FE_OVF_SPANS); continue; }
+                if (slot >= P.col_slots) { atomicOr(&P.flags[f], (uint32_t)FE_OVF_SPANS); continue; }
                 const DevRSpan r = resolve_sky_span(fe_span(0, 0, 0, 0, SPAN_SKY, x), P.scene, P.k, fr);
-                const size_t i = ((size_t)f * FE_MAX_SPANS_PER_COL + slot) * (size_t)W + (size_t)x;
+                const size_t i = ((size_t)f * P.col_slots + slot) * (size_t)W + (size_t)x;
                 P.keys[i] = FE_KEY_PLANE | (pi << 2) | (uint32_t)kind;
                 P.sspans[2 * i] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
                 P.sspans[2 * i + 1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(FE_FIN_THREADS) void dg_fe_finalize(FeParams P) {
     const int chunk = (W + FE_FIN_THREADS - 1) / FE_FIN_THREADS;
     const int xa = tid * chunk, xb = min(W, xa + chunk);
     uint32_t mine = 0;
-    for (int x = xa; x < xb; x++) mine += min(cnt[x], FE_MAX_SPANS_PER_COL);
+    for (int x = xa; x < xb; x++) mine += min(cnt[x], P.col_slots);
     uint32_t incl = mine;
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t up = __shfl_up(incl, d);
@@ -120,20 +120,20 @@ __global__ __launch_bounds__(FE_FIN_THREADS) void dg_fe_finalize(FeParams P) {
     if (!fits && tid == 0) atomicOr(&P.flags[f], (uint32_t)FE_OVF_FRAME);
     uint32_t off = wave_sum[tid >> 6] + incl - mine;
     uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
-    if (tid == 0) coff[W] = fits ? total : 0u;
+    if (tid == 0) { coff[W] = fits ? total : 0u; P.totals[f] = total; }
 
     // 3. every column's spans in draw order: rank by key (keys of one column are distinct), scatter
     FeU4 *out = reinterpret_cast<FeU4 *>(P.rspans + fr.span_base);
     for (int x = xa; x < xb; x++) {
-        const uint32_t n = min(cnt[x], FE_MAX_SPANS_PER_COL);
+        const uint32_t n = min(cnt[x], P.col_slots);
         coff[x] = fits ? off : 0u;
         if (fits) {
             for (uint32_t i = 0; i < n; i++) {
-                const size_t si = ((size_t)f * FE_MAX_SPANS_PER_COL + i) * (size_t)W + (size_t)x;
+                const size_t si = ((size_t)f * P.col_slots + i) * (size_t)W + (size_t)x;
                 const uint32_t key = P.keys[si];
                 uint32_t rank = 0;
                 for (uint32_t j = 0; j < n; j++) {
-                    const uint32_t kj = P.keys[((size_t)f * FE_MAX_SPANS_PER_COL + j) * (size_t)W + (size_t)x];
+                    const uint32_t kj = P.keys[((size_t)f * P.col_slots + j) * (size_t)W + (size_t)x];
                     rank += (kj < key || (kj == key && j < i)) ? 1u : 0u;          // the tie-break keeps the scatter a permutation
                 }
                 out[2 * (size_t)(off + rank)] = P.sspans[2 * si];

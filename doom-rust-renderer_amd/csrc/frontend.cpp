@@ -186,6 +186,10 @@ struct Walker {
         if (status == DG_OK) { status = DG_ERR_RENDER; err = m; }
         return status;
     }
+    int fail_parts(const std::string &m) {                          // parts mode cannot tell: let the host list path decide
+        if (status == DG_OK) { status = kPartsUnsupported; err = m; }
+        return status;
+    }
 
     // Flats::get_animated at this frame's timestamp
     int resolve_flat(int flat, int anim) {
@@ -282,7 +286,7 @@ struct Walker {
         if (parts_mode) {
             if (tex >= 0) {
                 const BitmapInfo &bi = sc.bitmaps[(size_t)tex];
-                if (bi.w <= 0 || bi.h <= 0) { fail("zero-sized bitmap (reference divides by zero)"); return; }
+                if (bi.w <= 0 || bi.h <= 0) { fail_parts("zero-sized bitmap"); return; }
             }
             FePart p;
             std::memset(&p, 0, sizeof p);
@@ -306,7 +310,7 @@ struct Walker {
             p.ceil_plane.gwz = k.GCFX * p.ceil_plane.wz;
             p.ceil_plane.lightf = lightf;
             p.ceil_plane.flat_off = (uint32_t)s.ceil_flat * 4096u;
-            if (A.parts.size() >= 65535) { fail("more than 65535 wall records in a frame"); return; }
+            if (A.parts.size() >= 65535) { fail_parts("more than 65535 wall records in a frame"); return; }
             A.parts.push_back(p);
             recs.push_back(r);
             return;
@@ -493,7 +497,7 @@ struct Walker {
             int x0 = wrap_i16(bot.sx), x1 = wrap_i16(bot.ex);        // columns [x0, x1)
             if (x0 < x1 && (x0 < 0 || x1 > W)) { fail("map object column out of range (index panic)"); return; }
             if (parts_mode) {
-                if (bi.w <= 0 || bi.h <= 0) { if (x0 < x1) { fail("zero-sized bitmap (reference divides by zero)"); return; } continue; }
+                if (bi.w <= 0 || bi.h <= 0) { fail_parts("zero-sized bitmap"); return; }
                 FeSprite sp;
                 std::memset(&sp, 0, sizeof sp);
                 sp.x0 = x0; sp.x1 = x1;

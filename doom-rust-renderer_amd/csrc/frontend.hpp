@@ -56,6 +56,9 @@ void fill_view_trig(dg_view &v);
 
 // Parts mode: the per-seg and per-sprite half only (BSP order, transform, clip, projection, pegging, sprite sorting and the
 // sprite / masked-wall draw sequence); fills arena.parts / sprites / behind.  The per-column half runs on the GPU (frontend.hip).
+// Returns DG_OK, DG_ERR_RENDER (the reference would panic before any column is walked) or kPartsUnsupported (a case only the
+// host list path can judge: the caller redoes the frame with build_frame_lists).
+constexpr int kPartsUnsupported = 1000;
 int build_frame_parts(const Scene &sc, int W, int H, const dg_view &view, FrameArena &arena, std::string &err);
 
 // Per-record constants of render_vertical_bitmap_line (bitmap_render.rs:233-251), shared by the binner and the parts builder.

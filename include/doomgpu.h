@@ -81,7 +81,16 @@ typedef struct dg_config {
     int32_t max_batch;     /* frames per submission */
     int32_t slots;         /* in-flight submissions (>= 1); each owns a framebuffer slab of max_batch frames */
     int32_t host_threads;  /* list-generation threads for dg_render_views / dg_submit_views (0 = CPU affinity share, capped at 16) */
+    int32_t front_end;     /* DG_FE_*: where the per-column half of Segs::process_sidedef / draw_map_objects runs */
 } dg_config;
+
+/* dg_config.front_end.  The per-seg half (BSP order, transform, clip, projection: segs.rs:353-590) always runs on the host.
+ *   DG_FE_HOST    the host also walks every screen column and ships finished span lists (what dg_draw_lists consumes)
+ *   DG_FE_DEVICE  the host ships per-seg / per-sprite records; one GPU lane per screen column does segs.rs:202-345,
+ *                 sidedef_visplanes.rs and map_objects.rs:130-209.  A batch that exceeds a device-side capacity is redone
+ *                 through DG_FE_HOST transparently (same pixels either way).
+ *   DG_FE_AUTO    = DG_FE_DEVICE */
+enum { DG_FE_AUTO = 0, DG_FE_HOST = 1, DG_FE_DEVICE = 2 };
 
 int dg_create(const dg_config *cfg, dg_ctx **out);
 void dg_destroy(dg_ctx *ctx);
@@ -173,6 +182,10 @@ typedef struct dg_timing {
     float host_ms;            /* host list generation + binning + packing of that submission (wall clock) */
     uint64_t n_spans, n_frames, covered_pixels;
     uint64_t n_walls, n_planes, list_bytes; /* drawn records / visplanes, bytes of lists copied to HBM */
+    int32_t front_end;        /* DG_FE_HOST or DG_FE_DEVICE: what that submission actually used; with DG_FE_DEVICE setup_ms is
+                                 the column walk (dg_fe_columns + dg_fe_finalize), n_walls = wall records, n_planes = sprites,
+                                 covered_pixels is not tracked (0) */
+    int32_t reserved;
 } dg_timing;
 int dg_slot_timing(dg_ctx *ctx, int slot, dg_timing *out);
 

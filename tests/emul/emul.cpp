@@ -135,16 +135,16 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
     fr.span_base = 0;
     FeFrame ff{0, (uint32_t)arena.parts.size(), 0, (uint32_t)arena.sprites.size(), 0, arena.behind_words, arena.n_sky_slots, 0};
     const uint32_t w64 = (uint32_t)((W + 63) / 64);
-    std::vector<uint32_t> keys((size_t)FE_MAX_SPANS_PER_COL * W), cnt((size_t)W), col_off((size_t)W + 1), flags(1, 0);
-    std::vector<FeU4> sspans((size_t)2 * FE_MAX_SPANS_PER_COL * W);
-    std::vector<FeColRec> recs((size_t)FE_MAX_RECS_PER_COL * W);
+    std::vector<uint32_t> keys((size_t)FE_DEFAULT_COL_SLOTS * W), cnt((size_t)W), col_off((size_t)W + 1), flags(1, 0);
+    std::vector<FeU4> sspans((size_t)2 * FE_DEFAULT_COL_SLOTS * W);
+    std::vector<FeColRec> recs((size_t)FE_DEFAULT_COL_SLOTS * W);
     std::vector<uint64_t> events((size_t)FE_MAX_SKY_SLOTS * 3 * w64, 0);
-    std::vector<DevRSpan> rspans((size_t)W * FE_MAX_SPANS_PER_COL);
+    std::vector<DevRSpan> rspans((size_t)W * FE_DEFAULT_COL_SLOTS);
     FeParams P;
     P.scene = ds; P.k = k; P.frames = &fr; P.fframes = &ff; P.parts = arena.parts.data(); P.sprites = arena.sprites.data();
     P.behind = arena.behind.data(); P.keys = keys.data(); P.sspans = sspans.data(); P.recs = recs.data(); P.cnt = cnt.data();
-    P.events = events.data(); P.flags = flags.data(); P.col_off = col_off.data(); P.rspans = rspans.data();
-    P.n_frames = 1; P.span_stride = (uint32_t)rspans.size(); P.w64 = w64;
+    P.events = events.data(); P.flags = flags.data(); P.totals = nullptr; P.col_off = col_off.data(); P.rspans = rspans.data();
+    P.n_frames = 1; P.span_stride = (uint32_t)rspans.size(); P.w64 = w64; P.col_slots = FE_DEFAULT_COL_SLOTS;
 
     // dg_fe_columns, one "lane" at a time
     for (int x = 0; x < W; x++) {
@@ -180,7 +180,7 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
                 if (!fe_gap(add, flush, x, p.sx, p.ex)) continue;
                 n_gaps++;
                 const uint32_t slot = cnt[(size_t)x]++;
-                if (slot >= FE_MAX_SPANS_PER_COL) { flags[0] |= FE_OVF_SPANS; continue; }
+                if (slot >= FE_DEFAULT_COL_SLOTS) { flags[0] |= FE_OVF_SPANS; continue; }
                 const DevRSpan r = resolve_sky_span(fe_span(0, 0, 0, 0, SPAN_SKY, x), ds, k, fr);
                 const size_t i = (size_t)slot * W + (size_t)x;
                 keys[i] = FE_KEY_PLANE | (pi << 2) | (uint32_t)kind;
@@ -191,7 +191,7 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
     }
     uint32_t off = 0;
     for (int x = 0; x < W; x++) {
-        const uint32_t n = std::min<uint32_t>(cnt[(size_t)x], FE_MAX_SPANS_PER_COL);
+        const uint32_t n = std::min<uint32_t>(cnt[(size_t)x], FE_DEFAULT_COL_SLOTS);
         col_off[(size_t)x] = off;
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t key = keys[(size_t)i * W + x];

@@ -19,8 +19,8 @@ def scene1994(dg, wad1994):
     return dg.Scene(wad1994, "e1m1")
 
 
-def make_ctx(dg, scene, W, H, batch, slots=2):
-    ctx = dg.Context(W, H, max_batch=batch, slots=slots)
+def make_ctx(dg, scene, W, H, batch, slots=2, front_end=0):
+    ctx = dg.Context(W, H, max_batch=batch, slots=slots, front_end=front_end)
     ctx.upload_scene(scene)
     return ctx
 
@@ -30,12 +30,14 @@ def test_native_library_is_loaded(dg):
     assert "libdoomgpu.so" in open("/proc/self/maps").read()
 
 
-def test_full_camera_path_320x200_bit_exact(dg, scene1993, oracle_scene1993, path1993):
+@pytest.mark.parametrize("front_end", [1, 2], ids=["host-lists", "device-column-walk"])
+def test_full_camera_path_320x200_bit_exact(dg, scene1993, oracle_scene1993, path1993, front_end):
     """BASELINE config 1: 1 000-frame scripted path at 320x200, every frame byte-compared with the CPU oracle."""
     W, H, B = 320, 200, 250
-    ctx = make_ctx(dg, scene1993, W, H, B)
+    ctx = make_ctx(dg, scene1993, W, H, B, front_end=front_end)
     for b0 in range(0, 1000, B):
         out = ctx.render(dg.make_views(path1993[b0:b0 + B]))
+        assert ctx.timing(0)["front_end"] == front_end
         for k in range(B):
             ref = np.frombuffer(oracle_scene1993.render(W, H, path1993[b0 + k]), dtype=np.uint8).reshape(H, W, 3)
             assert np.array_equal(out[k], ref), f"frame {b0 + k}"
@@ -69,10 +71,11 @@ def test_golden_hashes_on_gpu(dg, scene1993, path1993, golden_frames):
         ctx.close()
 
 
-def test_heavy_map_bit_exact(dg, scene1994, oracle_scene1994, path1994, golden_frames):
+@pytest.mark.parametrize("front_end", [1, 2], ids=["host-lists", "device-column-walk"])
+def test_heavy_map_bit_exact(dg, scene1994, oracle_scene1994, path1994, golden_frames, front_end):
     W, H = 320, 200
-    idx = sorted(set(range(0, 1000, 8)) | {int(i) for i in golden_frames[1994]["320x200"]})
-    ctx = make_ctx(dg, scene1994, W, H, len(idx))
+    idx = sorted(set(range(0, 1000, 8)) | {277} | {int(i) for i in golden_frames[1994]["320x200"]})   # 277: zero-filled sky visplane columns
+    ctx = make_ctx(dg, scene1994, W, H, len(idx), front_end=front_end)
     out = ctx.render(dg.make_views(path1994[idx]))
     for k, i in enumerate(idx):
         ref = np.frombuffer(oracle_scene1994.render(W, H, path1994[i]), dtype=np.uint8).reshape(H, W, 3)
@@ -308,4 +311,54 @@ def test_pinned_host_readback(dg, scene1993, path1993):
     got = np.ctypeslib.as_array((ctypes.c_uint8 * (4 * ctx.frame_bytes)).from_address(p)).reshape(4, 200, 320, 3)
     assert np.array_equal(got, ref)
     dg.lib().dg_free_host(p)
+    ctx.close()
+
+
+def test_front_ends_agree_1280x800(dg, scene1993, scene1994, path1993, path1994):
+    """Host span lists vs device column walk: same frames byte for byte, and each context reports the path it ran."""
+    W, H = 1280, 800
+    for scene, path in [(scene1993, path1993), (scene1994, path1994)]:
+        idx = list(range(0, 1000, 40))
+        views = dg.make_views(path[idx])
+        out = {}
+        for fe in (dg.DG_FE_HOST, dg.DG_FE_DEVICE):
+            ctx = make_ctx(dg, scene, W, H, len(idx), slots=1, front_end=fe)
+            out[fe] = ctx.render(views).copy()
+            t = ctx.timing(0)
+            assert t["front_end"] == fe and t["n_spans"] > 0
+            ctx.close()
+        assert np.array_equal(out[dg.DG_FE_HOST], out[dg.DG_FE_DEVICE])
+
+
+def test_device_front_end_capacity_falls_back_to_host_lists(dg, scene1994, oracle_scene1994, path1994, monkeypatch):
+    """Two capacity limits of the device column walk, both answered by redoing the batch through the host list path:
+    (a) more wall records than the record slab holds (known before the launch), (b) more spans in a screen column than
+    the scratch has slots (found by the kernel, reported through the overflow flags at dg_wait)."""
+    W, H = 320, 200
+    ref809 = np.frombuffer(oracle_scene1994.render(W, H, path1994[809]), dtype=np.uint8).reshape(H, W, 3)
+    ctx = make_ctx(dg, scene1994, W, H, 1, slots=1, front_end=dg.DG_FE_DEVICE)       # frame 809: 2 104 records > 2 048 per frame
+    assert np.array_equal(ctx.render(dg.make_views(path1994[809:810]))[0], ref809)
+    assert ctx.timing(0)["front_end"] == dg.DG_FE_HOST
+    assert np.array_equal(ctx.render(dg.make_views(path1994[100:101]))[0],
+                          np.frombuffer(oracle_scene1994.render(W, H, path1994[100]), dtype=np.uint8).reshape(H, W, 3))
+    assert ctx.timing(0)["front_end"] == dg.DG_FE_DEVICE
+    ctx.close()
+
+    monkeypatch.setenv("DOOMGPU_FE_COLUMN_SLOTS", "5")
+    idx = list(range(0, 1000, 50))
+    ctx = make_ctx(dg, scene1994, W, H, len(idx), slots=2, front_end=dg.DG_FE_DEVICE)
+    monkeypatch.delenv("DOOMGPU_FE_COLUMN_SLOTS")
+    views = dg.make_views(path1994[idx])
+    out = ctx.render(views)
+    assert ctx.timing(0)["front_end"] == dg.DG_FE_HOST
+    for k, i in enumerate(idx):
+        assert np.array_equal(out[k], np.frombuffer(oracle_scene1994.render(W, H, path1994[i]), dtype=np.uint8).reshape(H, W, 3)), f"frame {i}"
+    # asynchronous slots + prepared replays take the same route
+    ctx.submit(1, views)
+    ctx.wait(1)
+    assert np.array_equal(ctx.readback(1, 0, len(idx)), out)
+    ctx.prepare(0, views)
+    ctx.replay(0)
+    ctx.wait(0)
+    assert np.array_equal(ctx.readback(0, 0, len(idx)), out) and ctx.timing(0)["front_end"] == dg.DG_FE_HOST
     ctx.close()
