@@ -6,7 +6,7 @@
 //   per slot: list slab  [DevFrame x F | col_off x F*(W+1) | DevWallRec.. | DevPlaneRec.. | DevSpan..]  one H2D copy
 //             rspan slab DevRSpan 32 B per span (device-only, written by dg_setup_spans, walked by dg_raster_tiles)
 //             framebuffer slab  F x 3*W*H bytes RGB24 (the reference's Pixels.pixels, one per frame)
-//             DG_FE_DEVICE: record slab [DevFrame x F | FeFrame x F | FePart.. | FeSprite.. | behind bits..] (one H2D copy),
+//             DG_FE_DEVICE: record slab [DevFrame x F | FeFrame x F | FePart.. | part column ranges.. | FeSprite.. | behind bits.. | sky slot -> part..] (one H2D copy),
 //             col_off F*(W+1) written by dg_fe_finalize, 2F status words (overflow flags, span totals)
 //   per ctx : DG_FE_DEVICE column scratch [F][slot][W]: keys 4 B, spans 32 B (48 slots), wall-record columns 16 B (48 slots),
 //             counts, sky event bits — shared by the slots because their kernels run back to back
@@ -131,7 +131,7 @@ struct Slot {
 struct FeFrameOut {               // parts-mode output of one frame, owned per batch index
     std::vector<FePart> parts;
     std::vector<FeSprite> sprites;
-    std::vector<uint32_t> behind;
+    std::vector<uint32_t> behind, sky_parts;
     uint32_t behind_words = 0, n_sky_slots = 0;
     DevFrame hdr{};
 };
@@ -293,7 +293,7 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
         fill_view_trig(v);
         rc[(size_t)i] = build_frame_parts(sc, W, H, v, A, errs[(size_t)i]);
         if (rc[(size_t)i]) return;
-        o.parts.swap(A.parts); o.sprites.swap(A.sprites); o.behind.swap(A.behind);
+        o.parts.swap(A.parts); o.sprites.swap(A.sprites); o.behind.swap(A.behind); o.sky_parts.swap(A.sky_parts);
         o.behind_words = A.behind_words; o.n_sky_slots = A.n_sky_slots;
         o.hdr = make_frame_header(v);
     });
@@ -301,23 +301,27 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
         if (rc[(size_t)i] == kPartsUnsupported) return kPartsUnsupported;
         if (rc[(size_t)i]) return set_err(rc[(size_t)i], "frame " + std::to_string(i) + ": " + errs[(size_t)i]);
     }
-    uint64_t parts = 0, sprites = 0, behind = 0;
+    uint64_t parts = 0, sprites = 0, behind = 0, skies = 0;
+    uint32_t max_sky = 0;
     std::vector<FeFrame> ffs((size_t)n);
     for (int i = 0; i < n; i++) {
         const FeFrameOut &o = c->fe_out[(size_t)i];
         if (o.n_sky_slots > FE_MAX_SKY_SLOTS) return kPartsUnsupported;
         ffs[(size_t)i] = FeFrame{(uint32_t)parts, (uint32_t)o.parts.size(), (uint32_t)sprites, (uint32_t)o.sprites.size(), (uint32_t)behind,
-                                 o.behind_words, o.n_sky_slots, 0u};
-        parts += o.parts.size(); sprites += o.sprites.size(); behind += o.behind.size();
+                                 o.behind_words, o.n_sky_slots, (uint32_t)skies};
+        parts += o.parts.size(); sprites += o.sprites.size(); behind += o.behind.size(); skies += o.n_sky_slots;
+        max_sky = std::max(max_sky, o.n_sky_slots);
     }
     if (parts > c->fe_part_cap || sprites > c->fe_sprite_cap || behind > c->fe_behind_cap) return kPartsUnsupported;
     const uint32_t span_stride = (uint32_t)(c->span_cap_per_batch / (size_t)c->cfg.max_batch);
     const size_t off_frames = 0;
     const size_t off_ff = align_up(off_frames + (size_t)n * sizeof(DevFrame), 256);
     const size_t off_parts = align_up(off_ff + (size_t)n * sizeof(FeFrame), 256);
-    const size_t off_sprites = align_up(off_parts + parts * sizeof(FePart), 256);
+    const size_t off_bounds = align_up(off_parts + parts * sizeof(FePart), 256);
+    const size_t off_sprites = align_up(off_bounds + parts * 4, 256);
     const size_t off_behind = align_up(off_sprites + sprites * sizeof(FeSprite), 256);
-    const size_t total = off_behind + behind * 4;
+    const size_t off_sky = align_up(off_behind + behind * 4, 256);
+    const size_t total = off_sky + skies * 4;
     if (total > c->fe_slab_cap) return kPartsUnsupported;
     c->pool->parallel_for(n, [&](int i, int) {
         FeFrameOut &o = c->fe_out[(size_t)i];
@@ -326,8 +330,11 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
         std::memcpy(s.h_fe + off_frames + (size_t)i * sizeof(DevFrame), &o.hdr, sizeof(DevFrame));
         std::memcpy(s.h_fe + off_ff + (size_t)i * sizeof(FeFrame), &ff, sizeof(FeFrame));
         if (!o.parts.empty()) std::memcpy(s.h_fe + off_parts + (size_t)ff.part_base * sizeof(FePart), o.parts.data(), o.parts.size() * sizeof(FePart));
+        uint32_t *bnd = reinterpret_cast<uint32_t *>(s.h_fe + off_bounds) + ff.part_base;
+        for (size_t k = 0; k < o.parts.size(); k++) bnd[k] = (uint32_t)o.parts[k].sx | ((uint32_t)o.parts[k].ex << 16);
         if (!o.sprites.empty()) std::memcpy(s.h_fe + off_sprites + (size_t)ff.sprite_base * sizeof(FeSprite), o.sprites.data(), o.sprites.size() * sizeof(FeSprite));
         if (!o.behind.empty()) std::memcpy(s.h_fe + off_behind + (size_t)ff.behind_base * 4, o.behind.data(), o.behind.size() * 4);
+        if (!o.sky_parts.empty()) std::memcpy(s.h_fe + off_sky + (size_t)ff.sky_base * 4, o.sky_parts.data(), o.sky_parts.size() * 4);
     });
     FeParams &F = s.FP;
     F.scene = c->dscene;
@@ -335,8 +342,11 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     F.frames = reinterpret_cast<const DevFrame *>(s.d_fe + off_frames);
     F.fframes = reinterpret_cast<const FeFrame *>(s.d_fe + off_ff);
     F.parts = reinterpret_cast<const FePart *>(s.d_fe + off_parts);
+    F.bounds = reinterpret_cast<const uint32_t *>(s.d_fe + off_bounds);
     F.sprites = reinterpret_cast<const FeSprite *>(s.d_fe + off_sprites);
     F.behind = reinterpret_cast<const uint32_t *>(s.d_fe + off_behind);
+    F.sky_parts = reinterpret_cast<const uint32_t *>(s.d_fe + off_sky);
+    F.max_sky_slots = max_sky;
     F.keys = c->d_fe_keys; F.sspans = c->d_fe_sspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt; F.events = c->d_fe_events;
     F.flags = s.d_status; F.totals = s.d_status + c->cfg.max_batch;
     F.col_off = s.d_fe_coloff; F.rspans = s.d_rspans;
@@ -540,8 +550,8 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         c->fe_part_cap = F * 2048;         // wall records per frame on average (e1m1-like maps: 20-600)
         c->fe_sprite_cap = F * 256;
         c->fe_behind_cap = F * 256 * 32;   // one bit per (sprite, wall record)
-        c->fe_slab_cap = align_up(F * sizeof(DevFrame), 256) + align_up(F * sizeof(FeFrame), 256) + align_up(c->fe_part_cap * sizeof(FePart), 256) +
-                         align_up(c->fe_sprite_cap * sizeof(FeSprite), 256) + c->fe_behind_cap * 4 + 1024;
+        c->fe_slab_cap = align_up(F * sizeof(DevFrame), 256) + align_up(F * sizeof(FeFrame), 256) + align_up(c->fe_part_cap * sizeof(FePart), 256) + align_up(c->fe_part_cap * 4, 256) +
+                         align_up(c->fe_sprite_cap * sizeof(FeSprite), 256) + align_up(c->fe_behind_cap * 4, 256) + F * FE_MAX_SKY_SLOTS * 4 + 1024;
     }
     c->slots.resize((size_t)cfg->slots);
     hipError_t e;

@@ -26,8 +26,10 @@ struct FeParams {
     const DevFrame *frames;       // [n_frames] view constants + span_base (= f * span_stride)
     const FeFrame *fframes;       // [n_frames]
     const FePart *parts;
+    const uint32_t *bounds;       // per part: sx | ex << 16 (the column range, for the lane-parallel hit test)
     const FeSprite *sprites;
     const uint32_t *behind;
+    const uint32_t *sky_parts;    // per sky slot: index of its part within the frame
     // per-column scratch, [frame][slot][W] so that neighbouring lanes touch neighbouring addresses
     uint32_t *keys;               // col_slots slots
     FeU4 *sspans;                 // 2 x FeU4 per slot
@@ -42,6 +44,7 @@ struct FeParams {
     int32_t n_frames;
     uint32_t span_stride;         // rspans reserved per frame
     uint32_t w64;                 // (W + 63) / 64
+    uint32_t max_sky_slots;       // max n_sky_slots over the frames of the batch (grid of dg_fe_gaps)
     uint32_t col_slots;           // span slots and wall-record slots per screen column in the scratch arrays (<= FE_MAX_COL_SLOTS)
 };
 

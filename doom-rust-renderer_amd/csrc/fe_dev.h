@@ -56,7 +56,7 @@ struct FeFrame {
     uint32_t behind_base;         // uint32 words
     uint32_t behind_words;        // words per sprite row = ceil(n_parts / 32)
     uint32_t n_sky_slots;
-    uint32_t pad;
+    uint32_t sky_base;            // into the batch's sky_parts array
 };
 static_assert(sizeof(FeFrame) == 32, "FeFrame layout");
 
@@ -74,7 +74,7 @@ enum : uint32_t { FE_EV_FADD = 1, FE_EV_CADD = 2, FE_EV_FLUSH = 4 };          //
 enum : uint32_t { FE_OVF_SPANS = 1, FE_OVF_RECS = 2, FE_OVF_FRAME = 4 };      // per-frame overflow flags (the batch is redone on the host)
 
 constexpr uint32_t FE_DEFAULT_COL_SLOTS = 48;  // spans / wall-record columns a screen column may hold before its frame is flagged as overflowing
-constexpr uint32_t FE_MAX_COL_SLOTS = 512;     // = SPAN_CAP of dg_raster_tiles
+constexpr uint32_t FE_MAX_COL_SLOTS = 128;     // dg_fe_scatter stages 64 columns x this many keys in LDS (32 KB)
 constexpr uint32_t FE_KEY_WALL = 1u << 30;  // sort key = phase << 30 | major << 2 | minor
 constexpr uint32_t FE_KEY_PLANE = 2u << 30;
 constexpr uint32_t FE_KEY_LATE = 3u << 30;

@@ -297,7 +297,11 @@ struct Walker {
             p.flags = (f.only_occlusions ? FEP_ONLY_OCCL : 0u) | (f.lower ? FEP_LOWER : 0u) | (f.upper ? FEP_UPPER : 0u) |
                       (f.draw_ceiling ? FEP_DRAW_CEILING : 0u) | (f.two_sided_mid ? FEP_TWO_SIDED_MID : 0u) | (tex >= 0 ? FEP_HAS_BITMAP : 0u) |
                       (fsky ? FEP_FLOOR_SKY : 0u) | (csky ? FEP_CEIL_SKY : 0u);
-            p.sky_slot = (planes_here && (fsky || (csky && f.draw_ceiling))) ? (int32_t)A.n_sky_slots++ : -1;
+            p.sky_slot = -1;
+            if (planes_here && (fsky || (csky && f.draw_ceiling))) {
+                p.sky_slot = (int32_t)A.n_sky_slots++;
+                A.sky_parts.push_back((uint32_t)A.parts.size());
+            }
             if (tex >= 0)
                 p.wall = make_wall_rec(sc.bitmaps[(size_t)tex], r.line.a.x, r.line.a.y, r.line.b.x, r.line.b.y, r.start_offset, r.start_x, r.end_x,
                                        bottom_height, top_height, r.offset_x, r.offset_y, r.light);
@@ -655,7 +659,7 @@ int build_frame_lists(const Scene &sc, int W, int H, const dg_view &view, FrameA
 
 int build_frame_parts(const Scene &sc, int W, int H, const dg_view &view, FrameArena &A, std::string &err) {
     if (W <= 0 || H <= 0 || W > 16384 || H > 16384) { err = "bad frame size"; return DG_ERR_INVALID; }
-    A.parts.clear(); A.sprites.clear(); A.behind.clear(); A.behind_words = 0; A.n_sky_slots = 0;
+    A.parts.clear(); A.sprites.clear(); A.behind.clear(); A.sky_parts.clear(); A.behind_words = 0; A.n_sky_slots = 0;
     A.recs->clear();
     Walker wk(sc, W, H, view, A, err);
     wk.parts_mode = true;

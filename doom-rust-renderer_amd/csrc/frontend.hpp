@@ -34,6 +34,7 @@ struct FrameArena {
     // parts mode (device column walk): per-seg / per-sprite records instead of finished columns
     std::vector<FePart> parts;
     std::vector<FeSprite> sprites;
+    std::vector<uint32_t> sky_parts;    // per sky slot: index of the part
     std::vector<uint32_t> behind;       // n_sprites rows of behind_words bits: wall record p is behind sprite s
     uint32_t behind_words = 0, n_sky_slots = 0;
     // scratch

@@ -142,7 +142,7 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
     std::vector<DevRSpan> rspans((size_t)W * FE_DEFAULT_COL_SLOTS);
     FeParams P;
     P.scene = ds; P.k = k; P.frames = &fr; P.fframes = &ff; P.parts = arena.parts.data(); P.sprites = arena.sprites.data();
-    P.behind = arena.behind.data(); P.keys = keys.data(); P.sspans = sspans.data(); P.recs = recs.data(); P.cnt = cnt.data();
+    P.behind = arena.behind.data(); P.bounds = nullptr; P.keys = keys.data(); P.sspans = sspans.data(); P.recs = recs.data(); P.cnt = cnt.data();
     P.events = events.data(); P.flags = flags.data(); P.totals = nullptr; P.col_off = col_off.data(); P.rspans = rspans.data();
     P.n_frames = 1; P.span_stride = (uint32_t)rspans.size(); P.w64 = w64; P.col_slots = FE_DEFAULT_COL_SLOTS;
 
@@ -168,11 +168,13 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
         cnt[(size_t)x] = c.nsp;
         flags[0] |= c.ovf;
     }
-    // dg_fe_finalize
+    // dg_fe_gaps, dg_fe_scan, dg_fe_scatter
     uint64_t n_gaps = 0;
-    for (uint32_t pi = 0; pi < ff.n_parts; pi++) {
+    if (arena.sky_parts.size() != arena.n_sky_slots) { g_err = "sky_parts / n_sky_slots mismatch"; return DG_ERR_INVALID; }
+    for (uint32_t si = 0; si < ff.n_sky_slots; si++) {            // dg_fe_gaps: one wave per sky slot
+        const uint32_t pi = arena.sky_parts[si];
         const FePart &p = P.parts[pi];
-        if (p.sky_slot < 0) continue;
+        if (p.sky_slot != (int32_t)si) { g_err = "sky slot table does not point back at its part"; return DG_ERR_INVALID; }
         for (int kind = 0; kind < 2; kind++) {
             if (!(p.flags & (kind ? FEP_CEIL_SKY : FEP_FLOOR_SKY))) continue;
             const uint64_t *add = fe_event_words(P, 0, p.sky_slot, kind), *flush = fe_event_words(P, 0, p.sky_slot, 2);
