@@ -8,10 +8,13 @@ Workload (config.workload): BASELINE config 2 — the 1 000-frame scripted camer
 map, rendered natively at 1280x800 (the size the ">= 10 000 fps" target is quoted on), one MI355X per rank.  No id
 WAD can be shipped, so the map is the committed synthetic IWAD (seed 1993) and `data` says "synthetic".
 
-A *step* is one pass of the hot path over one batch of `--batch` consecutive path frames whose seg / visplane /
-sprite lists are already resident in HBM (4 slots x 250 frames = the whole path).  `value` = frames / time over exactly
-K steps: span-setup + tile-raster kernels producing K*batch RGB24 frames in HBM.  The PCIe-inclusive number (host list
-generation on T threads + H2D + the same kernels, double-buffered) is reported next to it as `e2e` and is never `value`.
+A *step* is one pass of the hot path over one batch of `--batch` consecutive path frames whose per-seg / per-sprite
+records (the output of the BSP walk, clip and projection) are already resident in HBM (4 slots x 250 frames = the whole
+path).  `value` = frames / time over exactly K steps: device column walk (dg_fe_columns, dg_fe_gaps, dg_fe_scan,
+dg_fe_scatter) + tile raster (dg_raster_tiles) producing K*batch RGB24 frames in HBM.  With `--front-end host` the
+resident input is the finished column-major span lists instead (span setup + tile raster), the round-1 first definition.
+The PCIe-inclusive number (host record generation on T threads + H2D + the same kernels, double-buffered) is reported
+next to it as `e2e` and is never `value`.
 
 Multi-GPU: the path shards with no exchange step — rank r renders its own camera path (same map, route rotated by
 r/N and reversed for odd r) on GPU LOCAL_RANK; there is NO data-path collective and no RCCL.  torch.distributed (gloo,
@@ -19,8 +22,8 @@ CPU tensors) is used only for the timing barrier and the MAX over ranks; value =
 
 roofline: dominant kernel dg_raster_tiles, HBM-bound model.  achieved = algorithmic bytes per launch / mean launch
 duration from HIP events recorded on the kernel's own stream during the timed steps (dg_slot_timing).  Algorithmic
-bytes per frame = 3*W*H (RGB24 stored once) + W*H (one texel byte per pixel) + list bytes read (24 B per span incl. aux,
-48 B per wall record, 16 B per plane, 4*(W+1) column index) — SURVEY.md §8d, DESIGN.md "Roofline accounting".
+bytes per frame = 3*W*H (RGB24 stored once) + W*H (one texel byte per pixel) + list bytes the kernel reads (32 B per
+span, 4*(W+1) column index) — SURVEY.md §8d, DESIGN.md "Roofline accounting".
 cpu_baseline: the CPU oracle (oracle/doomref.c, a port of the reference renderer) on 1 host core over a bounded
 sample of the same frames at the same size (rank 0, N = 1 only).
 """
@@ -66,6 +69,7 @@ def main():
     ap.add_argument("--batch", type=int, default=250)
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--front-end", choices=["device", "host"], default="device", help="where the per-column half of the seg / sprite processing runs")
     ap.add_argument("--cpu-sample", type=int, default=4, help="cpu_baseline renders every n-th path frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -95,7 +99,8 @@ def main():
     route = rank_route(sw.synth_route(1993), rank, world)
     path = cp.make_camera_path(route, lambda x, y, d: scene.floor_height_at(x, y, d), 1000)
     n_slots = max(1, min(args.slots, (1000 + B - 1) // B))
-    ctx = dg.Context(W, H, max_batch=B, slots=n_slots, device=device, host_threads=args.host_threads)
+    fe = dg.DG_FE_HOST if args.front_end == "host" else dg.DG_FE_DEVICE
+    ctx = dg.Context(W, H, max_batch=B, slots=n_slots, device=device, host_threads=args.host_threads, front_end=fe)
     ctx.upload_scene(scene)
 
     batches = [np.concatenate([path, path])[b0:b0 + B] for b0 in range(0, n_slots * B, B)]
@@ -126,7 +131,7 @@ def main():
         raster_ms.append(t["raster_ms"])
         setup_ms.append(t["setup_ms"])
         nf = t["n_frames"]
-        alg_bytes.append(nf * (3 * W * H + W * H + 4 * (W + 1)) + 24 * t["n_spans"] + 48 * t["n_walls"] + 16 * t["n_planes"])
+        alg_bytes.append(nf * (3 * W * H + W * H + 4 * (W + 1)) + 32 * t["n_spans"])
         stats.update(t)
 
     t0 = time.perf_counter()
@@ -149,7 +154,7 @@ def main():
     # ---- PCIe-inclusive end-to-end (host list generation + H2D + kernels), double-buffered ----------------------
     e2e = None
     if not args.no_e2e:
-        nb = max(4, min(12, args.steps))
+        nb = max(4, min(24, args.steps))
         for i in range(2):
             ctx.submit(i % n_slots, views[i % n_slots])
         sync_all()
@@ -158,13 +163,13 @@ def main():
         t1 = time.perf_counter()
         for i in range(nb):
             s = i % n_slots
-            ctx.submit(s, views[s])
-            host_ms.append(ctx.timing(s)["host_ms"])
+            ctx.submit(s, views[s])           # returns once the batch is queued; waits only if the slot is still busy
         sync_all()
         barrier()
         e2e_s = dist_max(time.perf_counter() - t1, dist)
+        host_ms = [ctx.timing(s)["host_ms"] for s in range(min(n_slots, nb))]   # after the clock: dg_slot_timing synchronises
         e2e = {"value": aggregate_fps(nb * B, world, e2e_s), "unit": "frames/s",
-               "includes": "host list generation + pinned staging + H2D + setup/raster kernels, frames left in HBM",
+               "includes": "host BSP walk / record generation + pinned staging + H2D + all kernels, frames left in HBM",
                "host_threads": ctx.host_threads, "host_ms_per_batch": float(np.mean(host_ms)),
                "list_bytes_per_frame": int(stats.get("list_bytes", 0) // max(1, stats.get("n_frames", 1)))}
 
@@ -203,7 +208,7 @@ def main():
             traffic = None
     roofline = {"kernel": "dg_raster_tiles", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic, "algorithmic_bytes_per_launch": float(np.mean(alg_bytes)),
-                "mean_launch_ms": mean_raster_s * 1e3, "setup_kernel_mean_ms": float(np.mean(setup_ms)),
+                "mean_launch_ms": mean_raster_s * 1e3, "front_end_kernels_mean_ms": float(np.mean(setup_ms)),
                 "frames_per_launch": B, "pixels_per_s": B * W * H / mean_raster_s}
 
     # ---- CPU baseline (oracle = port of the reference renderer), rank 0, N = 1 only ---------------------------------
@@ -241,7 +246,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic e1m1-like IWAD (seed 1993), 1000-frame scripted camera path, {W}x{H} native, "
-                                   f"{B} frames per step, lists resident in HBM", "width": W, "height": H, "frames_per_step": B,
+                                   f"{B} frames per step, " + ("per-seg / per-sprite records" if stats.get("front_end") == dg.DG_FE_DEVICE else "span lists") +
+                                   " resident in HBM", "front_end": "device column walk" if stats.get("front_end") == dg.DG_FE_DEVICE else "host span lists",
+                       "width": W, "height": H, "frames_per_step": B,
                        "slots": n_slots, "parallelism": f"{world} independent camera path(s), one per GPU, no collective"},
             "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "e2e_host_frames": e2e_host,
         }
