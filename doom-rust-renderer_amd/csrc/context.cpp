@@ -8,7 +8,7 @@
 //             framebuffer slab  F x 3*W*H bytes RGB24 (the reference's Pixels.pixels, one per frame)
 //             DG_FE_DEVICE: record slab [DevFrame x F | FeFrame x F | FePart.. | part column ranges.. | FeSprite.. | behind bits.. | sky slot -> part..] (one H2D copy),
 //             col_off F*(W+1) written by dg_fe_finalize, 2F status words (overflow flags, span totals)
-//   per ctx : DG_FE_DEVICE column scratch [F][slot][W]: keys 4 B, spans 32 B (48 slots), wall-record columns 16 B (48 slots),
+//   per ctx : DG_FE_DEVICE column scratch [F][slot][W]: compact spans 16 B (48 slots), wall-record columns 16 B (48 slots),
 //             counts, sky event bits — shared by the slots because their kernels run back to back
 #include <hip/hip_runtime_api.h>
 #include <sched.h>
@@ -161,8 +161,8 @@ struct dg_ctx {
     std::vector<FeFrameOut> fe_out;     // one per frame of a batch
     uint32_t fe_col_slots = FE_DEFAULT_COL_SLOTS;
     size_t fe_part_cap = 0, fe_sprite_cap = 0, fe_behind_cap = 0, fe_slab_cap = 0;
-    uint32_t *d_fe_keys = nullptr, *d_fe_cnt = nullptr;
-    FeU4 *d_fe_sspans = nullptr;
+    uint32_t *d_fe_cnt = nullptr;
+    FeU4 *d_fe_cspans = nullptr;
     FeColRec *d_fe_recs = nullptr;
     uint64_t *d_fe_events = nullptr;
 };
@@ -195,9 +195,8 @@ void free_ctx(dg_ctx *c) {
     if (c->d_texel_idx) (void)hipFree(c->d_texel_idx);
     if (c->d_texel_opq) (void)hipFree(c->d_texel_opq);
     if (c->d_flats) (void)hipFree(c->d_flats);
-    if (c->d_fe_keys) (void)hipFree(c->d_fe_keys);
     if (c->d_fe_cnt) (void)hipFree(c->d_fe_cnt);
-    if (c->d_fe_sspans) (void)hipFree(c->d_fe_sspans);
+    if (c->d_fe_cspans) (void)hipFree(c->d_fe_cspans);
     if (c->d_fe_recs) (void)hipFree(c->d_fe_recs);
     if (c->d_fe_events) (void)hipFree(c->d_fe_events);
     delete c;
@@ -347,7 +346,7 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     F.behind = reinterpret_cast<const uint32_t *>(s.d_fe + off_behind);
     F.sky_parts = reinterpret_cast<const uint32_t *>(s.d_fe + off_sky);
     F.max_sky_slots = max_sky;
-    F.keys = c->d_fe_keys; F.sspans = c->d_fe_sspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt; F.events = c->d_fe_events;
+    F.cspans = c->d_fe_cspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt; F.events = c->d_fe_events;
     F.flags = s.d_status; F.totals = s.d_status + c->cfg.max_batch;
     F.col_off = s.d_fe_coloff; F.rspans = s.d_rspans;
     F.n_frames = n; F.span_stride = span_stride; F.w64 = (uint32_t)((W + 63) / 64); F.col_slots = c->fe_col_slots;
@@ -541,7 +540,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     c->fe_enabled = cfg->front_end != DG_FE_HOST;
     if (c->fe_enabled) {
         // Scratch slots per screen column (spans and wall-record columns).  A column that needs more sends its batch through
-        // the host list path; DOOMGPU_FE_COLUMN_SLOTS trades scratch HBM (52 B x slots x width x max_batch) against that.
+        // the host list path; DOOMGPU_FE_COLUMN_SLOTS trades scratch HBM (32 B x slots x width x max_batch) against that.
         if (const char *e = std::getenv("DOOMGPU_FE_COLUMN_SLOTS")) {
             const long v = std::strtol(e, nullptr, 10);
             if (v >= 1 && v <= (long)FE_MAX_COL_SLOTS) c->fe_col_slots = (uint32_t)v;
@@ -558,8 +557,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
 #define CTX_TRY(expr) if ((e = (expr)) != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(e); free_ctx(c); return set_err(DG_ERR_HIP, m); }
     if (c->fe_enabled) {
         const size_t w64 = (W + 63) / 64;
-        CTX_TRY(hipMalloc((void **)&c->d_fe_keys, F * c->fe_col_slots * W * 4));
-        CTX_TRY(hipMalloc((void **)&c->d_fe_sspans, F * c->fe_col_slots * W * 2 * sizeof(FeU4)));
+        CTX_TRY(hipMalloc((void **)&c->d_fe_cspans, F * c->fe_col_slots * W * sizeof(FeU4)));
         CTX_TRY(hipMalloc((void **)&c->d_fe_recs, F * c->fe_col_slots * W * sizeof(FeColRec)));
         CTX_TRY(hipMalloc((void **)&c->d_fe_cnt, F * W * 4));
         CTX_TRY(hipMalloc((void **)&c->d_fe_events, F * FE_MAX_SKY_SLOTS * 3 * w64 * 8));

@@ -7,8 +7,8 @@
 //   fe_sprite_column  the clip arrays and the column push of draw_map_objects                       src/renderer/map_objects.rs:130-209
 //   fe_gap            the zero-filled Visplane entries between two adds of one visplane             src/renderer/visplanes.rs:28-38
 //
-// Spans are resolved on the spot into the raster kernel's DevRSpan (raster_core.h) and appended to the column's scratch
-// list with a sort key that encodes the reference's draw order (frontend.hpp: walls in BSP order, visplanes in push
+// Spans are appended to the column's scratch list in a compact form (extent + which record they texture from) with a
+// sort key that encodes the reference's draw order (frontend.hpp: walls in BSP order, visplanes in push
 // order, then the sprite / masked-wall sequence).
 #pragma once
 #include <stddef.h>
@@ -31,8 +31,8 @@ struct FeParams {
     const uint32_t *behind;
     const uint32_t *sky_parts;    // per sky slot: index of its part within the frame
     // per-column scratch, [frame][slot][W] so that neighbouring lanes touch neighbouring addresses
-    uint32_t *keys;               // col_slots slots
-    FeU4 *sspans;                 // 2 x FeU4 per slot
+    FeU4 *cspans;                 // col_slots slots of one compact span: x = draw-order key, y = ctop | cbot << 16,
+                                  // z = top_y | bot_y << 16 (walls), w = FES_* source (resolved into a DevRSpan by dg_fe_scatter)
     FeColRec *recs;               // col_slots slots
     uint32_t *cnt;                // [frame][W] spans emitted per column
     uint64_t *events;             // [frame][FE_MAX_SKY_SLOTS][3][W64] add-floor / add-ceiling / flush bits per column
@@ -57,12 +57,13 @@ struct FeColumn {                 // what one lane carries through the walk
 DG_HD int32_t fe_min(int32_t a, int32_t b) { return a < b ? a : b; }
 DG_HD int32_t fe_max(int32_t a, int32_t b) { return a > b ? a : b; }
 
-DG_HD void fe_emit(const FeParams &P, int f, FeColumn &c, uint32_t key, const DevRSpan &r) {
+// FeU4.w of a compact span: which record its texture-mapping constants come from.
+enum : uint32_t { FES_KIND_SHIFT = 30, FES_SPRITE = 1u << 29, FES_CEIL = 1u << 28, FES_INDEX_MASK = (1u << 28) - 1 };
+
+DG_HD void fe_emit(const FeParams &P, int f, FeColumn &c, uint32_t key, int32_t ctop, int32_t cbot, int32_t top_y, int32_t bot_y, uint32_t src) {
     if (c.nsp >= P.col_slots) { c.ovf |= FE_OVF_SPANS; return; }
     const size_t i = ((size_t)f * P.col_slots + c.nsp) * (size_t)P.k.W + (size_t)c.x;
-    P.keys[i] = key;
-    P.sspans[2 * i] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
-    P.sspans[2 * i + 1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};
+    P.cspans[i] = FeU4{key, (uint32_t)ctop | ((uint32_t)cbot << 16), (uint32_t)(uint16_t)top_y | ((uint32_t)(uint16_t)bot_y << 16), src};
     c.nsp++;
 }
 
@@ -74,15 +75,30 @@ DG_HD DevSpan fe_span(int32_t ctop, int32_t cbot, int32_t top_y, int32_t bot_y, 
 }
 
 // One Visplane::add_point (visplanes.rs:28-38) as draw_visplane / draw_sky will see it (visplanes.rs:61-62,95-101).
-DG_HD void fe_plane(const FeParams &P, int f, const DevFrame &fr, FeColumn &c, uint32_t key, bool sky, const DevPlaneRec &pr, int32_t top, int32_t bottom) {
+DG_HD void fe_plane(const FeParams &P, int f, FeColumn &c, uint32_t key, bool sky, uint32_t src, int32_t top, int32_t bottom) {
     const int32_t t = fe_max(top, 0), b = fe_min(bottom, P.k.H - 1);
     if (sky) {
         if (t > b) return;
-        fe_emit(P, f, c, key, resolve_sky_span(fe_span(t, b, 0, 0, SPAN_SKY, c.x), P.scene, P.k, fr));
+        fe_emit(P, f, c, key, t, b, 0, 0, ((uint32_t)SPAN_SKY << FES_KIND_SHIFT) | src);
     } else {
         if (wrap_i16(b - t) <= 1) return;
-        fe_emit(P, f, c, key, resolve_flat_span(fe_span(t, b, 0, 0, SPAN_FLAT, c.x), pr, P.k));
+        fe_emit(P, f, c, key, t, b, 0, 0, ((uint32_t)SPAN_FLAT << FES_KIND_SHIFT) | src);
     }
+}
+
+// The compact span of column x as the raster kernel wants it (what dg_setup_spans does for host-built lists).
+DG_HD DevRSpan fe_resolve(const FeParams &P, const DevFrame &fr, const FeFrame &ff, int32_t x, const FeU4 &cs) {
+    const uint32_t kind = cs.w >> FES_KIND_SHIFT, idx = cs.w & FES_INDEX_MASK;
+    const int32_t ctop = (int32_t)(cs.y & 0xffffu), cbot = (int32_t)(cs.y >> 16);
+    if (kind == SPAN_WALL) {
+        const DevWallRec &r = (cs.w & FES_SPRITE) ? P.sprites[ff.sprite_base + idx].wall : P.parts[ff.part_base + idx].wall;
+        return resolve_wall_span(fe_span(ctop, cbot, lo_i16(cs.z), hi_i16(cs.z), SPAN_WALL, x), r);
+    }
+    if (kind == SPAN_FLAT) {
+        const FePart &p = P.parts[ff.part_base + idx];
+        return resolve_flat_span(fe_span(ctop, cbot, 0, 0, SPAN_FLAT, x), (cs.w & FES_CEIL) ? p.ceil_plane : p.floor_plane, P.k);
+    }
+    return resolve_sky_span(fe_span(ctop, cbot, 0, 0, SPAN_SKY, x), P.scene, P.k, fr);
 }
 
 DG_HD void fe_occlude(const FeParams &P, FeColumn &c) {                        // segs.rs:113-117
@@ -91,7 +107,7 @@ DG_HD void fe_occlude(const FeParams &P, FeColumn &c) {                        /
 }
 
 // Column c.x of part `pi` (sx <= x <= ex).  Returns FE_EV_* bits.
-DG_HD uint32_t fe_part_column(const FeParams &P, int f, const DevFrame &fr, const FePart &p, uint32_t pi, FeColumn &c) {
+DG_HD uint32_t fe_part_column(const FeParams &P, int f, const FePart &p, uint32_t pi, FeColumn &c) {
     const int32_t hm1 = P.k.H - 1, x = c.x;
     const uint32_t fl = p.flags;
     const bool two = (fl & FEP_TWO_SIDED_MID) != 0, only = (fl & FEP_ONLY_OCCL) != 0, lower = (fl & FEP_LOWER) != 0, upper = (fl & FEP_UPPER) != 0;
@@ -121,28 +137,28 @@ DG_HD uint32_t fe_part_column(const FeParams &P, int f, const DevFrame &fr, cons
             }
             if ((fl & FEP_HAS_BITMAP) && (two || !only)) {                     // inline draw (segs.rs:231-258) or masked replay (segs.rs:593-597)
                 const uint32_t key = two ? (FE_KEY_LATE | (p.seq << 2)) : (FE_KEY_WALL | (pi << 2));
-                fe_emit(P, f, c, key, resolve_wall_span(fe_span(ct, cb, top_y, bottom_y, SPAN_WALL, x), p.wall));
+                fe_emit(P, f, c, key, ct, cb, top_y, bottom_y, ((uint32_t)SPAN_WALL << FES_KIND_SHIFT) | pi);
             }
         }
         if (planes_here && vis) {
             bool added = false;
             if (cb < fo && cb != hm1) {
-                fe_plane(P, f, fr, c, FE_KEY_PLANE | (pi << 2), (fl & FEP_FLOOR_SKY) != 0, p.floor_plane, cb, fo);
+                fe_plane(P, f, c, FE_KEY_PLANE | (pi << 2), (fl & FEP_FLOOR_SKY) != 0, pi, cb, fo);
                 added = true; ev |= FE_EV_FADD;
             }
             if (drawc && ct > co && ct != -1) {
-                fe_plane(P, f, fr, c, FE_KEY_PLANE | (pi << 2) | 1u, (fl & FEP_CEIL_SKY) != 0, p.ceil_plane, co, ct);
+                fe_plane(P, f, c, FE_KEY_PLANE | (pi << 2) | 1u, (fl & FEP_CEIL_SKY) != 0, FES_CEIL | pi, co, ct);
                 added = true; ev |= FE_EV_CADD;
             }
             if (!added) ev |= FE_EV_FLUSH;
         } else if (planes_here && !vis && fo > co) {                           // occluded wall, open vertical gap (segs.rs:293-318)
             if (bottom_y <= co) {
-                fe_plane(P, f, fr, c, FE_KEY_PLANE | (pi << 2), (fl & FEP_FLOOR_SKY) != 0, p.floor_plane, co, fo);
+                fe_plane(P, f, c, FE_KEY_PLANE | (pi << 2), (fl & FEP_FLOOR_SKY) != 0, pi, co, fo);
                 ev |= FE_EV_FADD;
                 fe_occlude(P, c);
             }
             if (drawc && top_y >= fo) {
-                fe_plane(P, f, fr, c, FE_KEY_PLANE | (pi << 2) | 1u, (fl & FEP_CEIL_SKY) != 0, p.ceil_plane, co, fo);
+                fe_plane(P, f, c, FE_KEY_PLANE | (pi << 2) | 1u, (fl & FEP_CEIL_SKY) != 0, FES_CEIL | pi, co, fo);
                 ev |= FE_EV_CADD;
                 fe_occlude(P, c);
             }
@@ -164,7 +180,7 @@ DG_HD uint32_t fe_part_column(const FeParams &P, int f, const DevFrame &fr, cons
 
 // Column c.x of one sprite (x0 <= x < x1): clip arrays from the wall records of this column that are not behind the
 // sprite's centre, then the clipped column (map_objects.rs:130-209).
-DG_HD void fe_sprite_column(const FeParams &P, int f, const FeFrame &ff, const FeSprite &s, FeColumn &c) {
+DG_HD void fe_sprite_column(const FeParams &P, int f, const FeFrame &ff, const FeSprite &s, uint32_t si, FeColumn &c) {
     const int32_t H = P.k.H, x = c.x;
     int32_t top_clip = -1, bottom_clip = H;
     const uint32_t *row = P.behind + ff.behind_base + s.behind_off;
@@ -184,7 +200,7 @@ DG_HD void fe_sprite_column(const FeParams &P, int f, const FeFrame &ff, const F
     const int32_t ct = fe_max(0, fe_max(top_y, top_clip));
     const int32_t cb = fe_min(H - 1, fe_min(bottom_y, bottom_clip));
     if (ct > cb) return;
-    fe_emit(P, f, c, FE_KEY_LATE | (s.seq << 2), resolve_wall_span(fe_span(ct, cb, top_y, bottom_y, SPAN_WALL, x), s.wall));
+    fe_emit(P, f, c, FE_KEY_LATE | (s.seq << 2), ct, cb, top_y, bottom_y, ((uint32_t)SPAN_WALL << FES_KIND_SHIFT) | FES_SPRITE | si);
 }
 
 // Is column x a zero-filled entry of a visplane of this part: no add and no flush at x, and the nearest event on

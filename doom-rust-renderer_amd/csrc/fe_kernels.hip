@@ -3,13 +3,14 @@
 //
 //   dg_fe_columns   one lane per (frame, screen column): walks the frame's parts in BSP order with the column's three
 //                   occlusion values in registers (the reference keeps them in horizontal_ocl / floor_ver_ocl /
-//                   ceiling_ver_ocl, segs.rs:70-74), resolves every wall / visplane / sprite span on the spot and appends
-//                   it to the column's scratch list.  Records are wave-uniform: 64 lanes test 64 records' column
+//                   ceiling_ver_ocl, segs.rs:70-74) and appends every wall / visplane / sprite span, in a compact 16-byte
+//                   form, to the column's scratch list.  Records are wave-uniform: 64 lanes test 64 records' column
 //                   ranges at once, the hits are fetched with one coalesced load and broadcast with v_readlane.  HBM-bound scratch writes are laid
 //                   out [slot][column] so the 64 lanes of a wave store 64 adjacent records.
 //   dg_fe_gaps      one wave per (frame, part with a sky flat): the 1-pixel sky entries of zero-filled visplane columns.
 //   dg_fe_scan      one workgroup per frame: scans the per-column counts into col_off.
-//   dg_fe_scatter   ranks every column's spans by draw-order key and scatters them into the column-major list.
+//   dg_fe_scatter   ranks every column's spans by draw-order key, resolves their texture-mapping constants (DevRSpan) and
+//                   scatters them into the column-major list.
 //
 // Integer / f32 work only — nothing here is GEMM shaped.
 #include <hip/hip_runtime.h>
@@ -50,7 +51,6 @@ __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
     const int lane = (int)(threadIdx.x & 63);
     const int wx0 = __builtin_amdgcn_readfirstlane(x - lane), wx1 = wx0 + 63;
     if (wx0 >= W) return;                                                               // whole wave past the right edge
-    const DevFrame fr = P.frames[f];
     const FeFrame ff = P.fframes[f];
     const uint32_t n_parts = __builtin_amdgcn_readfirstlane(ff.n_parts), part_base = __builtin_amdgcn_readfirstlane(ff.part_base);
     const uint32_t n_sprites = __builtin_amdgcn_readfirstlane(ff.n_sprites), sprite_base = __builtin_amdgcn_readfirstlane(ff.sprite_base);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
             const FePart p = unpack_words<FePart>(next);
             if (hit) next = fetch_words(parts + base + (uint32_t)__builtin_ctzll(hit), lane);
             uint32_t ev = 0;
-            if (active && x >= p.sx && x <= p.ex) ev = fe_part_column(P, f, fr, p, pi, c);
+            if (active && x >= p.sx && x <= p.ex) ev = fe_part_column(P, f, p, pi, c);
             if (p.sky_slot >= 0) {                                                      // wave-uniform: all 64 lanes reach the ballots
                 const uint64_t bf = __ballot((ev & FE_EV_FADD) != 0), bc = __ballot((ev & FE_EV_CADD) != 0), bl = __ballot((ev & FE_EV_FLUSH) != 0);
                 if (lane == 0) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
             const uint32_t si = base + (uint32_t)__builtin_ctzll(hit);
             hit &= hit - 1;
             const FeSprite s = unpack_words<FeSprite>(fetch_words(sprites + si, lane));
-            if (active && x >= s.x0 && x < s.x1) fe_sprite_column(P, f, ff, s, c);
+            if (active && x >= s.x0 && x < s.x1) fe_sprite_column(P, f, ff, s, si, c);
         }
     }
     if (active) P.cnt[(size_t)f * (size_t)W + (size_t)x] = c.nsp;
@@ -110,7 +110,6 @@ __global__ __launch_bounds__(64) void dg_fe_gaps(FeParams P) {
     if (si >= ff.n_sky_slots) return;
     const int W = P.k.W;
     const int lane = (int)threadIdx.x;
-    const DevFrame fr = P.frames[f];
     const uint32_t pi = P.sky_parts[ff.sky_base + si];
     const FePart &p = P.parts[ff.part_base + pi];
     const int sx = p.sx, ex = p.ex;
@@ -123,11 +122,8 @@ __global__ __launch_bounds__(64) void dg_fe_gaps(FeParams P) {
             if (!fe_gap(add, flush, x, sx, ex)) continue;
             const uint32_t slot = atomicAdd(&cnt[x], 1u);
             if (slot >= P.col_slots) { atomicOr(&P.flags[f], (uint32_t)FE_OVF_SPANS); continue; }
-            const DevRSpan r = resolve_sky_span(fe_span(0, 0, 0, 0, SPAN_SKY, x), P.scene, P.k, fr);
-            const size_t i = ((size_t)f * P.col_slots + slot) * (size_t)W + (size_t)x;
-            P.keys[i] = FE_KEY_PLANE | (pi << 2) | (uint32_t)kind;
-            P.sspans[2 * i] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
-            P.sspans[2 * i + 1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};
+            P.cspans[((size_t)f * P.col_slots + slot) * (size_t)W + (size_t)x] =
+                FeU4{FE_KEY_PLANE | (pi << 2) | (uint32_t)kind, 0u, 0u, (uint32_t)SPAN_SKY << FES_KIND_SHIFT};
         }
     }
 }
@@ -174,7 +170,8 @@ __global__ __launch_bounds__(FE_SCAN_THREADS) void dg_fe_scan(FeParams P) {
     }
 }
 
-// Every column's spans into draw order: rank by key among the column's spans (distinct keys), scatter into the
+// Every column's spans into draw order and into the raster kernel's form: rank by key among the column's spans
+// (distinct keys), resolve the texture-mapping constants (what dg_setup_spans does for host-built lists), scatter into the
 // column-major list.  64 adjacent columns x FE_SCATTER_GROUPS slot groups per workgroup: the lanes of a wave read the
 // same slot of 64 adjacent columns (coalesced in the [slot][column] scratch layout); the keys are staged in LDS once.
 __global__ __launch_bounds__(64 * FE_SCATTER_GROUPS) void dg_fe_scatter(FeParams P) {
@@ -187,21 +184,22 @@ __global__ __launch_bounds__(64 * FE_SCATTER_GROUPS) void dg_fe_scatter(FeParams
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
     uint32_t off = 0, n = 0;
     if (x < W) { off = coff[x]; n = coff[x + 1] - off; }      // n = 0 for every column of a frame that did not fit
-    const uint32_t *keys = P.keys + (size_t)f * P.col_slots * (size_t)W + (size_t)x;
-    const FeU4 *src = P.sspans + 2 * ((size_t)f * P.col_slots * (size_t)W + (size_t)x);
-    for (uint32_t i = g; i < n; i += FE_SCATTER_GROUPS) lkeys[i * 64 + (uint32_t)lx] = keys[(size_t)i * (size_t)W];
+    const FeU4 *src = P.cspans + (size_t)f * P.col_slots * (size_t)W + (size_t)x;
+    for (uint32_t i = g; i < n; i += FE_SCATTER_GROUPS) lkeys[i * 64 + (uint32_t)lx] = src[(size_t)i * (size_t)W].x;
     __syncthreads();
-    FeU4 *out = reinterpret_cast<FeU4 *>(P.rspans + P.frames[f].span_base);
+    const DevFrame fr = P.frames[f];
+    const FeFrame ff = P.fframes[f];
+    FeU4 *out = reinterpret_cast<FeU4 *>(P.rspans + fr.span_base);
     for (uint32_t i = g; i < n; i += FE_SCATTER_GROUPS) {
-        const FeU4 a = src[2 * (size_t)i * (size_t)W], b = src[2 * (size_t)i * (size_t)W + 1];
-        const uint32_t key = lkeys[i * 64 + (uint32_t)lx];
+        const FeU4 cs = src[(size_t)i * (size_t)W];
         uint32_t rank = 0;
         for (uint32_t j = 0; j < n; j++) {
             const uint32_t kj = lkeys[j * 64 + (uint32_t)lx];
-            rank += (kj < key || (kj == key && j < i)) ? 1u : 0u;          // the tie-break keeps the scatter a permutation
+            rank += (kj < cs.x || (kj == cs.x && j < i)) ? 1u : 0u;        // the tie-break keeps the scatter a permutation
         }
-        out[2 * (size_t)(off + rank)] = a;
-        out[2 * (size_t)(off + rank) + 1] = b;
+        const DevRSpan r = fe_resolve(P, fr, ff, x, cs);
+        out[2 * (size_t)(off + rank)] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
+        out[2 * (size_t)(off + rank) + 1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};
     }
 }
 

@@ -135,14 +135,14 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
     fr.span_base = 0;
     FeFrame ff{0, (uint32_t)arena.parts.size(), 0, (uint32_t)arena.sprites.size(), 0, arena.behind_words, arena.n_sky_slots, 0};
     const uint32_t w64 = (uint32_t)((W + 63) / 64);
-    std::vector<uint32_t> keys((size_t)FE_DEFAULT_COL_SLOTS * W), cnt((size_t)W), col_off((size_t)W + 1), flags(1, 0);
-    std::vector<FeU4> sspans((size_t)2 * FE_DEFAULT_COL_SLOTS * W);
+    std::vector<uint32_t> cnt((size_t)W), col_off((size_t)W + 1), flags(1, 0);
+    std::vector<FeU4> cspans((size_t)FE_DEFAULT_COL_SLOTS * W);
     std::vector<FeColRec> recs((size_t)FE_DEFAULT_COL_SLOTS * W);
     std::vector<uint64_t> events((size_t)FE_MAX_SKY_SLOTS * 3 * w64, 0);
     std::vector<DevRSpan> rspans((size_t)W * FE_DEFAULT_COL_SLOTS);
     FeParams P;
     P.scene = ds; P.k = k; P.frames = &fr; P.fframes = &ff; P.parts = arena.parts.data(); P.sprites = arena.sprites.data();
-    P.behind = arena.behind.data(); P.bounds = nullptr; P.keys = keys.data(); P.sspans = sspans.data(); P.recs = recs.data(); P.cnt = cnt.data();
+    P.behind = arena.behind.data(); P.bounds = nullptr; P.cspans = cspans.data(); P.recs = recs.data(); P.cnt = cnt.data();
     P.events = events.data(); P.flags = flags.data(); P.totals = nullptr; P.col_off = col_off.data(); P.rspans = rspans.data();
     P.n_frames = 1; P.span_stride = (uint32_t)rspans.size(); P.w64 = w64; P.col_slots = FE_DEFAULT_COL_SLOTS;
 
@@ -153,7 +153,7 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
         for (uint32_t pi = 0; pi < ff.n_parts; pi++) {
             const FePart &p = P.parts[pi];
             if (x < p.sx || x > p.ex) continue;
-            uint32_t ev = fe_part_column(P, 0, fr, p, pi, c);
+            uint32_t ev = fe_part_column(P, 0, p, pi, c);
             if (p.sky_slot >= 0) {
                 uint64_t *e = events.data() + (size_t)p.sky_slot * 3 * w64 + (size_t)(x >> 6);
                 if (ev & FE_EV_FADD) e[0] |= 1ull << (x & 63);
@@ -163,7 +163,7 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
         }
         for (uint32_t si = 0; si < ff.n_sprites; si++) {
             const FeSprite &s = P.sprites[si];
-            if (x >= s.x0 && x < s.x1) fe_sprite_column(P, 0, ff, s, c);
+            if (x >= s.x0 && x < s.x1) fe_sprite_column(P, 0, ff, s, si, c);
         }
         cnt[(size_t)x] = c.nsp;
         flags[0] |= c.ovf;
@@ -183,11 +183,7 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
                 n_gaps++;
                 const uint32_t slot = cnt[(size_t)x]++;
                 if (slot >= FE_DEFAULT_COL_SLOTS) { flags[0] |= FE_OVF_SPANS; continue; }
-                const DevRSpan r = resolve_sky_span(fe_span(0, 0, 0, 0, SPAN_SKY, x), ds, k, fr);
-                const size_t i = (size_t)slot * W + (size_t)x;
-                keys[i] = FE_KEY_PLANE | (pi << 2) | (uint32_t)kind;
-                sspans[2 * i] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
-                sspans[2 * i + 1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};
+                cspans[(size_t)slot * W + (size_t)x] = FeU4{FE_KEY_PLANE | (pi << 2) | (uint32_t)kind, 0u, 0u, (uint32_t)SPAN_SKY << FES_KIND_SHIFT};
             }
         }
     }
@@ -196,14 +192,13 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
         const uint32_t n = std::min<uint32_t>(cnt[(size_t)x], FE_DEFAULT_COL_SLOTS);
         col_off[(size_t)x] = off;
         for (uint32_t i = 0; i < n; i++) {
-            const uint32_t key = keys[(size_t)i * W + x];
+            const FeU4 cs = cspans[(size_t)i * W + x];
             uint32_t rank = 0;
             for (uint32_t j = 0; j < n; j++) {
-                const uint32_t kj = keys[(size_t)j * W + x];
-                rank += (kj < key || (kj == key && j < i)) ? 1u : 0u;
+                const uint32_t kj = cspans[(size_t)j * W + x].x;
+                rank += (kj < cs.x || (kj == cs.x && j < i)) ? 1u : 0u;
             }
-            std::memcpy(&rspans[off + rank].w[0], &sspans[2 * ((size_t)i * W + x)], 16);
-            std::memcpy(&rspans[off + rank].w[4], &sspans[2 * ((size_t)i * W + x) + 1], 16);
+            rspans[off + rank] = fe_resolve(P, fr, ff, x, cs);
         }
         off += n;
     }
