@@ -6,9 +6,9 @@
 //   per slot: list slab  [DevFrame x F | col_off x F*(W+1) | DevWallRec.. | DevPlaneRec.. | DevSpan..]  one H2D copy
 //             rspan slab DevRSpan 32 B per span (device-only, written by dg_setup_spans, walked by dg_raster_tiles)
 //             framebuffer slab  F x 3*W*H bytes RGB24 (the reference's Pixels.pixels, one per frame)
-//             DG_FE_DEVICE: record slab [DevFrame x F | FeFrame x F | FePart.. | part column ranges.. | FeSprite.. | behind bits.. | sky slot -> part..] (one H2D copy),
+//             DG_FE_DEVICE: record slab [DevFrame x F | FeFrame x F | FePart.. | FeSprite.. | behind bits.. | sky slot -> part.. | column bins..] (one H2D copy),
 //             col_off F*(W+1) written by dg_fe_finalize, 2F status words (overflow flags, span totals)
-//   per ctx : DG_FE_DEVICE column scratch [F][slot][W]: compact spans 16 B (48 slots), wall-record columns 16 B (48 slots),
+//   per ctx : DG_FE_DEVICE column scratch [F][slot][W]: compact spans 16 B (48 slots), wall-record columns 8 B (48 slots),
 //             counts, sky event bits — shared by the slots because their kernels run back to back
 #include <hip/hip_runtime_api.h>
 #include <sched.h>
@@ -105,7 +105,7 @@ private:
 
 struct Slot {
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_raster = nullptr, ev_done = nullptr;
+    hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_raster = nullptr, ev_rstart = nullptr;
     uint8_t *h_lists = nullptr;   // pinned staging
     uint8_t *d_lists = nullptr;
     DevRSpan *d_rspans = nullptr;
@@ -131,7 +131,8 @@ struct Slot {
 struct FeFrameOut {               // parts-mode output of one frame, owned per batch index
     std::vector<FePart> parts;
     std::vector<FeSprite> sprites;
-    std::vector<uint32_t> behind, sky_parts;
+    std::vector<uint32_t> behind, sky_parts, bin_off, sbin_off;
+    std::vector<uint16_t> bin_parts, sbin_sprites;
     uint32_t behind_words = 0, n_sky_slots = 0;
     DevFrame hdr{};
 };
@@ -149,6 +150,7 @@ struct dg_ctx {
     uint8_t *d_texel_idx = nullptr, *d_texel_opq = nullptr, *d_flats = nullptr;
     DevScene dscene{};
     std::vector<Slot> slots;
+    hipEvent_t last_front = nullptr;    // end of the last column walk: the shared column scratch is free again
     hipEvent_t last_raster = nullptr;   // raster kernels of different slots run back to back; list uploads overlap them
     std::unique_ptr<Pool> pool;
     std::vector<std::unique_ptr<FrameArena>> arenas;   // one per worker (+ caller)
@@ -160,7 +162,7 @@ struct dg_ctx {
     bool fe_scene_ok = false;           // ... and the uploaded scene allows it (sky bitmap >= 256x128, see bin_frame)
     std::vector<FeFrameOut> fe_out;     // one per frame of a batch
     uint32_t fe_col_slots = FE_DEFAULT_COL_SLOTS;
-    size_t fe_part_cap = 0, fe_sprite_cap = 0, fe_behind_cap = 0, fe_slab_cap = 0;
+    size_t fe_part_cap = 0, fe_sprite_cap = 0, fe_behind_cap = 0, fe_bin_cap = 0, fe_sbin_cap = 0, fe_slab_cap = 0;
     uint32_t *d_fe_cnt = nullptr;
     FeU4 *d_fe_cspans = nullptr;
     FeColRec *d_fe_recs = nullptr;
@@ -188,7 +190,7 @@ void free_ctx(dg_ctx *c) {
         if (s.ev_start) (void)hipEventDestroy(s.ev_start);
         if (s.ev_setup) (void)hipEventDestroy(s.ev_setup);
         if (s.ev_raster) (void)hipEventDestroy(s.ev_raster);
-        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.ev_rstart) (void)hipEventDestroy(s.ev_rstart);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     if (c->d_palette) (void)hipFree(c->d_palette);
@@ -293,6 +295,7 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
         rc[(size_t)i] = build_frame_parts(sc, W, H, v, A, errs[(size_t)i]);
         if (rc[(size_t)i]) return;
         o.parts.swap(A.parts); o.sprites.swap(A.sprites); o.behind.swap(A.behind); o.sky_parts.swap(A.sky_parts);
+        o.bin_off.swap(A.bin_off); o.bin_parts.swap(A.bin_parts); o.sbin_off.swap(A.sbin_off); o.sbin_sprites.swap(A.sbin_sprites);
         o.behind_words = A.behind_words; o.n_sky_slots = A.n_sky_slots;
         o.hdr = make_frame_header(v);
     });
@@ -300,27 +303,33 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
         if (rc[(size_t)i] == kPartsUnsupported) return kPartsUnsupported;
         if (rc[(size_t)i]) return set_err(rc[(size_t)i], "frame " + std::to_string(i) + ": " + errs[(size_t)i]);
     }
-    uint64_t parts = 0, sprites = 0, behind = 0, skies = 0;
+    uint64_t parts = 0, sprites = 0, behind = 0, skies = 0, bins = 0, sbins = 0;
     uint32_t max_sky = 0;
     std::vector<FeFrame> ffs((size_t)n);
     for (int i = 0; i < n; i++) {
         const FeFrameOut &o = c->fe_out[(size_t)i];
         if (o.n_sky_slots > FE_MAX_SKY_SLOTS) return kPartsUnsupported;
         ffs[(size_t)i] = FeFrame{(uint32_t)parts, (uint32_t)o.parts.size(), (uint32_t)sprites, (uint32_t)o.sprites.size(), (uint32_t)behind,
-                                 o.behind_words, o.n_sky_slots, (uint32_t)skies};
+                                 o.behind_words, o.n_sky_slots, (uint32_t)skies, (uint32_t)bins, (uint32_t)sbins, {0u, 0u}};
         parts += o.parts.size(); sprites += o.sprites.size(); behind += o.behind.size(); skies += o.n_sky_slots;
+        bins += o.bin_parts.size(); sbins += o.sbin_sprites.size();
         max_sky = std::max(max_sky, o.n_sky_slots);
     }
-    if (parts > c->fe_part_cap || sprites > c->fe_sprite_cap || behind > c->fe_behind_cap) return kPartsUnsupported;
+    if (parts > c->fe_part_cap || sprites > c->fe_sprite_cap || behind > c->fe_behind_cap || bins > c->fe_bin_cap || sbins > c->fe_sbin_cap)
+        return kPartsUnsupported;
+    const size_t nb1 = (size_t)(W + FE_BIN_W - 1) / FE_BIN_W + 1;
     const uint32_t span_stride = (uint32_t)(c->span_cap_per_batch / (size_t)c->cfg.max_batch);
     const size_t off_frames = 0;
     const size_t off_ff = align_up(off_frames + (size_t)n * sizeof(DevFrame), 256);
     const size_t off_parts = align_up(off_ff + (size_t)n * sizeof(FeFrame), 256);
-    const size_t off_bounds = align_up(off_parts + parts * sizeof(FePart), 256);
-    const size_t off_sprites = align_up(off_bounds + parts * 4, 256);
+    const size_t off_sprites = align_up(off_parts + parts * sizeof(FePart), 256);
     const size_t off_behind = align_up(off_sprites + sprites * sizeof(FeSprite), 256);
     const size_t off_sky = align_up(off_behind + behind * 4, 256);
-    const size_t total = off_sky + skies * 4;
+    const size_t off_boff = align_up(off_sky + skies * 4, 256);
+    const size_t off_sboff = align_up(off_boff + (size_t)n * nb1 * 4, 256);
+    const size_t off_bins = align_up(off_sboff + (size_t)n * nb1 * 4, 256);
+    const size_t off_sbins = align_up(off_bins + bins * 2, 256);
+    const size_t total = off_sbins + sbins * 2;
     if (total > c->fe_slab_cap) return kPartsUnsupported;
     c->pool->parallel_for(n, [&](int i, int) {
         FeFrameOut &o = c->fe_out[(size_t)i];
@@ -329,11 +338,13 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
         std::memcpy(s.h_fe + off_frames + (size_t)i * sizeof(DevFrame), &o.hdr, sizeof(DevFrame));
         std::memcpy(s.h_fe + off_ff + (size_t)i * sizeof(FeFrame), &ff, sizeof(FeFrame));
         if (!o.parts.empty()) std::memcpy(s.h_fe + off_parts + (size_t)ff.part_base * sizeof(FePart), o.parts.data(), o.parts.size() * sizeof(FePart));
-        uint32_t *bnd = reinterpret_cast<uint32_t *>(s.h_fe + off_bounds) + ff.part_base;
-        for (size_t k = 0; k < o.parts.size(); k++) bnd[k] = (uint32_t)o.parts[k].sx | ((uint32_t)o.parts[k].ex << 16);
         if (!o.sprites.empty()) std::memcpy(s.h_fe + off_sprites + (size_t)ff.sprite_base * sizeof(FeSprite), o.sprites.data(), o.sprites.size() * sizeof(FeSprite));
         if (!o.behind.empty()) std::memcpy(s.h_fe + off_behind + (size_t)ff.behind_base * 4, o.behind.data(), o.behind.size() * 4);
         if (!o.sky_parts.empty()) std::memcpy(s.h_fe + off_sky + (size_t)ff.sky_base * 4, o.sky_parts.data(), o.sky_parts.size() * 4);
+        std::memcpy(s.h_fe + off_boff + (size_t)i * nb1 * 4, o.bin_off.data(), nb1 * 4);
+        std::memcpy(s.h_fe + off_sboff + (size_t)i * nb1 * 4, o.sbin_off.data(), nb1 * 4);
+        if (!o.bin_parts.empty()) std::memcpy(s.h_fe + off_bins + (size_t)ff.bin_base * 2, o.bin_parts.data(), o.bin_parts.size() * 2);
+        if (!o.sbin_sprites.empty()) std::memcpy(s.h_fe + off_sbins + (size_t)ff.sbin_base * 2, o.sbin_sprites.data(), o.sbin_sprites.size() * 2);
     });
     FeParams &F = s.FP;
     F.scene = c->dscene;
@@ -341,11 +352,14 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     F.frames = reinterpret_cast<const DevFrame *>(s.d_fe + off_frames);
     F.fframes = reinterpret_cast<const FeFrame *>(s.d_fe + off_ff);
     F.parts = reinterpret_cast<const FePart *>(s.d_fe + off_parts);
-    F.bounds = reinterpret_cast<const uint32_t *>(s.d_fe + off_bounds);
     F.sprites = reinterpret_cast<const FeSprite *>(s.d_fe + off_sprites);
     F.behind = reinterpret_cast<const uint32_t *>(s.d_fe + off_behind);
     F.sky_parts = reinterpret_cast<const uint32_t *>(s.d_fe + off_sky);
     F.max_sky_slots = max_sky;
+    F.bin_off = reinterpret_cast<const uint32_t *>(s.d_fe + off_boff);
+    F.sbin_off = reinterpret_cast<const uint32_t *>(s.d_fe + off_sboff);
+    F.bin_parts = reinterpret_cast<const uint16_t *>(s.d_fe + off_bins);
+    F.sbin_sprites = reinterpret_cast<const uint16_t *>(s.d_fe + off_sbins);
     F.cspans = c->d_fe_cspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt; F.events = c->d_fe_events;
     F.flags = s.d_status; F.totals = s.d_status + c->cfg.max_batch;
     F.col_off = s.d_fe_coloff; F.rspans = s.d_rspans;
@@ -377,17 +391,30 @@ int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *
 }
 
 int enqueue_kernels(dg_ctx *c, Slot &s) {
-    // The slot's H2D copy is already queued on its stream and may overlap the previous slot's kernels; the kernels
-    // themselves are chained behind the previous submission's raster kernel (they fill the chip on their own).
-    if (c->last_raster && c->last_raster != s.ev_raster) HIP_TRY(hipStreamWaitEvent(s.stream, c->last_raster, 0));
-    HIP_TRY(hipEventRecord(s.ev_start, s.stream));
+    // The slot's H2D copy is already queued on its stream and may overlap the previous slot's kernels.  Raster kernels run
+    // back to back (each fills the chip on its own).  The column walk of this submission only needs the shared column
+    // scratch, which is free once the previous submission's scatter kernel has finished, so it overlaps that submission's
+    // raster kernel (the walk is latency bound, the raster issue bound).
     if (s.fe_mode) {
+        if (c->last_front && c->last_front != s.ev_setup) HIP_TRY(hipStreamWaitEvent(s.stream, c->last_front, 0));
+        HIP_TRY(hipEventRecord(s.ev_start, s.stream));
         HIP_TRY(hipMemsetAsync(s.d_status, 0, (size_t)2 * (size_t)c->cfg.max_batch * 4, s.stream));
+        const size_t ev_kind = (size_t)s.FP.n_frames * s.FP.max_sky_slots * s.FP.w64 * 8;     // bytes of one event kind (fe_event_words)
+        if (ev_kind) {
+            HIP_TRY(hipMemsetAsync(s.FP.events, 0x00, 2 * ev_kind, s.stream));                                        // add-floor, add-ceiling
+            HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(s.FP.events) + 2 * ev_kind, 0xff, ev_kind, s.stream));   // flush
+        }
         HIP_TRY(launch_fe(s.FP, s.stream));
+        HIP_TRY(hipEventRecord(s.ev_setup, s.stream));
+        c->last_front = s.ev_setup;
+        if (c->last_raster && c->last_raster != s.ev_raster) HIP_TRY(hipStreamWaitEvent(s.stream, c->last_raster, 0));
     } else {
+        if (c->last_raster && c->last_raster != s.ev_raster) HIP_TRY(hipStreamWaitEvent(s.stream, c->last_raster, 0));
+        HIP_TRY(hipEventRecord(s.ev_start, s.stream));
         HIP_TRY(launch_setup(s.P, s.max_spans, s.stream));
+        HIP_TRY(hipEventRecord(s.ev_setup, s.stream));
     }
-    HIP_TRY(hipEventRecord(s.ev_setup, s.stream));
+    HIP_TRY(hipEventRecord(s.ev_rstart, s.stream));
     HIP_TRY(launch_raster(s.P, s.stream));
     HIP_TRY(hipEventRecord(s.ev_raster, s.stream));
     c->last_raster = s.ev_raster;
@@ -540,7 +567,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     c->fe_enabled = cfg->front_end != DG_FE_HOST;
     if (c->fe_enabled) {
         // Scratch slots per screen column (spans and wall-record columns).  A column that needs more sends its batch through
-        // the host list path; DOOMGPU_FE_COLUMN_SLOTS trades scratch HBM (32 B x slots x width x max_batch) against that.
+        // the host list path; DOOMGPU_FE_COLUMN_SLOTS trades scratch HBM (24 B x slots x width x max_batch) against that.
         if (const char *e = std::getenv("DOOMGPU_FE_COLUMN_SLOTS")) {
             const long v = std::strtol(e, nullptr, 10);
             if (v >= 1 && v <= (long)FE_MAX_COL_SLOTS) c->fe_col_slots = (uint32_t)v;
@@ -549,8 +576,11 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         c->fe_part_cap = F * 2048;         // wall records per frame on average (e1m1-like maps: 20-600)
         c->fe_sprite_cap = F * 256;
         c->fe_behind_cap = F * 256 * 32;   // one bit per (sprite, wall record)
-        c->fe_slab_cap = align_up(F * sizeof(DevFrame), 256) + align_up(F * sizeof(FeFrame), 256) + align_up(c->fe_part_cap * sizeof(FePart), 256) + align_up(c->fe_part_cap * 4, 256) +
-                         align_up(c->fe_sprite_cap * sizeof(FeSprite), 256) + align_up(c->fe_behind_cap * 4, 256) + F * FE_MAX_SKY_SLOTS * 4 + 1024;
+        c->fe_bin_cap = F * 16384;         // column-bin entries (a record is listed in every 64-column strip it touches)
+        c->fe_sbin_cap = F * 2048;
+        c->fe_slab_cap = align_up(F * sizeof(DevFrame), 256) + align_up(F * sizeof(FeFrame), 256) + align_up(c->fe_part_cap * sizeof(FePart), 256) +
+                         align_up(c->fe_sprite_cap * sizeof(FeSprite), 256) + align_up(c->fe_behind_cap * 4, 256) + align_up(F * FE_MAX_SKY_SLOTS * 4, 256) +
+                         2 * align_up(F * ((W + FE_BIN_W - 1) / FE_BIN_W + 1) * 4, 256) + align_up(c->fe_bin_cap * 2, 256) + c->fe_sbin_cap * 2 + 1024;
     }
     c->slots.resize((size_t)cfg->slots);
     hipError_t e;
@@ -567,7 +597,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         CTX_TRY(hipEventCreate(&s.ev_start));
         CTX_TRY(hipEventCreate(&s.ev_setup));
         CTX_TRY(hipEventCreate(&s.ev_raster));
-        CTX_TRY(hipEventCreate(&s.ev_done));
+        CTX_TRY(hipEventCreate(&s.ev_rstart));
         CTX_TRY(hipHostMalloc((void **)&s.h_lists, lists_cap, hipHostMallocDefault));
         CTX_TRY(hipMalloc((void **)&s.d_lists, lists_cap));
         CTX_TRY(hipMalloc((void **)&s.d_rspans, c->span_cap_per_batch * sizeof(DevRSpan)));
@@ -748,7 +778,7 @@ int dg_slot_timing(dg_ctx *c, int slot, dg_timing *out) {
     }
     std::memset(out, 0, sizeof *out);
     HIP_TRY(hipEventElapsedTime(&out->setup_ms, s.ev_start, s.ev_setup));
-    HIP_TRY(hipEventElapsedTime(&out->raster_ms, s.ev_setup, s.ev_raster));
+    HIP_TRY(hipEventElapsedTime(&out->raster_ms, s.ev_rstart, s.ev_raster));
     HIP_TRY(hipEventElapsedTime(&out->total_ms, s.ev_start, s.ev_raster));
     out->n_spans = s.n_spans; out->n_frames = (uint64_t)s.n_frames; out->covered_pixels = s.covered;
     out->host_ms = s.host_ms; out->list_bytes = s.list_bytes;

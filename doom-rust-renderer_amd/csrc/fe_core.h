@@ -26,7 +26,10 @@ struct FeParams {
     const DevFrame *frames;       // [n_frames] view constants + span_base (= f * span_stride)
     const FeFrame *fframes;       // [n_frames]
     const FePart *parts;
-    const uint32_t *bounds;       // per part: sx | ex << 16 (the column range, for the lane-parallel hit test)
+    const uint32_t *bin_off;      // [frame][n_bins + 1]  column bins of the parts (fe_dev.h)
+    const uint16_t *bin_parts;
+    const uint32_t *sbin_off;     // [frame][n_bins + 1]  column bins of the sprites
+    const uint16_t *sbin_sprites;
     const FeSprite *sprites;
     const uint32_t *behind;
     const uint32_t *sky_parts;    // per sky slot: index of its part within the frame
@@ -35,7 +38,8 @@ struct FeParams {
                                   // z = top_y | bot_y << 16 (walls), w = FES_* source (resolved into a DevRSpan by dg_fe_scatter)
     FeColRec *recs;               // col_slots slots
     uint32_t *cnt;                // [frame][W] spans emitted per column
-    uint64_t *events;             // [frame][FE_MAX_SKY_SLOTS][3][W64] add-floor / add-ceiling / flush bits per column
+    uint64_t *events;             // [3][n_frames][max_sky_slots][W64] add-floor / add-ceiling / flush bits per column; the host
+                                  // presets add = 0, flush = 1 (what a horizontally occluded column yields), see fe_event_words
     uint32_t *flags;              // [frame] FE_OVF_*
     uint32_t *totals;             // [frame] spans of the frame (written by dg_fe_finalize)
     // outputs consumed by dg_raster_tiles
@@ -43,7 +47,7 @@ struct FeParams {
     DevRSpan *rspans;
     int32_t n_frames;
     uint32_t span_stride;         // rspans reserved per frame
-    uint32_t w64;                 // (W + 63) / 64
+    uint32_t w64;                 // (W + 63) / 64 = number of column bins
     uint32_t max_sky_slots;       // max n_sky_slots over the frames of the batch (grid of dg_fe_gaps)
     uint32_t col_slots;           // span slots and wall-record slots per screen column in the scratch arrays (<= FE_MAX_COL_SLOTS)
 };
@@ -52,7 +56,15 @@ struct FeColumn {                 // what one lane carries through the walk
     int32_t x;
     int32_t hor, fo, co;          // horizontal_ocl / floor_ver_ocl / ceiling_ver_ocl of this column (segs.rs:70-74)
     uint32_t nsp, nrec, ovf;
+    size_t sp_at, rec_at;         // element index of the column's next free slot in cspans / recs (advances by W per slot)
 };
+
+DG_HD FeColumn fe_column_start(const FeParams &P, int f, int32_t x) {         // Segs::new, segs.rs:97-99
+    FeColumn c;
+    c.x = x; c.hor = 0; c.fo = P.k.H; c.co = -1; c.nsp = 0; c.nrec = 0; c.ovf = 0;
+    c.sp_at = c.rec_at = (size_t)f * P.col_slots * (size_t)P.k.W + (size_t)x;
+    return c;
+}
 
 DG_HD int32_t fe_min(int32_t a, int32_t b) { return a < b ? a : b; }
 DG_HD int32_t fe_max(int32_t a, int32_t b) { return a > b ? a : b; }
@@ -62,8 +74,8 @@ enum : uint32_t { FES_KIND_SHIFT = 30, FES_SPRITE = 1u << 29, FES_CEIL = 1u << 2
 
 DG_HD void fe_emit(const FeParams &P, int f, FeColumn &c, uint32_t key, int32_t ctop, int32_t cbot, int32_t top_y, int32_t bot_y, uint32_t src) {
     if (c.nsp >= P.col_slots) { c.ovf |= FE_OVF_SPANS; return; }
-    const size_t i = ((size_t)f * P.col_slots + c.nsp) * (size_t)P.k.W + (size_t)c.x;
-    P.cspans[i] = FeU4{key, (uint32_t)ctop | ((uint32_t)cbot << 16), (uint32_t)(uint16_t)top_y | ((uint32_t)(uint16_t)bot_y << 16), src};
+    P.cspans[c.sp_at] = FeU4{key, (uint32_t)ctop | ((uint32_t)cbot << 16), (uint32_t)(uint16_t)top_y | ((uint32_t)(uint16_t)bot_y << 16), src};
+    c.sp_at += (size_t)P.k.W;
     c.nsp++;
 }
 
@@ -128,10 +140,16 @@ DG_HD uint32_t fe_part_column(const FeParams &P, int f, const FePart &p, uint32_
                 if (c.nrec >= P.col_slots) c.ovf |= FE_OVF_RECS;
                 else {
                     FeColRec r;
-                    r.part = (uint16_t)pi;
-                    r.kind = (uint16_t)((two ? FEC_TWO_SIDED : 0) | (ext_b ? FEC_EXT_BOTTOM : 0) | (ext_t ? FEC_EXT_TOP : 0) | (drawc ? FEC_DRAW_CEILING : 0));
-                    r.ctop = (int16_t)ct; r.cbot = (int16_t)cb; r.bot_y = (int16_t)bottom_y; r.top_y = (int16_t)top_y; r.pad = 0;
-                    P.recs[((size_t)f * P.col_slots + c.nrec) * (size_t)P.k.W + (size_t)x] = r;
+                    r.part = (uint16_t)pi; r.pad = 0;
+                    if (two) {                                                 // ST_TWOSIDED branch, map_objects.rs:152-163
+                        r.top_cand = (int16_t)(drawc ? top_y : -32768);
+                        r.bottom_cand = (int16_t)bottom_y;
+                    } else {                                                   // solid: map_objects.rs:141-151
+                        r.top_cand = (int16_t)(ext_t ? cb : -32768);
+                        r.bottom_cand = (int16_t)(ext_b ? ct : 32767);
+                    }
+                    P.recs[c.rec_at] = r;
+                    c.rec_at += (size_t)P.k.W;
                     c.nrec++;
                 }
             }
@@ -184,15 +202,18 @@ DG_HD void fe_sprite_column(const FeParams &P, int f, const FeFrame &ff, const F
     const int32_t H = P.k.H, x = c.x;
     int32_t top_clip = -1, bottom_clip = H;
     const uint32_t *row = P.behind + ff.behind_base + s.behind_off;
-    for (uint32_t i = 0; i < c.nrec; i++) {
-        const FeColRec r = P.recs[((size_t)f * P.col_slots + i) * (size_t)P.k.W + (size_t)x];
-        if ((row[r.part >> 5] >> (r.part & 31)) & 1u) continue;
-        if (r.kind & FEC_TWO_SIDED) {
-            if (r.kind & FEC_DRAW_CEILING) top_clip = fe_max(top_clip, r.top_y);
-            bottom_clip = fe_min(bottom_clip, r.bot_y);
-        } else {
-            if (r.kind & FEC_EXT_BOTTOM) bottom_clip = fe_min(bottom_clip, r.ctop);
-            if (r.kind & FEC_EXT_TOP) top_clip = fe_max(top_clip, r.cbot);
+    const size_t at0 = (size_t)f * P.col_slots * (size_t)P.k.W + (size_t)x, W = (size_t)P.k.W;
+    // eight records (then their eight behind-bit words) are loaded before any is used: independent loads, two round trips
+    // per eight records instead of two per record
+    for (uint32_t i0 = 0; i0 < c.nrec; i0 += 8) {
+        FeColRec r[8];
+        uint32_t w[8];
+        for (uint32_t k = 0; k < 8; k++) r[k] = P.recs[at0 + (size_t)(i0 + k < c.nrec ? i0 + k : c.nrec - 1) * W];
+        for (uint32_t k = 0; k < 8; k++) w[k] = row[r[k].part >> 5];
+        for (uint32_t k = 0; k < 8; k++) {
+            if (i0 + k >= c.nrec || ((w[k] >> (r[k].part & 31)) & 1u)) continue;
+            top_clip = fe_max(top_clip, r[k].top_cand);
+            bottom_clip = fe_min(bottom_clip, r[k].bottom_cand);
         }
     }
     const int32_t bottom_y = f32_as_i16(s.bsy + ((float)x - s.bsx) * s.bdelta);
@@ -233,8 +254,12 @@ DG_HD bool fe_gap(const uint64_t *add, const uint64_t *flush, int32_t x, int32_t
     return true;
 }
 
-DG_HD const uint64_t *fe_event_words(const FeParams &P, int f, int32_t sky_slot, int kind) {
-    return P.events + (((size_t)f * FE_MAX_SKY_SLOTS + (size_t)sky_slot) * 3 + (size_t)kind) * (size_t)P.w64;
+// Event words of one (frame, sky slot): kind 0 = add-floor, 1 = add-ceiling, 2 = flush.  The arrays are preset to
+// "add = 0, flush = 1" — exactly what every column of a part yields once the column is horizontally occluded
+// (segs.rs:337-341) — so the walk of a column (or of a wavefront whose 64 columns are all occluded) may stop early.
+// Bits outside the part's [sx, ex] are never interpreted (fe_gap bounds every scan).
+DG_HD uint64_t *fe_event_words(const FeParams &P, int f, int32_t sky_slot, int kind) {
+    return P.events + (((size_t)kind * (size_t)P.n_frames + (size_t)f) * (size_t)P.max_sky_slots + (size_t)sky_slot) * (size_t)P.w64;
 }
 
 }  // namespace dg

@@ -57,18 +57,28 @@ struct FeFrame {
     uint32_t behind_words;        // words per sprite row = ceil(n_parts / 32)
     uint32_t n_sky_slots;
     uint32_t sky_base;            // into the batch's sky_parts array
+    uint32_t bin_base;            // into the batch's bin_parts array (entries)
+    uint32_t sbin_base;           // into the batch's sbin_sprites array
+    uint32_t pad[2];
 };
-static_assert(sizeof(FeFrame) == 32, "FeFrame layout");
+static_assert(sizeof(FeFrame) == 48, "FeFrame layout");
 
-// Per-column scratch written by the walk and read back by the same lane when it clips the sprites.
-enum : uint16_t { FEC_TWO_SIDED = 1, FEC_EXT_BOTTOM = 2, FEC_EXT_TOP = 4, FEC_DRAW_CEILING = 8 };
-struct FeColRec {                 // BitmapColumn of one wall record at this screen column (bitmap_render.rs:19-25)
+// Column bins: the frame is cut into FE_BIN_W-column strips (one wavefront of dg_fe_columns each); for every strip the
+// host lists, in BSP order, the parts whose column range touches it, and likewise the sprites.  off[] arrays are
+// [frame][n_bins + 1], relative to the frame's bin_base / sbin_base.
+constexpr int FE_BIN_W = 64;
+
+// Per-column scratch written by the walk and read back by the same lane when it clips the sprites: what one wall record
+// contributes to draw_map_objects' clip arrays at this screen column (map_objects.rs:141-163) if it is not behind the
+// sprite.  Solid records clip with their clipped extent, two-sided ones with their unclipped extent (BitmapColumn,
+// bitmap_render.rs:19-25); a side that does not clip is stored as the neutral element of max / min.
+struct FeColRec {
     uint16_t part;
-    uint16_t kind;                // FEC_* : how draw_map_objects uses it (map_objects.rs:141-163)
-    int16_t ctop, cbot, bot_y, top_y;
-    uint32_t pad;
+    uint16_t pad;
+    int16_t top_cand;             // top_clip    = max(top_clip, top_cand)
+    int16_t bottom_cand;          // bottom_clip = min(bottom_clip, bottom_cand)
 };
-static_assert(sizeof(FeColRec) == 16, "FeColRec layout");
+static_assert(sizeof(FeColRec) == 8, "FeColRec layout");
 
 enum : uint32_t { FE_EV_FADD = 1, FE_EV_CADD = 2, FE_EV_FLUSH = 4 };          // SidedefVisPlanes events of one column of one part
 enum : uint32_t { FE_OVF_SPANS = 1, FE_OVF_RECS = 2, FE_OVF_FRAME = 4 };      // per-frame overflow flags (the batch is redone on the host)

@@ -26,14 +26,8 @@ constexpr int FE_COL_THREADS = 256;
 constexpr int FE_SCAN_THREADS = 1024;
 constexpr int FE_SCATTER_GROUPS = 4;      // slot groups per screen column in dg_fe_scatter
 
-// A record is wave-uniform.  Lanes 0..N-1 fetch one dword each (one coalesced load instead of a chain of scalar-cache
-// misses: a frame's records do not fit the 16 KB scalar cache), then every field is broadcast with v_readlane.
-template <typename T>
-__device__ __forceinline__ uint32_t fetch_words(const T *rec, int lane) {
-    constexpr int N = (int)(sizeof(T) / 4);
-    static_assert(N <= 64, "record larger than a wave");
-    return reinterpret_cast<const uint32_t *>(rec)[lane < N ? lane : 0];
-}
+// A record is wave-uniform: it is staged as dwords across lanes (one coalesced load instead of a chain of scalar-cache
+// misses: a frame's records do not fit the 16 KB scalar cache) and every field is then broadcast with v_readlane.
 template <typename T>
 __device__ __forceinline__ T unpack_words(uint32_t v) {
     constexpr int N = (int)(sizeof(T) / 4);
@@ -43,60 +37,77 @@ __device__ __forceinline__ T unpack_words(uint32_t v) {
     return u.t;
 }
 
+// Walks one column bin: `n` record indices (BSP / array order) at `list`, records at `recs`.  64 indices are read with
+// one load; then up to 16 records at a time travel HBM -> registers -> LDS with eight independent loads in flight (a
+// record is at most 32 dwords: lanes 0-31 fetch an even entry, lanes 32-63 the odd one), so the ~1 us load latency is
+// paid once per 16 records instead of once per record; fn(index, record) is then called for each, in order, with the
+// record broadcast from LDS into scalar registers, until it returns false (wave-uniform).
+template <typename T, typename Fn>
+__device__ __forceinline__ void walk_bin(const uint16_t *list, uint32_t n, const T *recs, uint32_t *lrec, int lane, Fn fn) {
+    constexpr uint32_t NW = (uint32_t)(sizeof(T) / 4);
+    static_assert(NW <= 32, "record larger than half a wave");
+    for (uint32_t g64 = 0; g64 < n; g64 += 64) {
+        const uint32_t m = min(64u, n - g64);
+        const int my = (uint32_t)lane < m ? (int)list[g64 + (uint32_t)lane] : 0;
+        for (uint32_t g = 0; g < m; g += 16) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t ja = (uint32_t)__builtin_amdgcn_readlane(my, (int)min(g + 2 * k, m - 1));
+                const uint32_t jb = (uint32_t)__builtin_amdgcn_readlane(my, (int)min(g + 2 * k + 1, m - 1));
+                v[k] = reinterpret_cast<const uint32_t *>(recs + (lane < 32 ? ja : jb))[(uint32_t)(lane & 31) < NW ? (lane & 31) : 0];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) lrec[k * 64 + (uint32_t)lane] = v[k];
+            const uint32_t nh = min(16u, m - g);
+            for (uint32_t h = 0; h < nh; h++) {
+                const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane(my, (int)(g + h));
+                if (!fn(idx, unpack_words<T>(lrec[h * 32 + (uint32_t)(lane & 31)]))) return;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
+    __shared__ uint32_t lrec_all[(FE_COL_THREADS / 64) * 16 * 32];
     const int f = blockIdx.y;
     const int W = P.k.W;
     const int x = (int)(blockIdx.x * FE_COL_THREADS + threadIdx.x);
     const bool active = x < W;
     const int lane = (int)(threadIdx.x & 63);
-    const int wx0 = __builtin_amdgcn_readfirstlane(x - lane), wx1 = wx0 + 63;
+    const int wx0 = __builtin_amdgcn_readfirstlane(x - lane);
     if (wx0 >= W) return;                                                               // whole wave past the right edge
+    const uint32_t bin = (uint32_t)wx0 / FE_BIN_W;                                      // this wave's column bin
+    uint32_t *lrec = lrec_all + (threadIdx.x >> 6) * (16 * 32);                         // this wave's 16-record staging area
     const FeFrame ff = P.fframes[f];
-    const uint32_t n_parts = __builtin_amdgcn_readfirstlane(ff.n_parts), part_base = __builtin_amdgcn_readfirstlane(ff.part_base);
-    const uint32_t n_sprites = __builtin_amdgcn_readfirstlane(ff.n_sprites), sprite_base = __builtin_amdgcn_readfirstlane(ff.sprite_base);
-    const FePart *parts = P.parts + part_base;
-    const uint32_t *bounds = P.bounds + part_base;
-    const FeSprite *sprites = P.sprites + sprite_base;
+    const uint32_t *boff = P.bin_off + (size_t)f * (P.w64 + 1) + bin, *sboff = P.sbin_off + (size_t)f * (P.w64 + 1) + bin;
+    const uint32_t b0 = __builtin_amdgcn_readfirstlane(boff[0]), b1 = __builtin_amdgcn_readfirstlane(boff[1]);
+    const uint32_t s0 = __builtin_amdgcn_readfirstlane(sboff[0]), s1 = __builtin_amdgcn_readfirstlane(sboff[1]);
+    const uint32_t part_base = __builtin_amdgcn_readfirstlane(ff.part_base), sprite_base = __builtin_amdgcn_readfirstlane(ff.sprite_base);
 
-    FeColumn c;
-    c.x = x; c.hor = 0; c.fo = P.k.H; c.co = -1; c.nsp = 0; c.nrec = 0; c.ovf = 0;     // Segs::new, segs.rs:97-99
+    FeColumn c = fe_column_start(P, f, x);
 
-    // Parts in BSP order, 64 at a time: every lane tests one part's column range against the wave's 64 columns, the hits
-    // are then processed in order (lowest bit first) with the next hit's record already in flight.
-    for (uint32_t base = 0; base < n_parts; base += 64) {
-        const uint32_t b = base + (uint32_t)lane < n_parts ? bounds[base + (uint32_t)lane] : 0xffffu;   // sx = 0xffff, ex = 0: never hits
-        const int bsx = (int)(b & 0xffffu), bex = (int)(b >> 16);
-        uint64_t hit = __ballot(bex >= wx0 && bsx <= wx1);
-        uint32_t next = hit ? fetch_words(parts + base + (uint32_t)__builtin_ctzll(hit), lane) : 0u;
-        while (hit) {
-            const uint32_t pi = base + (uint32_t)__builtin_ctzll(hit);
-            hit &= hit - 1;
-            const FePart p = unpack_words<FePart>(next);
-            if (hit) next = fetch_words(parts + base + (uint32_t)__builtin_ctzll(hit), lane);
-            uint32_t ev = 0;
-            if (active && x >= p.sx && x <= p.ex) ev = fe_part_column(P, f, p, pi, c);
-            if (p.sky_slot >= 0) {                                                      // wave-uniform: all 64 lanes reach the ballots
-                const uint64_t bf = __ballot((ev & FE_EV_FADD) != 0), bc = __ballot((ev & FE_EV_CADD) != 0), bl = __ballot((ev & FE_EV_FLUSH) != 0);
-                if (lane == 0) {
-                    uint64_t *e = P.events + ((size_t)f * FE_MAX_SKY_SLOTS + (size_t)p.sky_slot) * 3 * (size_t)P.w64 + (size_t)(wx0 >> 6);
-                    e[0] = bf;
-                    e[P.w64] = bc;
-                    e[2 * (size_t)P.w64] = bl;
-                }
+    // parts in BSP order: the ones whose column range touches this wave's 64 columns (listed by the host)
+    walk_bin(P.bin_parts + ff.bin_base + b0, b1 - b0, P.parts + part_base, lrec, lane, [&](uint32_t pi, const FePart &p) {
+        uint32_t ev = 0;
+        if (active && x >= p.sx && x <= p.ex) ev = fe_part_column(P, f, p, pi, c);
+        if (p.sky_slot >= 0) {                                                          // wave-uniform: all 64 lanes reach the ballots
+            const uint64_t bf = __ballot((ev & FE_EV_FADD) != 0), bc = __ballot((ev & FE_EV_CADD) != 0), bl = __ballot((ev & FE_EV_FLUSH) != 0);
+            if (lane == 0) {
+                fe_event_words(P, f, p.sky_slot, 0)[bin] = bf;
+                fe_event_words(P, f, p.sky_slot, 1)[bin] = bc;
+                fe_event_words(P, f, p.sky_slot, 2)[bin] = bl;
             }
         }
-    }
-    for (uint32_t base = 0; base < n_sprites; base += 64) {
-        int sx0 = 1, sx1 = 0;
-        if (base + (uint32_t)lane < n_sprites) { sx0 = sprites[base + (uint32_t)lane].x0; sx1 = sprites[base + (uint32_t)lane].x1; }
-        uint64_t hit = __ballot(sx1 > wx0 && sx0 <= wx1 && sx0 < sx1);
-        while (hit) {
-            const uint32_t si = base + (uint32_t)__builtin_ctzll(hit);
-            hit &= hit - 1;
-            const FeSprite s = unpack_words<FeSprite>(fetch_words(sprites + si, lane));
-            if (active && x >= s.x0 && x < s.x1) fe_sprite_column(P, f, ff, s, si, c);
-        }
-    }
+        // Once every column of the wave is horizontally occluded nothing behind can draw, clip or add a visplane entry
+        // (segs.rs:211,337-341): the rest of the bin only yields flush events, which is what the event words are preset to.
+        return __ballot(active && !c.hor) != 0;
+    });
+    // then the sprites (their clip arrays need the finished wall-record columns of this screen column)
+    walk_bin(P.sbin_sprites + ff.sbin_base + s0, s1 - s0, P.sprites + sprite_base, lrec, lane, [&](uint32_t si, const FeSprite &s) {
+        if (active && x >= s.x0 && x < s.x1) fe_sprite_column(P, f, ff, s, si, c);
+        return true;
+    });
     if (active) P.cnt[(size_t)f * (size_t)W + (size_t)x] = c.nsp;
     if (c.ovf) atomicOr(&P.flags[f], c.ovf);
 }

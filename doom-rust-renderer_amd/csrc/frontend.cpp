@@ -657,6 +657,28 @@ int build_frame_lists(const Scene &sc, int W, int H, const dg_view &view, FrameA
     return DG_OK;
 }
 
+namespace {
+// Counting sort of records into FE_BIN_W-column strips, keeping their order (lo/hi: first / last column, inclusive).
+template <typename T, typename Range>
+void bin_by_columns(const std::vector<T> &recs, int W, Range range, std::vector<uint32_t> &off, std::vector<uint16_t> &idx) {
+    const int nb = (W + FE_BIN_W - 1) / FE_BIN_W;
+    off.assign((size_t)nb + 1, 0u);
+    for (const T &r : recs) {
+        int lo, hi;
+        if (!range(r, lo, hi)) continue;
+        for (int b = lo / FE_BIN_W; b <= hi / FE_BIN_W; b++) off[(size_t)b + 1]++;
+    }
+    for (int b = 0; b < nb; b++) off[(size_t)b + 1] += off[(size_t)b];
+    idx.resize(off[(size_t)nb]);
+    std::vector<uint32_t> cur(off.begin(), off.end() - 1);
+    for (size_t i = 0; i < recs.size(); i++) {
+        int lo, hi;
+        if (!range(recs[i], lo, hi)) continue;
+        for (int b = lo / FE_BIN_W; b <= hi / FE_BIN_W; b++) idx[cur[(size_t)b]++] = (uint16_t)i;
+    }
+}
+}  // namespace
+
 int build_frame_parts(const Scene &sc, int W, int H, const dg_view &view, FrameArena &A, std::string &err) {
     if (W <= 0 || H <= 0 || W > 16384 || H > 16384) { err = "bad frame size"; return DG_ERR_INVALID; }
     A.parts.clear(); A.sprites.clear(); A.behind.clear(); A.sky_parts.clear(); A.behind_words = 0; A.n_sky_slots = 0;
@@ -666,7 +688,11 @@ int build_frame_parts(const Scene &sc, int W, int H, const dg_view &view, FrameA
     wk.walk_bsp();
     if (wk.status) return wk.status;
     wk.map_objects();
-    return wk.status;
+    if (wk.status) return wk.status;
+    if (A.sprites.size() > 65535) { err = "more than 65535 sprites in a frame"; return kPartsUnsupported; }
+    bin_by_columns(A.parts, W, [](const FePart &p, int &lo, int &hi) { lo = p.sx; hi = p.ex; return true; }, A.bin_off, A.bin_parts);
+    bin_by_columns(A.sprites, W, [](const FeSprite &s, int &lo, int &hi) { lo = s.x0; hi = s.x1 - 1; return s.x0 < s.x1; }, A.sbin_off, A.sbin_sprites);
+    return DG_OK;
 }
 
 }  // namespace dg

@@ -35,6 +35,8 @@ struct FrameArena {
     std::vector<FePart> parts;
     std::vector<FeSprite> sprites;
     std::vector<uint32_t> sky_parts;    // per sky slot: index of the part
+    std::vector<uint32_t> bin_off, sbin_off;         // column bins (fe_dev.h): n_bins + 1 offsets each
+    std::vector<uint16_t> bin_parts, sbin_sprites;
     std::vector<uint32_t> behind;       // n_sprites rows of behind_words bits: wall record p is behind sprite s
     uint32_t behind_words = 0, n_sky_slots = 0;
     // scratch

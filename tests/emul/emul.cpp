@@ -133,35 +133,42 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
 
     DevFrame fr = bf.hdr;            // view constants (same helper as the product: bin_frame fills them)
     fr.span_base = 0;
-    FeFrame ff{0, (uint32_t)arena.parts.size(), 0, (uint32_t)arena.sprites.size(), 0, arena.behind_words, arena.n_sky_slots, 0};
+    FeFrame ff{0, (uint32_t)arena.parts.size(), 0, (uint32_t)arena.sprites.size(), 0, arena.behind_words, arena.n_sky_slots, 0, 0, 0, {0, 0}};
     const uint32_t w64 = (uint32_t)((W + 63) / 64);
     std::vector<uint32_t> cnt((size_t)W), col_off((size_t)W + 1), flags(1, 0);
     std::vector<FeU4> cspans((size_t)FE_DEFAULT_COL_SLOTS * W);
     std::vector<FeColRec> recs((size_t)FE_DEFAULT_COL_SLOTS * W);
-    std::vector<uint64_t> events((size_t)FE_MAX_SKY_SLOTS * 3 * w64, 0);
+    const size_t ev_kind = (size_t)arena.n_sky_slots * w64;               // preset like the product: add = 0, flush = 1
+    std::vector<uint64_t> events(3 * ev_kind + 1, 0);
+    std::fill(events.begin() + 2 * (ptrdiff_t)ev_kind, events.end(), ~0ull);
     std::vector<DevRSpan> rspans((size_t)W * FE_DEFAULT_COL_SLOTS);
     FeParams P;
     P.scene = ds; P.k = k; P.frames = &fr; P.fframes = &ff; P.parts = arena.parts.data(); P.sprites = arena.sprites.data();
-    P.behind = arena.behind.data(); P.bounds = nullptr; P.cspans = cspans.data(); P.recs = recs.data(); P.cnt = cnt.data();
+    P.behind = arena.behind.data(); P.bin_off = arena.bin_off.data(); P.bin_parts = arena.bin_parts.data();
+    P.sbin_off = arena.sbin_off.data(); P.sbin_sprites = arena.sbin_sprites.data(); P.cspans = cspans.data(); P.recs = recs.data(); P.cnt = cnt.data();
     P.events = events.data(); P.flags = flags.data(); P.totals = nullptr; P.col_off = col_off.data(); P.rspans = rspans.data();
-    P.n_frames = 1; P.span_stride = (uint32_t)rspans.size(); P.w64 = w64; P.col_slots = FE_DEFAULT_COL_SLOTS;
+    P.n_frames = 1; P.max_sky_slots = arena.n_sky_slots; P.span_stride = (uint32_t)rspans.size(); P.w64 = w64; P.col_slots = FE_DEFAULT_COL_SLOTS;
 
     // dg_fe_columns, one "lane" at a time
     for (int x = 0; x < W; x++) {
-        FeColumn c;
-        c.x = x; c.hor = 0; c.fo = H; c.co = -1; c.nsp = 0; c.nrec = 0; c.ovf = 0;
-        for (uint32_t pi = 0; pi < ff.n_parts; pi++) {
+        FeColumn c = fe_column_start(P, 0, x);
+        const uint32_t bin = (uint32_t)x / FE_BIN_W;                       // the wave that owns this column walks its bin's lists
+        for (uint32_t bi = arena.bin_off[bin]; bi < arena.bin_off[bin + 1]; bi++) {
+            const uint32_t pi = arena.bin_parts[bi];
             const FePart &p = P.parts[pi];
             if (x < p.sx || x > p.ex) continue;
             uint32_t ev = fe_part_column(P, 0, p, pi, c);
             if (p.sky_slot >= 0) {
-                uint64_t *e = events.data() + (size_t)p.sky_slot * 3 * w64 + (size_t)(x >> 6);
-                if (ev & FE_EV_FADD) e[0] |= 1ull << (x & 63);
-                if (ev & FE_EV_CADD) e[w64] |= 1ull << (x & 63);
-                if (ev & FE_EV_FLUSH) e[2 * (size_t)w64] |= 1ull << (x & 63);
+                const uint64_t bit = 1ull << (x & 63);
+                for (int kind = 0; kind < 3; kind++) {
+                    uint64_t &w = fe_event_words(P, 0, p.sky_slot, kind)[x >> 6];
+                    w = (ev & (1u << kind)) ? (w | bit) : (w & ~bit);
+                }
             }
+            if (c.hor) break;      // the rest of the bin only yields flush events = the preset (dg_fe_columns stops per wave)
         }
-        for (uint32_t si = 0; si < ff.n_sprites; si++) {
+        for (uint32_t bi = arena.sbin_off[bin]; bi < arena.sbin_off[bin + 1]; bi++) {
+            const uint32_t si = arena.sbin_sprites[bi];
             const FeSprite &s = P.sprites[si];
             if (x >= s.x0 && x < s.x1) fe_sprite_column(P, 0, ff, s, si, c);
         }

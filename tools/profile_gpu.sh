@@ -1,10 +1,12 @@
 #!/bin/bash
 # Profiling recipe for the GPU box (run through gpurun from the repo root).  Writes under gpurun_out/prof_<tag>/.
 # Counter passes are separate runs with --pmc only (no trace domains), as the MI355X guide prescribes.
+# Usage: tools/profile_gpu.sh <tag> [extra bench.py flags, e.g. --front-end host]
 set -o pipefail
 TAG=${1:-r01}
+shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-BENCH="python3 bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-e2e"
+BENCH="python3 bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-e2e $*"
 export TMPDIR=/tmp
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 && echo trace ok

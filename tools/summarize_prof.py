@@ -10,7 +10,7 @@ out.append("## PMC passes (separate runs, mean per dispatch)\n```\n")
 for f in sorted(glob.glob(base + "/pmc_*/*/*_counter_collection.csv")):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         if "rocclr" in k:
             continue
