@@ -23,7 +23,7 @@ namespace dg {
 namespace {
 
 constexpr int FE_COL_THREADS = 256;
-constexpr int FE_SCAN_THREADS = 1024;
+constexpr int FE_SCAN_THREADS = 256;       // small workgroups find a free CU slot while the previous raster kernel is still running
 constexpr int FE_SCATTER_GROUPS = 4;      // slot groups per screen column in dg_fe_scatter
 
 // A record is wave-uniform: it is staged as dwords across lanes (one coalesced load instead of a chain of scalar-cache

@@ -3,11 +3,18 @@
 import collections, csv, glob, sys
 base, title = sys.argv[1], sys.argv[2]
 out = [f"# rocprofv3 summary — {title}\n\n"]
-ks = glob.glob(base + "/trace/*/*_kernel_stats.csv")
+import os as _os
+ks = sorted(glob.glob(base + "/trace/*/*_kernel_stats.csv"), key=_os.path.getmtime)
 if ks:
-    out.append("## --kernel-trace --stats (kernel_stats.csv)\n```\n" + open(ks[0]).read() + "```\n")
+    out.append("## --kernel-trace --stats (kernel_stats.csv)\n```\n" + open(ks[-1]).read() + "```\n")
 out.append("## PMC passes (separate runs, mean per dispatch)\n```\n")
-for f in sorted(glob.glob(base + "/pmc_*/*/*_counter_collection.csv")):
+import os
+latest = {}
+for f in glob.glob(base + "/pmc_*/*/*_counter_collection.csv"):
+    d = f.split("/pmc_")[1].split("/")[0]
+    if d not in latest or os.path.getmtime(f) > os.path.getmtime(latest[d]):
+        latest[d] = f
+for f in [latest[d] for d in sorted(latest)]:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
