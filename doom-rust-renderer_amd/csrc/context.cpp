@@ -121,7 +121,8 @@ struct Slot {
     // device column walk (DG_FE_DEVICE)
     uint8_t *h_fe = nullptr, *d_fe = nullptr;   // record slab: pinned staging / HBM
     uint32_t *d_fe_coloff = nullptr;
-    uint32_t *d_status = nullptr, *h_status = nullptr;   // [F] overflow flags, [F] spans per frame
+    uint32_t *d_status = nullptr, *h_status = nullptr;   // [F] overflow flags, [F] spans per frame; on the device followed by the
+                                                         // sky event bits (fe_event_words) so that one fill clears both
     FeParams FP{};
     bool fe_mode = false;         // the last submission went through the device column walk
     bool fe_check = false;        // ... and its overflow flags have not been looked at yet
@@ -166,7 +167,6 @@ struct dg_ctx {
     uint32_t *d_fe_cnt = nullptr;
     FeU4 *d_fe_cspans = nullptr;
     FeColRec *d_fe_recs = nullptr;
-    uint64_t *d_fe_events = nullptr;
 };
 
 namespace {
@@ -200,7 +200,6 @@ void free_ctx(dg_ctx *c) {
     if (c->d_fe_cnt) (void)hipFree(c->d_fe_cnt);
     if (c->d_fe_cspans) (void)hipFree(c->d_fe_cspans);
     if (c->d_fe_recs) (void)hipFree(c->d_fe_recs);
-    if (c->d_fe_events) (void)hipFree(c->d_fe_events);
     delete c;
 }
 
@@ -360,7 +359,8 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     F.sbin_off = reinterpret_cast<const uint32_t *>(s.d_fe + off_sboff);
     F.bin_parts = reinterpret_cast<const uint16_t *>(s.d_fe + off_bins);
     F.sbin_sprites = reinterpret_cast<const uint16_t *>(s.d_fe + off_sbins);
-    F.cspans = c->d_fe_cspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt; F.events = c->d_fe_events;
+    F.cspans = c->d_fe_cspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt;
+    F.events = reinterpret_cast<uint64_t *>(s.d_status + 2 * (size_t)c->cfg.max_batch);
     F.flags = s.d_status; F.totals = s.d_status + c->cfg.max_batch;
     F.col_off = s.d_fe_coloff; F.rspans = s.d_rspans;
     F.n_frames = n; F.span_stride = span_stride; F.w64 = (uint32_t)((W + 63) / 64); F.col_slots = c->fe_col_slots;
@@ -398,12 +398,8 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
     if (s.fe_mode) {
         if (c->last_front && c->last_front != s.ev_setup) HIP_TRY(hipStreamWaitEvent(s.stream, c->last_front, 0));
         HIP_TRY(hipEventRecord(s.ev_start, s.stream));
-        HIP_TRY(hipMemsetAsync(s.d_status, 0, (size_t)2 * (size_t)c->cfg.max_batch * 4, s.stream));
-        const size_t ev_kind = (size_t)s.FP.n_frames * s.FP.max_sky_slots * s.FP.w64 * 8;     // bytes of one event kind (fe_event_words)
-        if (ev_kind) {
-            HIP_TRY(hipMemsetAsync(s.FP.events, 0x00, 2 * ev_kind, s.stream));                                        // add-floor, add-ceiling
-            HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(s.FP.events) + 2 * ev_kind, 0xff, ev_kind, s.stream));   // flush
-        }
+        const size_t ev_bytes = (size_t)3 * (size_t)s.FP.n_frames * s.FP.max_sky_slots * s.FP.w64 * 8;   // all three event kinds (fe_event_words)
+        HIP_TRY(hipMemsetAsync(s.d_status, 0, (size_t)2 * (size_t)c->cfg.max_batch * 4 + ev_bytes, s.stream));
         HIP_TRY(launch_fe(s.FP, s.stream));
         HIP_TRY(hipEventRecord(s.ev_setup, s.stream));
         c->last_front = s.ev_setup;
@@ -586,11 +582,9 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     hipError_t e;
 #define CTX_TRY(expr) if ((e = (expr)) != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(e); free_ctx(c); return set_err(DG_ERR_HIP, m); }
     if (c->fe_enabled) {
-        const size_t w64 = (W + 63) / 64;
         CTX_TRY(hipMalloc((void **)&c->d_fe_cspans, F * c->fe_col_slots * W * sizeof(FeU4)));
         CTX_TRY(hipMalloc((void **)&c->d_fe_recs, F * c->fe_col_slots * W * sizeof(FeColRec)));
         CTX_TRY(hipMalloc((void **)&c->d_fe_cnt, F * W * 4));
-        CTX_TRY(hipMalloc((void **)&c->d_fe_events, F * FE_MAX_SKY_SLOTS * 3 * w64 * 8));
     }
     for (Slot &s : c->slots) {
         CTX_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
@@ -606,7 +600,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
             CTX_TRY(hipHostMalloc((void **)&s.h_fe, c->fe_slab_cap, hipHostMallocDefault));
             CTX_TRY(hipMalloc((void **)&s.d_fe, c->fe_slab_cap));
             CTX_TRY(hipMalloc((void **)&s.d_fe_coloff, F * (W + 1) * 4));
-            CTX_TRY(hipMalloc((void **)&s.d_status, 2 * F * 4));
+            CTX_TRY(hipMalloc((void **)&s.d_status, 2 * F * 4 + F * FE_MAX_SKY_SLOTS * 3 * ((W + 63) / 64) * 8));
             CTX_TRY(hipHostMalloc((void **)&s.h_status, 2 * F * 4, hipHostMallocDefault));
         }
         s.lists_cap = lists_cap;

@@ -38,8 +38,8 @@ struct FeParams {
                                   // z = top_y | bot_y << 16 (walls), w = FES_* source (resolved into a DevRSpan by dg_fe_scatter)
     FeColRec *recs;               // col_slots slots
     uint32_t *cnt;                // [frame][W] spans emitted per column
-    uint64_t *events;             // [3][n_frames][max_sky_slots][W64] add-floor / add-ceiling / flush bits per column; the host
-                                  // presets add = 0, flush = 1 (what a horizontally occluded column yields), see fe_event_words
+    uint64_t *events;             // [3][n_frames][max_sky_slots][W64] add-floor / add-ceiling / not-flushed bits per column,
+                                  // zeroed by the host (= what a horizontally occluded column yields), see fe_event_words
     uint32_t *flags;              // [frame] FE_OVF_*
     uint32_t *totals;             // [frame] spans of the frame (written by dg_fe_finalize)
     // outputs consumed by dg_raster_tiles
@@ -225,28 +225,29 @@ DG_HD void fe_sprite_column(const FeParams &P, int f, const FeFrame &ff, const F
 }
 
 // Is column x a zero-filled entry of a visplane of this part: no add and no flush at x, and the nearest event on
-// either side inside [sx, ex] is an add (the visplane was opened before x and extended after it).
-DG_HD bool fe_gap(const uint64_t *add, const uint64_t *flush, int32_t x, int32_t sx, int32_t ex) {
+// either side inside [sx, ex] is an add (the visplane was opened before x and extended after it).  `open` holds the
+// complement of the flush bits (1 = the column was walked and did not flush).
+DG_HD bool fe_gap(const uint64_t *add, const uint64_t *open, int32_t x, int32_t sx, int32_t ex) {
     const int32_t w0 = x >> 6, b0 = x & 63;
-    if (((add[w0] | flush[w0]) >> b0) & 1ull) return false;
+    if (((add[w0] | ~open[w0]) >> b0) & 1ull) return false;
     {   // nearest event to the left
         int32_t w = w0;
-        uint64_t m = (add[w] | flush[w]) & ((1ull << b0) - 1ull);
+        uint64_t m = (add[w] | ~open[w]) & ((1ull << b0) - 1ull);
         while (!m) {
             if (w * 64 <= sx) return false;
             w--;
-            m = add[w] | flush[w];
+            m = add[w] | ~open[w];
         }
         const int32_t b = 63 - __builtin_clzll(m);
         if (w * 64 + b < sx || !((add[w] >> b) & 1ull)) return false;
     }
     {   // nearest event to the right
         int32_t w = w0;
-        uint64_t m = (add[w] | flush[w]) & (b0 == 63 ? 0ull : ~0ull << (b0 + 1));
+        uint64_t m = (add[w] | ~open[w]) & (b0 == 63 ? 0ull : ~0ull << (b0 + 1));
         while (!m) {
             if (w * 64 + 63 >= ex) return false;
             w++;
-            m = add[w] | flush[w];
+            m = add[w] | ~open[w];
         }
         const int32_t b = __builtin_ctzll(m);
         if (w * 64 + b > ex || !((add[w] >> b) & 1ull)) return false;
@@ -254,9 +255,9 @@ DG_HD bool fe_gap(const uint64_t *add, const uint64_t *flush, int32_t x, int32_t
     return true;
 }
 
-// Event words of one (frame, sky slot): kind 0 = add-floor, 1 = add-ceiling, 2 = flush.  The arrays are preset to
-// "add = 0, flush = 1" — exactly what every column of a part yields once the column is horizontally occluded
-// (segs.rs:337-341) — so the walk of a column (or of a wavefront whose 64 columns are all occluded) may stop early.
+// Event words of one (frame, sky slot): kind 0 = add-floor, 1 = add-ceiling, 2 = not flushed.  The arrays are zeroed
+// before the walk: "no add, flushed" is exactly what every column of a part yields once the column is horizontally
+// occluded (segs.rs:337-341), so the walk of a column (or of a wavefront whose 64 columns are all occluded) may stop early.
 // Bits outside the part's [sx, ex] are never interpreted (fe_gap bounds every scan).
 DG_HD uint64_t *fe_event_words(const FeParams &P, int f, int32_t sky_slot, int kind) {
     return P.events + (((size_t)kind * (size_t)P.n_frames + (size_t)f) * (size_t)P.max_sky_slots + (size_t)sky_slot) * (size_t)P.w64;

@@ -138,9 +138,8 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
     std::vector<uint32_t> cnt((size_t)W), col_off((size_t)W + 1), flags(1, 0);
     std::vector<FeU4> cspans((size_t)FE_DEFAULT_COL_SLOTS * W);
     std::vector<FeColRec> recs((size_t)FE_DEFAULT_COL_SLOTS * W);
-    const size_t ev_kind = (size_t)arena.n_sky_slots * w64;               // preset like the product: add = 0, flush = 1
+    const size_t ev_kind = (size_t)arena.n_sky_slots * w64;               // zeroed like the product: no add, flushed
     std::vector<uint64_t> events(3 * ev_kind + 1, 0);
-    std::fill(events.begin() + 2 * (ptrdiff_t)ev_kind, events.end(), ~0ull);
     std::vector<DevRSpan> rspans((size_t)W * FE_DEFAULT_COL_SLOTS);
     FeParams P;
     P.scene = ds; P.k = k; P.frames = &fr; P.fframes = &ff; P.parts = arena.parts.data(); P.sprites = arena.sprites.data();
@@ -160,9 +159,10 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
             uint32_t ev = fe_part_column(P, 0, p, pi, c);
             if (p.sky_slot >= 0) {
                 const uint64_t bit = 1ull << (x & 63);
-                for (int kind = 0; kind < 3; kind++) {
+                for (int kind = 0; kind < 3; kind++) {                 // kind 2 stores "walked and not flushed"
                     uint64_t &w = fe_event_words(P, 0, p.sky_slot, kind)[x >> 6];
-                    w = (ev & (1u << kind)) ? (w | bit) : (w & ~bit);
+                    const bool on = kind < 2 ? (ev & (1u << kind)) != 0 : !(ev & FE_EV_FLUSH);
+                    w = on ? (w | bit) : (w & ~bit);
                 }
             }
             if (c.hor) break;      // the rest of the bin only yields flush events = the preset (dg_fe_columns stops per wave)
@@ -184,9 +184,9 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
         if (p.sky_slot != (int32_t)si) { g_err = "sky slot table does not point back at its part"; return DG_ERR_INVALID; }
         for (int kind = 0; kind < 2; kind++) {
             if (!(p.flags & (kind ? FEP_CEIL_SKY : FEP_FLOOR_SKY))) continue;
-            const uint64_t *add = fe_event_words(P, 0, p.sky_slot, kind), *flush = fe_event_words(P, 0, p.sky_slot, 2);
+            const uint64_t *add = fe_event_words(P, 0, p.sky_slot, kind), *open = fe_event_words(P, 0, p.sky_slot, 2);
             for (int x = p.sx; x <= p.ex; x++) {
-                if (!fe_gap(add, flush, x, p.sx, p.ex)) continue;
+                if (!fe_gap(add, open, x, p.sx, p.ex)) continue;
                 n_gaps++;
                 const uint32_t slot = cnt[(size_t)x]++;
                 if (slot >= FE_DEFAULT_COL_SLOTS) { flags[0] |= FE_OVF_SPANS; continue; }
