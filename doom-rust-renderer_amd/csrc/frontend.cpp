@@ -161,6 +161,28 @@ struct PlaneBuilder {          // one open visplane of SidedefVisPlanes (sidedef
     uint32_t first = 0;        // entry index in its pool
 };
 
+// Union of closed column intervals, kept sorted and merged (adjacent intervals fuse): Doom's "solidsegs", here only a
+// conservative summary of horizontal_ocl used to drop records that cannot matter.
+struct ColumnIntervals {
+    std::vector<std::pair<int, int>> iv;
+    void clear() { iv.clear(); }
+    bool covers(int lo, int hi) const {
+        for (const auto &r : iv) {
+            if (r.first > lo) return false;
+            if (r.second >= lo) return r.second >= hi;
+        }
+        return false;
+    }
+    void add(int lo, int hi) {
+        size_t i = 0;
+        while (i < iv.size() && iv[i].second + 1 < lo) i++;
+        size_t j = i;
+        while (j < iv.size() && iv[j].first <= hi + 1) { lo = std::min(lo, iv[j].first); hi = std::max(hi, iv[j].second); j++; }
+        iv.erase(iv.begin() + (ptrdiff_t)i, iv.begin() + (ptrdiff_t)j);
+        iv.insert(iv.begin() + (ptrdiff_t)i, std::make_pair(lo, hi));
+    }
+};
+
 struct Walker {
     const Scene &sc;
     const FrameConsts k;
@@ -172,6 +194,7 @@ struct Walker {
     float player_height;
     int status = DG_OK;
     bool parts_mode = false;      // record FePart / FeSprite instead of walking columns
+    ColumnIntervals solid_cols;   // parts mode: columns spanned by full-height solid parts so far
     uint32_t n_floor_planes_marker = 0;
     // visplanes carry a pool tag in the top bit of first_entry until finalisation
     static constexpr uint32_t kCeilPool = 0x80000000u;
@@ -284,6 +307,12 @@ struct Walker {
 
         const bool planes_here = !f.two_sided_mid && (full_height || f.only_occlusions);
         if (parts_mode) {
+            // Columns that an earlier full-height solid part spans are horizontally occluded whatever that part's own
+            // visibility was (segs.rs:341-344 runs for every column of the part).  A part lying entirely inside them can
+            // neither draw, clip, add a visplane entry nor occlude anything new (segs.rs:211,337-341): it is not shipped.
+            const bool opaque_full = !f.two_sided_mid && full_height;
+            if (solid_cols.covers(bot.sx, bot.ex)) return;
+            if (opaque_full) solid_cols.add(bot.sx, bot.ex);
             if (tex >= 0) {
                 const BitmapInfo &bi = sc.bitmaps[(size_t)tex];
                 if (bi.w <= 0 || bi.h <= 0) { fail_parts("zero-sized bitmap"); return; }
@@ -433,12 +462,39 @@ struct Walker {
     }
 
     // Renderer::render_node, mod.rs:69-104 — iterative, front child first, no culling (the reference has none)
+    // Parts mode only.  Can any seg inside the box (map coordinates) still matter?  No if the box lies behind the viewer or
+    // outside the 90-degree frustum (clip_to_viewport rejects every seg in it), or if the screen columns it can project to
+    // are all spanned by earlier full-height solid parts (every part of every seg in it would be dropped by
+    // solid_cols.covers).  The column range is widened by two columns against f32 rounding of the per-seg projection;
+    // boxes that straddle the viewer's depth-zero plane are always walked.
+    bool box_matters(const float *bb) const {
+        if (bb[0] > bb[2]) return false;                             // no segs below this child
+        float tmin = 3.0e38f, tmax = -3.0e38f, xmin = 3.0e38f, xmax = -3.0e38f;
+        for (int c = 0; c < 4; c++) {
+            V2 v = rot(sub(V2{bb[(c & 1) ? 2 : 0], bb[(c & 2) ? 3 : 1]}, ppos), view.cos_na, view.sin_na);
+            xmin = std::fmin(xmin, v.x); xmax = std::fmax(xmax, v.x);
+            if (v.x > 0.0f) { float t = v.y / v.x; tmin = std::fmin(tmin, t); tmax = std::fmax(tmax, t); }
+        }
+        if (xmax < -1.0f) return false;                              // wholly behind the viewer
+        if (xmin < 1.0f) return true;                                // around or next to the viewer: walk it
+        if (tmin > 1.001f || tmax < -1.001f) return false;           // wholly outside the frustum (|y| <= x)
+        const float K = k.ARC * k.GCFX;                              // sx = CFX - K * (y / x), misc.rs:147-158
+        float lo = k.CFX - K * std::fmin(tmax, 1.0f), hi = k.CFX - K * std::fmax(tmin, -1.0f);
+        int ilo = std::max(0, (int)std::floor(lo) - 2), ihi = std::min(k.W - 1, (int)std::floor(hi) + 2);
+        return !solid_cols.covers(ilo, ihi);
+    }
+
     void walk_bsp() {
         int16_t stack[256];
+        const float *box[256];
         int sp = 0;
-        stack[sp++] = (int16_t)(sc.nodes.size() - 1);
+        const bool cull = parts_mode && !sc.may_panic;               // a seg whose lookup would panic must be reached
+        stack[sp] = (int16_t)(sc.nodes.size() - 1);
+        box[sp++] = nullptr;
         while (sp > 0 && !status) {
-            int16_t c = stack[--sp];
+            --sp;
+            int16_t c = stack[sp];
+            if (cull && box[sp] && !box_matters(box[sp])) continue;
             if (c & (int16_t)0x8000) {
                 const SubSectorRec &ss = sc.subsectors[(size_t)(c & 0x7fff)];
                 for (int i = 0; i < ss.count && !status; i++) process_seg(sc.segs[(size_t)(ss.first + i)]);
@@ -449,8 +505,10 @@ struct Walker {
             bool is_left = left_of(ppos, Seg2{v1, v2});
             int16_t front = is_left ? n.lchild : n.rchild, back = is_left ? n.rchild : n.lchild;
             if (sp + 2 > 256) { fail("BSP deeper than 256"); return; }
-            stack[sp++] = back;
-            stack[sp++] = front;
+            stack[sp] = back;
+            box[sp++] = n.bb[is_left ? 0 : 1];
+            stack[sp] = front;
+            box[sp++] = n.bb[is_left ? 1 : 0];
         }
     }
 

@@ -523,6 +523,35 @@ Scene *load_scene_from_wad(const uint8_t *bytes, size_t len, const char *map_nam
                 }
             }
         }
+        // Bounding boxes of the subtrees (children precede parents, so one ascending pass suffices) and whether any record
+        // could make the reference panic when its seg is processed (then no seg may be skipped unseen, frontend.cpp).
+        {
+            auto grow = [](float *bb, float x, float y) { bb[0] = std::min(bb[0], x); bb[1] = std::min(bb[1], y); bb[2] = std::max(bb[2], x); bb[3] = std::max(bb[3], y); };
+            for (size_t i = 0; i < sc->nodes.size(); i++) {
+                NodeRec &d = sc->nodes[i];
+                const int16_t child[2] = {d.rchild, d.lchild};
+                for (int side = 0; side < 2; side++) {
+                    float *bb = d.bb[side];
+                    bb[0] = bb[1] = 3.0e38f; bb[2] = bb[3] = -3.0e38f;
+                    const size_t idx = (size_t)(child[side] & 0x7fff);
+                    if (child[side] & (int16_t)0x8000) {
+                        const SubSectorRec &ss = sc->subsectors[idx];
+                        for (int k = 0; k < ss.count; k++) {
+                            const SegRec &sg = sc->segs[(size_t)(ss.first + k)];
+                            grow(bb, sc->vx[(size_t)sg.v1], sc->vy[(size_t)sg.v1]);
+                            grow(bb, sc->vx[(size_t)sg.v2], sc->vy[(size_t)sg.v2]);
+                        }
+                    } else {
+                        for (int s2 = 0; s2 < 2; s2++) { grow(bb, sc->nodes[idx].bb[s2][0], sc->nodes[idx].bb[s2][1]); grow(bb, sc->nodes[idx].bb[s2][2], sc->nodes[idx].bb[s2][3]); }
+                    }
+                }
+            }
+            sc->may_panic = false;
+            for (const SidedefRec &sd : sc->sidedefs) sc->may_panic |= sd.upper == TEX_UNKNOWN || sd.lower == TEX_UNKNOWN || sd.middle == TEX_UNKNOWN;
+            for (const SectorRec &se : sc->sectors) sc->may_panic |= (se.floor_anim < 0 && se.floor_flat < 0) || (se.ceil_anim < 0 && se.ceil_flat < 0);
+            for (const AnimList &a : sc->anim)
+                for (int k = 0; k < a.n; k++) sc->may_panic |= a.flat[k] < 0;
+        }
         // Palette (first 768 bytes of PLAYPAL)
         {
             int pi = w.find("PLAYPAL");

@@ -37,7 +37,12 @@ struct SidedefRec {
 struct LinedefRec { int32_t v1, v2; int16_t flags; int16_t pad; int32_t front, back; };
 struct SegRec { int32_t v1, v2, linedef; int16_t offset; uint8_t direction; uint8_t pad; };
 struct SubSectorRec { int32_t first, count; };
-struct NodeRec { float x, y, dx, dy; int16_t rchild, lchild; };
+struct NodeRec {
+    float x, y, dx, dy;
+    int16_t rchild, lchild;
+    float bb[2][4];   // [0] = right child, [1] = left child: min x, min y, max x, max y over the seg vertices of the subtree
+                      // (computed at load from the segs themselves, not the NODES lump's boxes, which the reference ignores)
+};
 struct SpriteFrameRec { int32_t rotate; int32_t bitmap[8]; };     // sprites.rs:20-23
 struct MapObjectRec {                                            // map_objects.rs:11-17, renderer-visible part
     float x, y, angle;
@@ -63,6 +68,7 @@ struct Scene {
     std::vector<MapObjectRec> mobjs;
     float start_x = 0, start_y = 0, start_angle = 0;
     bool has_start = false;
+    bool may_panic = false;                         // some sidedef texture / sector flat lookup would panic in the reference when reached
     // graphics
     uint8_t palette[768];
     std::vector<BitmapInfo> bitmaps;

@@ -6,6 +6,7 @@
 // host logic and the list format against the oracle in a container without a GPU.  The GPU tier repeats the
 // same comparison through the real HIP kernels and the C-ABI.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 
@@ -224,5 +225,24 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
     raster_spans(ds, k, fr, pal.data(), col_off.data(), rspans.data(), W, H, rgb);
     if (stats) { stats[0] = off; stats[1] = ff.n_parts; stats[2] = ff.n_sprites; stats[3] = flags[0]; stats[4] = same ? 1 : 0; stats[5] = n_gaps; }
     return 0;
+}
+// Host-side cost of one frame (seconds, single thread): mode 0 = build_frame_lists + bin_frame (DG_FE_HOST), 1 = build_frame_parts (DG_FE_DEVICE).
+double emul_time_front_end(void *scene, int W, int H, const dg_view *views, int n, int iters, int mode) {
+    const Scene &sc = *(const Scene *)scene;
+    static thread_local FrameArena arena;
+    static thread_local BinnedFrame bf;
+    FrameConsts fk = make_consts(W, H);
+    std::string err;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0; it < iters; it++)
+        for (int i = 0; i < n; i++) {
+            dg_view v = views[i];
+            fill_view_trig(v);
+            if (mode == 0) {
+                dg_frame_lists fl;
+                if (build_frame_lists(sc, W, H, v, arena, fl, err) || bin_frame(sc, fk, fl, bf, err)) return -1.0;
+            } else if (build_frame_parts(sc, W, H, v, arena, err)) return -1.0;
+        }
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / ((double)iters * n);
 }
 }
