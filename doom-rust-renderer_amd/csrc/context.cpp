@@ -569,7 +569,12 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
             if (v >= 1 && v <= (long)FE_MAX_COL_SLOTS) c->fe_col_slots = (uint32_t)v;
         }
         c->fe_out.resize(F);
-        c->fe_part_cap = F * 2048;         // wall records per frame on average (e1m1-like maps: 20-600)
+        size_t parts_per_frame = 2048;     // wall records per frame on average (e1m1-like maps ship 20-200 after culling)
+        if (const char *e = std::getenv("DOOMGPU_FE_RECORDS_PER_FRAME")) {   // sizes the record slab; a batch that needs more goes through the host list path
+            const long v = std::strtol(e, nullptr, 10);
+            if (v >= 1 && v <= 65535) parts_per_frame = (size_t)v;
+        }
+        c->fe_part_cap = F * parts_per_frame;
         c->fe_sprite_cap = F * 256;
         c->fe_behind_cap = F * 256 * 32;   // one bit per (sprite, wall record)
         c->fe_bin_cap = F * 16384;         // column-bin entries (a record is listed in every 64-column strip it touches)

@@ -335,13 +335,15 @@ def test_device_front_end_capacity_falls_back_to_host_lists(dg, scene1994, oracl
     (a) more wall records than the record slab holds (known before the launch), (b) more spans in a screen column than
     the scratch has slots (found by the kernel, reported through the overflow flags at dg_wait)."""
     W, H = 320, 200
-    ref809 = np.frombuffer(oracle_scene1994.render(W, H, path1994[809]), dtype=np.uint8).reshape(H, W, 3)
-    ctx = make_ctx(dg, scene1994, W, H, 1, slots=1, front_end=dg.DG_FE_DEVICE)       # frame 809: 2 104 records > 2 048 per frame
-    assert np.array_equal(ctx.render(dg.make_views(path1994[809:810]))[0], ref809)
-    assert ctx.timing(0)["front_end"] == dg.DG_FE_HOST
-    assert np.array_equal(ctx.render(dg.make_views(path1994[100:101]))[0],
-                          np.frombuffer(oracle_scene1994.render(W, H, path1994[100]), dtype=np.uint8).reshape(H, W, 3))
-    assert ctx.timing(0)["front_end"] == dg.DG_FE_DEVICE
+    ref = [np.frombuffer(oracle_scene1994.render(W, H, path1994[i]), dtype=np.uint8).reshape(H, W, 3) for i in (711, 18)]
+    monkeypatch.setenv("DOOMGPU_FE_RECORDS_PER_FRAME", "40")             # frame 711 ships 86 wall records (after culling), frame 18 only 2
+    ctx = make_ctx(dg, scene1994, W, H, 1, slots=1, front_end=dg.DG_FE_DEVICE)
+    monkeypatch.delenv("DOOMGPU_FE_RECORDS_PER_FRAME")
+    assert np.array_equal(ctx.render(dg.make_views(path1994[711:712]))[0], ref[0])
+    t_big = ctx.timing(0)
+    assert np.array_equal(ctx.render(dg.make_views(path1994[18:19]))[0], ref[1])
+    t_small = ctx.timing(0)
+    assert (t_big["front_end"], t_small["front_end"]) == (dg.DG_FE_HOST, dg.DG_FE_DEVICE), (t_big, t_small)
     ctx.close()
 
     monkeypatch.setenv("DOOMGPU_FE_COLUMN_SLOTS", "5")
