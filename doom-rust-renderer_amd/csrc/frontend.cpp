@@ -194,7 +194,7 @@ struct Walker {
     float player_height;
     int status = DG_OK;
     bool parts_mode = false;      // record FePart / FeSprite instead of walking columns
-    ColumnIntervals solid_cols;   // parts mode: columns spanned by full-height solid parts so far
+    ColumnIntervals solid_cols;   // columns spanned by full-height solid parts so far
     uint32_t n_floor_planes_marker = 0;
     // visplanes carry a pool tag in the top bit of first_entry until finalisation
     static constexpr uint32_t kCeilPool = 0x80000000u;
@@ -306,13 +306,12 @@ struct Walker {
         r.sort_key = 0;
 
         const bool planes_here = !f.two_sided_mid && (full_height || f.only_occlusions);
+        // Columns that an earlier full-height solid part spans are horizontally occluded whatever that part's own
+        // visibility was (segs.rs:341-344 runs for every column of the part).  A part lying entirely inside them can
+        // neither draw, clip, add a visplane entry nor occlude anything new (segs.rs:211,337-341): it is dropped here.
+        if (solid_cols.covers(bot.sx, bot.ex)) return;
+        if (!f.two_sided_mid && full_height) solid_cols.add(bot.sx, bot.ex);
         if (parts_mode) {
-            // Columns that an earlier full-height solid part spans are horizontally occluded whatever that part's own
-            // visibility was (segs.rs:341-344 runs for every column of the part).  A part lying entirely inside them can
-            // neither draw, clip, add a visplane entry nor occlude anything new (segs.rs:211,337-341): it is not shipped.
-            const bool opaque_full = !f.two_sided_mid && full_height;
-            if (solid_cols.covers(bot.sx, bot.ex)) return;
-            if (opaque_full) solid_cols.add(bot.sx, bot.ex);
             if (tex >= 0) {
                 const BitmapInfo &bi = sc.bitmaps[(size_t)tex];
                 if (bi.w <= 0 || bi.h <= 0) { fail_parts("zero-sized bitmap"); return; }
@@ -462,7 +461,7 @@ struct Walker {
     }
 
     // Renderer::render_node, mod.rs:69-104 — iterative, front child first, no culling (the reference has none)
-    // Parts mode only.  Can any seg inside the box (map coordinates) still matter?  No if the box lies behind the viewer or
+    // Can any seg inside the box (map coordinates) still matter?  No if the box lies behind the viewer or
     // outside the 90-degree frustum (clip_to_viewport rejects every seg in it), or if the screen columns it can project to
     // are all spanned by earlier full-height solid parts (every part of every seg in it would be dropped by
     // solid_cols.covers).  The column range is widened by two columns against f32 rounding of the per-seg projection;
@@ -488,7 +487,7 @@ struct Walker {
         int16_t stack[256];
         const float *box[256];
         int sp = 0;
-        const bool cull = parts_mode && !sc.may_panic;               // a seg whose lookup would panic must be reached
+        const bool cull = !sc.may_panic;                             // a seg whose lookup would panic must be reached
         stack[sp] = (int16_t)(sc.nodes.size() - 1);
         box[sp++] = nullptr;
         while (sp > 0 && !status) {
