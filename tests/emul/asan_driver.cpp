@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../doom-rust-renderer_amd/csrc/binner.hpp"
+#include "../../doom-rust-renderer_amd/csrc/fe_core.h"
 #include "../../doom-rust-renderer_amd/csrc/frontend.hpp"
 #include "../../doom-rust-renderer_amd/csrc/scene.hpp"
 
@@ -20,6 +21,8 @@ static uint32_t rng_state = 2463534242u;
 static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 17; rng_state ^= rng_state << 5; return rng_state; }
 static float frand(float lo, float hi) { return lo + (hi - lo) * (float)(rnd() & 0xffffff) / 16777216.0f; }
 
+static int walk_parts_on_host(const Scene &sc, int W, int H, const dg_view &v, FrameArena &A);
+
 static int lists(const Scene &sc, int W, int H, dg_view v) {
     static FrameArena arena;
     static BinnedFrame bf;
@@ -28,7 +31,51 @@ static int lists(const Scene &sc, int W, int H, dg_view v) {
     fill_view_trig(v);
     int rc = build_frame_lists(sc, W, H, v, arena, fl, err);
     if (rc) return rc;
-    return bin_frame(sc, make_consts(W, H), fl, bf, err);
+    rc = bin_frame(sc, make_consts(W, H), fl, bf, err);
+    if (rc) return rc;
+    // parts mode (records for the device column walk) + a host replay of the column bodies over its output
+    static FrameArena parts_arena;
+    rc = build_frame_parts(sc, W, H, v, parts_arena, err);
+    if (rc == kPartsUnsupported) return 0;
+    if (rc) return rc;
+    return walk_parts_on_host(sc, W, H, v, parts_arena);
+}
+
+// The bodies of dg_fe_columns over one frame's records, with bounds-checked scratch (sanitizer coverage of fe_core.h).
+static int walk_parts_on_host(const Scene &sc, int W, int H, const dg_view &v, FrameArena &A) {
+    const FrameConsts fk = make_consts(W, H);
+    DevFrame fr = make_frame_header(v);
+    FeFrame ff{0, (uint32_t)A.parts.size(), 0, (uint32_t)A.sprites.size(), 0, A.behind_words, A.n_sky_slots, 0, 0, 0, {0, 0}};
+    const uint32_t w64 = (uint32_t)((W + 63) / 64), slots = 16;
+    std::vector<FeU4> cspans((size_t)slots * W);
+    std::vector<FeColRec> recs((size_t)slots * W);
+    std::vector<uint32_t> cnt((size_t)W), flags(1, 0);
+    std::vector<uint64_t> events((size_t)3 * (A.n_sky_slots + 1) * w64, 0);
+    FeParams P{};
+    P.k = DevConsts{fk.ARC, fk.GCFX, fk.CFX, fk.CFY, W, H};
+    P.frames = &fr; P.fframes = &ff; P.parts = A.parts.data(); P.sprites = A.sprites.data(); P.behind = A.behind.data();
+    P.cspans = cspans.data(); P.recs = recs.data(); P.cnt = cnt.data(); P.events = events.data(); P.flags = flags.data();
+    P.n_frames = 1; P.max_sky_slots = A.n_sky_slots; P.w64 = w64; P.col_slots = slots;
+    if (A.bin_off.size() != (size_t)w64 + 1 || A.sbin_off.size() != (size_t)w64 + 1) return -100;
+    for (int x = 0; x < W; x++) {
+        FeColumn c = fe_column_start(P, 0, x);
+        const uint32_t bin = (uint32_t)x / FE_BIN_W;
+        for (uint32_t bi = A.bin_off[bin]; bi < A.bin_off[bin + 1]; bi++) {
+            const uint32_t pi = A.bin_parts.at(bi);
+            const FePart &p = A.parts.at(pi);
+            if (x < p.sx || x > p.ex) continue;
+            const uint32_t ev = fe_part_column(P, 0, p, pi, c);
+            if (p.sky_slot >= 0 && (ev & FE_EV_FADD)) fe_event_words(P, 0, p.sky_slot, 0)[x >> 6] |= 1ull << (x & 63);
+            if (c.hor) break;
+        }
+        for (uint32_t bi = A.sbin_off[bin]; bi < A.sbin_off[bin + 1]; bi++) {
+            const uint32_t si = A.sbin_sprites.at(bi);
+            const FeSprite &sp = A.sprites.at(si);
+            if (x >= sp.x0 && x < sp.x1) fe_sprite_column(P, 0, ff, sp, si, c);
+        }
+        for (uint32_t i = 0; i < c.nsp; i++) (void)fe_resolve(P, fr, ff, x, cspans[(size_t)i * W + (size_t)x]);
+    }
+    return 0;
 }
 
 int main(int argc, char **argv) {
