@@ -239,6 +239,30 @@ def main():
                "sample": f"every {args.cpu_sample}th frame of the same 1000-frame path at {W}x{H} ({len(idx)} frames, {dt:.1f} s), "
                          "oracle/doomref.c -O2 -ffp-contract=off, cos/sin hoisted per frame",
                "host_cpus": os.cpu_count()}
+        # the same oracle with the sampled frames sharded over the host cores this process may use (one scene per thread: the
+        # oracle's lazy texture caches are per scene; ctypes releases the GIL around dr_render)
+        try:
+            import threading
+            ncores = max(1, min(len(os.sched_getaffinity(0)), 64))
+            scenes = [doomref.Scene(wad, "e1m1") for _ in range(ncores)]
+            bufs = [np.empty(3 * W * H, dtype=np.uint8) for _ in range(ncores)]
+            for sc_t, bt in zip(scenes, bufs):
+                sc_t.render(W, H, path[0], out=bt.ctypes.data)    # warm the lazy caches outside the clock
+
+            def work(t):
+                for i in idx[t::ncores]:
+                    scenes[t].render(W, H, path[i], out=bufs[t].ctypes.data)
+            th = [threading.Thread(target=work, args=(t,)) for t in range(ncores)]
+            tm = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            dtm = time.perf_counter() - tm
+            cpu["all_cores"] = {"value": len(idx) / dtm, "unit": "frames/s", "cores": ncores,
+                                "sample": f"the same {len(idx)} frames sharded over {ncores} threads ({dtm:.2f} s)"}
+        except Exception as e:                            # the single-core figure above is the contract; this one is extra
+            cpu["all_cores"] = {"error": str(e)}
         # parity of the frames the timed steps produced: every sampled frame, byte for byte, against the oracle
         bad = 0
         for s in range(n_slots):
