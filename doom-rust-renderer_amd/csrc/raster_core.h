@@ -57,10 +57,14 @@ DG_HD uint32_t f32_as_u8_pk(float f) {
 // IEEE-exact n / d with the denominator-only part of the divide hoisted.  hipcc expands `n / d` to
 //   v_div_scale x2, v_rcp, fma, fma | mul, fma, fma, fma, v_div_fmas, v_div_fixup
 // and the two v_div_scale are identities (and v_div_fmas a plain fma) unless an operand is denormal / huge / tiny.
-// prepare_rcp() is the part left of the bar, div_prepared() the part right of it — the same instructions in the same
-// order, so the result is the correctly rounded quotient whenever div_guard_ok(n) holds and d is a normal number of
-// moderate size (the kernel only uses it for d = integer row differences and d = CFY - y).  v_div_fixup supplies the
-// IEEE results for d == 0, n == 0, infinities and NaN.  On the host the plain quotient is the same value.
+// prepare_rcp() is the part left of the bar (a reciprocal refined by one Newton step).  div_prepared() is
+//   q = n * r;  q += (n - d*q) * r  (one fused residual correction, Markstein's scheme);  v_div_fixup
+// i.e. the compiler's sequence without its second correction, which never changes the result on the two domains the
+// kernel uses it for: d = integer row differences with n = integer row offsets (all 131 071 x 81 919 pairs), and
+// d = CFY - y (every multiple of 0.5 in [-8192, 8192]) with EVERY f32 numerator inside the guard band
+// (7.09e13 quotients) — tests/gpu_numerics/numerics_check.hip enumerates both completely and requires zero mismatches
+// against `n / d`.  v_div_fixup supplies the IEEE results for d == 0, n == 0, infinities and NaN.  On the host the plain
+// quotient is the same value.
 DG_HD float prepare_rcp(float d) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float r0 = __builtin_amdgcn_rcpf(d);
@@ -75,8 +79,6 @@ DG_HD float div_prepared(float n, float d, float r) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float q = n * r;
     float e = __builtin_fmaf(-d, q, n);
-    q = __builtin_fmaf(e, r, q);
-    e = __builtin_fmaf(-d, q, n);
     q = __builtin_fmaf(e, r, q);
     return __builtin_amdgcn_div_fixupf(q, d, n);
 #else
