@@ -205,6 +205,7 @@ def main():
     mean_raster_s = float(np.mean(raster_ms)) / 1e3
     achieved = float(np.mean(alg_bytes)) / mean_raster_s / 1e9
     traffic = None
+    valu = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
@@ -212,6 +213,13 @@ def main():
             key = f"{W}x{H}x{B}"
             if key in tj:
                 traffic = tj[key]["hbm_bytes_per_launch"]
+                n_valu = tj[key].get("valu_wave_instructions_per_launch")
+                if n_valu:
+                    # what actually bounds the kernel: the vector ALU issue rate (one wave64 instruction per 4 clocks per SIMD)
+                    model_ms = n_valu * 4.0 / (1024 * 2.4e9) * 1e3
+                    valu = {"wave_instructions_per_launch": n_valu, "clocks_per_instruction": 4, "simds": 1024, "clock_GHz": 2.4,
+                            "issue_limited_ms": model_ms, "frac_of_issue_limit": model_ms / (float(np.mean(iso_ms))),
+                            "source": "SQ_INSTS_VALU (rocprofv3 --pmc), profiles/traffic.json"}
         except Exception:
             traffic = None
     roofline = {"kernel": "dg_raster_tiles", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -221,7 +229,8 @@ def main():
                 "note": "achieved/frac are measured over the timed steps, where the next step's column-walk kernels overlap this kernel; "
                         "isolated_* is the same launch measured with nothing else on the GPU",
                 "isolated_launch_ms": float(np.mean(iso_ms)), "isolated_achieved": float(np.mean(alg_bytes)) / (float(np.mean(iso_ms)) / 1e3) / 1e9,
-                "isolated_frac": float(np.mean(alg_bytes)) / (float(np.mean(iso_ms)) / 1e3) / 1e9 / 8000.0}
+                "isolated_frac": float(np.mean(alg_bytes)) / (float(np.mean(iso_ms)) / 1e3) / 1e9 / 8000.0,
+                "valu_issue": valu}
 
     # ---- CPU baseline (oracle = port of the reference renderer), rank 0, N = 1 only ---------------------------------
     cpu = None
