@@ -149,6 +149,7 @@ struct dg_ctx {
     // device scene
     uint32_t *d_palette = nullptr;
     uint8_t *d_texel_idx = nullptr, *d_texel_opq = nullptr, *d_flats = nullptr;
+    uint2 *d_row_tab = nullptr;         // per-row constants of the flat / sky mappers (dg_row_table), rebuilt per scene upload
     DevScene dscene{};
     std::vector<Slot> slots;
     hipEvent_t last_front = nullptr;    // end of the last column walk: the shared column scratch is free again
@@ -197,6 +198,7 @@ void free_ctx(dg_ctx *c) {
     if (c->d_texel_idx) (void)hipFree(c->d_texel_idx);
     if (c->d_texel_opq) (void)hipFree(c->d_texel_opq);
     if (c->d_flats) (void)hipFree(c->d_flats);
+    if (c->d_row_tab) (void)hipFree(c->d_row_tab);
     if (c->d_fe_cnt) (void)hipFree(c->d_fe_cnt);
     if (c->d_fe_cspans) (void)hipFree(c->d_fe_cspans);
     if (c->d_fe_recs) (void)hipFree(c->d_fe_recs);
@@ -266,6 +268,7 @@ int build_batch_host(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_li
     P.spans = reinterpret_cast<const DevSpan *>(s.d_lists + off_spans);
     P.rspans = s.d_rspans;
     P.fb = s.d_fb;
+    P.row_tab = c->d_row_tab;
     P.n_frames = n;
     s.max_spans = max_spans; s.n_spans = spans; s.covered = covered; s.n_frames = n; s.n_walls = walls; s.n_planes = planes;
     s.list_bytes = total;
@@ -372,6 +375,7 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     P.walls = nullptr; P.planes = nullptr; P.spans = nullptr;
     P.rspans = s.d_rspans;
     P.fb = s.d_fb;
+    P.row_tab = c->d_row_tab;
     P.n_frames = n;
     s.max_spans = 0; s.n_spans = 0; s.covered = 0; s.n_frames = n; s.n_walls = parts; s.n_planes = sprites;
     s.list_bytes = total;
@@ -642,6 +646,9 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     if (!sc.flat_pool.empty()) HIP_TRY(hipMemcpy(c->d_flats, sc.flat_pool.data(), sc.flat_pool.size(), hipMemcpyHostToDevice));
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
     c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
+    if (!c->d_row_tab) HIP_TRY(hipMalloc((void **)&c->d_row_tab, (size_t)c->cfg.height * sizeof(uint2)));
+    HIP_TRY(launch_row_table(c->dscene, c->dk, c->d_row_tab, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
     c->scene = &sc;
     c->fe_scene_ok = sky.w >= 256 && sky.h >= 128;    // a smaller sky bitmap is an index panic only when a sky visplane is drawn: host path
     c->uploaded_texels = sc.texel_idx.size();

@@ -135,16 +135,18 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int y = y0 + lane;
     const float vy = P.k.CFY - (float)y;      // visplanes.rs:109, a per-row constant
-    const float r_vy = prepare_rcp(vy);
-    const int srow = sky_row(P.scene, P.k, y);    // visplanes.rs:68-72, a per-row constant
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
     const uint4 *gspans = reinterpret_cast<const uint4 *>(P.rspans + fr.span_base);
 
-    if (threadIdx.x < 256) pal[threadIdx.x] = P.scene.palette[threadIdx.x];
-    if (threadIdx.x <= TILE_W) {
-        const int xc = x0 + (int)threadIdx.x;
-        lcoff[threadIdx.x] = coff[xc < W ? xc : W];
-    }
+    // the three prologue loads are issued together (addresses clamped instead of branching around the loads)
+    const uint2 rt = P.row_tab[y < H ? y : H - 1];                    // prepared reciprocal of vy and the sky row (dg_row_table)
+    const uint32_t pal_v = P.scene.palette[threadIdx.x & 255];
+    const int xc = x0 + (int)(threadIdx.x <= TILE_W ? threadIdx.x : 0);
+    const uint32_t coff_v = coff[xc < W ? xc : W];
+    const float r_vy = bits_f32(rt.x);
+    const int srow = (int)rt.y;
+    if (threadIdx.x < 256) pal[threadIdx.x] = pal_v;
+    if (threadIdx.x <= TILE_W) lcoff[threadIdx.x] = coff_v;
     __syncthreads();
 
     // The spans of adjacent columns are one contiguous range of the column-major span array.  Stage as many whole columns
@@ -191,6 +193,21 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
             dst[2] = o2;
         }
     }
+}
+
+// Per-row constants of the flat and sky mappers for one frame size: the prepared reciprocal of vy = CFY - y (visplanes.rs:109)
+// and the sky texture row (visplanes.rs:68-72).  Same device code as the per-lane computation it replaces, run once per
+// scene upload instead of once per wavefront (~35 VALU instructions of every raster wave).
+__global__ void dg_row_table(DevScene scene, DevConsts k, uint2 *row_tab) {
+    const int y = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (y >= k.H) return;
+    const float vy = k.CFY - (float)y;
+    row_tab[y] = make_uint2(f32_bits(prepare_rcp(vy)), (uint32_t)sky_row(scene, k, y));
+}
+
+hipError_t launch_row_table(const DevScene &scene, const DevConsts &k, uint2 *row_tab, hipStream_t stream) {
+    hipLaunchKernelGGL(dg_row_table, dim3((unsigned)((k.H + 255) / 256)), dim3(256), 0, stream, scene, k, row_tab);
+    return hipGetLastError();
 }
 
 hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hipStream_t stream) {

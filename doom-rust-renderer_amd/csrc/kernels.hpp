@@ -1,6 +1,7 @@
 // kernels.hpp — launch interface between the context (host) and kernels.hip.
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
 
 #include "lists_dev.h"
 
@@ -16,10 +17,13 @@ struct RasterParams {
     const DevWallRec *walls;
     const DevPlaneRec *planes;
     uint8_t *fb;                 // n_frames x 3*W*H, RGB24
+    const uint2 *row_tab;        // [H] per screen row: x = bits of prepare_rcp(CFY - y), y = sky texture row (or -1); dg_row_table
     int32_t n_frames;
 };
 
 hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hipStream_t stream);
 hipError_t launch_raster(const RasterParams &P, hipStream_t stream);
+// Fills row_tab[0 .. H) for the given scene / frame size (once per dg_upload_scene).
+hipError_t launch_row_table(const DevScene &scene, const DevConsts &k, uint2 *row_tab, hipStream_t stream);
 
 }  // namespace dg
