@@ -9,7 +9,9 @@
 //                              * the spans of the tile's 64 columns are ONE contiguous range of the column-major span
 //                                array; they are staged in LDS with a single coalesced burst (16 KB), together with the
 //                                palette (1 KB) and the tile's column offsets;
-//                              * a wavefront takes one screen column at a time with lane = row.  Pass 1 walks the column's
+//                              * a wavefront owns eight of the tile's columns.  One pre-filter pass with lane = (column,
+//                                span slot) finds, for all eight at once, the spans that touch the tile's rows; then the
+//                                wave takes one column at a time with lane = row.  Pass 1 walks the column's touching
 //                                spans in draw order and records per row the last span covering it (one v_readlane per
 //                                span); pass 2 evaluates every row ONCE with its winner's parameters fetched from LDS —
 //                                exact last-writer-wins, no overdraw evaluation, one pass per span kind;
@@ -65,12 +67,49 @@ __device__ __forceinline__ uint32_t eval_flat(const RasterParams &P, const DevFr
     return shade(pal[P.scene.flats[o]], factor);
 }
 
-// One screen column (64 rows of it) for one wavefront, spans staged in LDS (lw0 = word 0 of every span, lsp = all 8 words).
-//   Pass 1  walk the column's spans in draw order; every row remembers the LAST span that covers it ("winner").  Spans
-//           that may be transparent (masked walls, sprites, sky: the immediate flag) are evaluated on the spot because
-//           whether they overwrite depends on the texel.  Cost per span: one v_readlane and a handful of scalar ops.
-//   Pass 2  each row fetches its winner's 8 words from LDS and is evaluated once — one pass per span KIND present, with
-//           per-lane parameters, instead of one pass per span; overdrawn pixels are never evaluated.
+// One span of the column meets this wave's 64 rows (pass 1).  Every row remembers the LAST opaque span that covers it
+// ("winner").  Spans that may be transparent (masked walls, sprites, sky with holes: the immediate flag) are evaluated on
+// the spot because whether they overwrite depends on the texel.  w0 and idx are wave-uniform.
+__device__ __forceinline__ void span_step(const RasterParams &P, const uint32_t *pal, const uint4 *lsp, uint32_t w0, uint32_t idx, int y, int srow,
+                                          uint32_t &color, uint32_t &winner) {
+    const bool in = (uint32_t)(y - w0_ctop(w0)) <= (uint32_t)(w0_cbot(w0) - w0_ctop(w0));
+    if (!w0_immediate(w0)) {
+        if (in) winner = idx;
+    } else if (in) {
+        const uint4 a = lsp[2 * idx], b = lsp[2 * idx + 1];   // same address in every lane: LDS broadcast
+        if (w0_kind(w0) == SPAN_WALL) {
+            bool opaque;
+            const uint32_t c = eval_wall(P, pal, a, b, y, opaque);
+            if (opaque) { color = c; winner = 0xffffffffu; }
+        } else {
+            const uint32_t o = sky_texel_offset(a.z, srow);
+            if (o != 0xffffffffu && P.scene.texel_opq[o]) { color = pal[P.scene.texel_idx[o]]; winner = 0xffffffffu; }
+        }
+    }
+}
+
+// Pass 2: each row fetches its winner's 8 words from LDS and is evaluated once — one pass per span KIND present, with
+// per-lane parameters, instead of one pass per span; overdrawn pixels are never evaluated.
+__device__ __forceinline__ uint32_t shade_winner(const RasterParams &P, const DevFrame &fr, const uint32_t *pal, const uint4 *lsp, uint32_t winner,
+                                                 uint32_t color, int y, float vy, float r_vy, int srow) {
+    if (winner != 0xffffffffu) {
+        const uint4 a = lsp[2 * winner], b = lsp[2 * winner + 1];
+        const uint32_t kind = w0_kind(a.x);
+        if (kind == SPAN_FLAT) {
+            color = eval_flat(P, fr, pal, a, b, vy, r_vy);
+        } else if (kind == SPAN_WALL) {
+            bool opaque;
+            color = eval_wall(P, pal, a, b, y, opaque);
+        } else {                                  // sky bitmap without holes: plain lookup, no lighting
+            const uint32_t o = sky_texel_offset(a.z, srow);
+            if (o != 0xffffffffu) color = pal[P.scene.texel_idx[o]];
+        }
+    }
+    return color;
+}
+
+// One screen column (64 rows of it) for one wavefront, any number of spans (lw0 = word 0 of every span, lsp = all 8 words):
+// lane i looks at span i, a ballot picks the spans touching these rows, one v_readlane per such span.
 __device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const DevFrame &fr, const uint32_t *pal, const uint32_t *lw0,
                                                   const uint4 *lsp, uint32_t n, int lane, int y, int y0, float vy, float r_vy, int srow) {
     uint32_t color = 0;
@@ -87,37 +126,24 @@ __device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const D
         while (m) {
             const int j = __builtin_ctzll(m);
             m &= m - 1;
-            const uint32_t w0 = bcast(w0v, j);
-            const bool in = (uint32_t)(y - w0_ctop(w0)) <= (uint32_t)(w0_cbot(w0) - w0_ctop(w0));
-            if (!w0_immediate(w0)) {
-                if (in) winner = base + (uint32_t)j;
-            } else if (in) {
-                const uint4 a = lsp[2 * (base + (uint32_t)j)], b = lsp[2 * (base + (uint32_t)j) + 1];   // same address in every lane: LDS broadcast
-                if (w0_kind(w0) == SPAN_WALL) {
-                    bool opaque;
-                    const uint32_t c = eval_wall(P, pal, a, b, y, opaque);
-                    if (opaque) { color = c; winner = 0xffffffffu; }
-                } else {
-                    const uint32_t o = sky_texel_offset(a.z, srow);
-                    if (o != 0xffffffffu && P.scene.texel_opq[o]) { color = pal[P.scene.texel_idx[o]]; winner = 0xffffffffu; }
-                }
-            }
+            span_step(P, pal, lsp, bcast(w0v, j), base + (uint32_t)j, y, srow, color, winner);
         }
     }
-    if (winner != 0xffffffffu) {
-        const uint4 a = lsp[2 * winner], b = lsp[2 * winner + 1];
-        const uint32_t kind = w0_kind(a.x);
-        if (kind == SPAN_FLAT) {
-            color = eval_flat(P, fr, pal, a, b, vy, r_vy);
-        } else if (kind == SPAN_WALL) {
-            bool opaque;
-            color = eval_wall(P, pal, a, b, y, opaque);
-        } else {                                  // sky bitmap without holes: plain lookup, no lighting
-            const uint32_t o = sky_texel_offset(a.z, srow);
-            if (o != 0xffffffffu) color = pal[P.scene.texel_idx[o]];
-        }
+    return shade_winner(P, fr, pal, lsp, winner, color, y, vy, r_vy, srow);
+}
+
+// The same for a column with at most 8 spans whose row filter was done by the wave-level pre-filter (dg_raster_tiles):
+// hm = bit j set when span j touches these rows, its word 0 sits in lane `lane0 + j` of w0f.
+__device__ __forceinline__ uint32_t raster_column_small(const RasterParams &P, const DevFrame &fr, const uint32_t *pal, uint32_t hm, uint32_t w0f,
+                                                        int lane0, const uint4 *lsp, int y, float vy, float r_vy, int srow) {
+    uint32_t color = 0;
+    uint32_t winner = 0xffffffffu;
+    while (hm) {
+        const int j = __builtin_ctz(hm);
+        hm &= hm - 1;
+        span_step(P, pal, lsp, bcast(w0f, lane0 + j), (uint32_t)j, y, srow, color, winner);
     }
-    return color;
+    return shade_winner(P, fr, pal, lsp, winner, color, y, vy, r_vy, srow);
 }
 
 __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
@@ -167,10 +193,31 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
             if ((i & 1u) == 0) lw0[i >> 1] = v.x;
         }
         __syncthreads();
-        for (int c = c_lo + wave; c < c_hi; c += WAVES) {
-            const uint32_t n0 = lcoff[c] - t0, n = lcoff[c + 1] - lcoff[c];
-            tile[lane * TILE_STRIDE + c] = raster_column(P, fr, pal, lw0 + n0, lspans + 2 * n0, n, lane, y, y0, vy, r_vy, srow);
+        // Wave-level pre-filter: this wave owns columns c_lo + wave + 8k (k = 0..7).  Lane (k, slot) = (lane >> 3, lane & 7)
+        // tests span `slot` of column k against the tile's rows, so ONE pass filters all eight columns (columns with more
+        // than 8 spans take the general path).
+        const int fk = lane >> 3, fslot = lane & 7;
+        const int fcol = c_lo + wave + WAVES * fk;
+        uint32_t f_n0 = 0, f_n = 0, f_w0 = 0;
+        bool f_hit = false;
+        if (fcol < c_hi) {
+            f_n0 = lcoff[fcol] - t0;
+            f_n = lcoff[fcol + 1] - lcoff[fcol];
+            if ((uint32_t)fslot < f_n && f_n <= 8u) {
+                f_w0 = lw0[f_n0 + (uint32_t)fslot];
+                f_hit = w0_cbot(f_w0) >= y0 && w0_ctop(f_w0) <= y0 + (TILE_H - 1);
+            }
         }
+        const unsigned long long hitm = __ballot(f_hit);
+        int k8 = 0;
+        for (int c = c_lo + wave; c < c_hi; c += WAVES, k8 += 8) {
+            const uint32_t n0 = bcast(f_n0, k8), n = bcast(f_n, k8);
+            uint32_t px;
+            if (n > 8u) px = raster_column(P, fr, pal, lw0 + n0, lspans + 2 * n0, n, lane, y, y0, vy, r_vy, srow);
+            else px = raster_column_small(P, fr, pal, (uint32_t)(hitm >> k8) & 0xffu, f_w0, k8, lspans + 2 * n0, y, vy, r_vy, srow);
+            tile[lane * TILE_STRIDE + c] = px;
+        }
+
         c_lo = c_hi;
         if (c_lo < TILE_W) __syncthreads();   // before the staging area is reused
     }
