@@ -364,3 +364,32 @@ def test_device_front_end_capacity_falls_back_to_host_lists(dg, scene1994, oracl
     ctx.wait(0)
     assert np.array_equal(ctx.readback(0, 0, len(idx)), out) and ctx.timing(0)["front_end"] == dg.DG_FE_HOST
     ctx.close()
+
+
+@pytest.mark.parametrize("seed,heavy,quirks", [(1993, False, False), (1994, True, False), (1993, False, True)])
+def test_random_views_device_walk_equals_host_lists(dg, synth, campath_mod, oracle, seed, heavy, quirks):
+    """2 000 random viewpoints per map (inside and outside the map, any heading, several eye heights) through both front
+    ends at two sizes: identical frames, and every 40th one also against the oracle."""
+    wad = synth.build_synth_iwad(seed=seed, heavy=heavy, quirks=quirks)
+    scene = dg.Scene(wad, "e1m1")
+    osc = oracle.Scene(wad, "e1m1")
+    rng = np.random.default_rng(seed + 23)
+    ext = (8400, 6400) if heavy else (4200, 3200)
+    recs = np.array([campath_mod.view_record(float(rng.uniform(-100, ext[0])), float(rng.uniform(-100, ext[1])), float(rng.uniform(-7, 7)),
+                                             float(rng.choice([-64, -8, 0, 24, 41, 200]))) for _ in range(2000)], dtype=np.float32)
+    for (W, H) in [(320, 200), (132, 67)]:
+        B = 500
+        ctxs = {fe: make_ctx(dg, scene, W, H, B, slots=1, front_end=fe) for fe in (dg.DG_FE_HOST, dg.DG_FE_DEVICE)}
+        for b0 in range(0, len(recs), B):
+            views = dg.make_views(recs[b0:b0 + B])
+            a = ctxs[dg.DG_FE_HOST].render(views).copy()
+            b = ctxs[dg.DG_FE_DEVICE].render(views)
+            assert ctxs[dg.DG_FE_DEVICE].timing(0)["front_end"] == dg.DG_FE_DEVICE
+            diff = [k for k in range(B) if not np.array_equal(a[k], b[k])]
+            assert not diff, f"{W}x{H}: views {[b0 + k for k in diff[:8]]} differ between the front ends"
+            for k in range(0, B, 40):
+                ref = np.frombuffer(osc.render(W, H, recs[b0 + k]), dtype=np.uint8).reshape(H, W, 3)
+                assert np.array_equal(b[k], ref), f"{W}x{H}: view {b0 + k} differs from the oracle"
+        for c in ctxs.values():
+            c.close()
+    scene.close()
