@@ -4,9 +4,10 @@
 //   dg_fe_columns   one lane per (frame, screen column): walks the frame's parts in BSP order with the column's three
 //                   occlusion values in registers (the reference keeps them in horizontal_ocl / floor_ver_ocl /
 //                   ceiling_ver_ocl, segs.rs:70-74) and appends every wall / visplane / sprite span, in a compact 16-byte
-//                   form, to the column's scratch list.  Records are wave-uniform: 64 lanes test 64 records' column
-//                   ranges at once, the hits are fetched with one coalesced load and broadcast with v_readlane.  HBM-bound scratch writes are laid
-//                   out [slot][column] so the 64 lanes of a wave store 64 adjacent records.
+//                   form, to the column's scratch list.  A wavefront owns one 64-column bin whose record list the host
+//                   prepared; records are wave-uniform, staged through LDS 16 at a time (eight loads in flight) and
+//                   broadcast field by field with v_readlane.  A wave whose 64 columns are all horizontally occluded stops
+//                   walking.  Scratch writes are laid out [slot][column]: the 64 lanes of a wave store 64 adjacent records.
 //   dg_fe_gaps      one wave per (frame, part with a sky flat): the 1-pixel sky entries of zero-filled visplane columns.
 //   dg_fe_scan      one workgroup per frame: scans the per-column counts into col_off.
 //   dg_fe_scatter   ranks every column's spans by draw-order key, resolves their texture-mapping constants (DevRSpan) and
