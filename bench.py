@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--front-end", choices=["device", "host"], default="device", help="where the per-column half of the seg / sprite processing runs")
     ap.add_argument("--cpu-sample", type=int, default=4, help="cpu_baseline renders every n-th path frame")
+    ap.add_argument("--wad", default=None, help="IWAD file to render instead of the synthetic one (e.g. doom1.wad); the camera path is derived from the map")
+    ap.add_argument("--map", default="e1m1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
@@ -94,9 +96,12 @@ def main():
     cp = importlib.import_module("doom-rust-renderer_amd.camera_path")
 
     W, H, B = args.width, args.height, args.batch
-    wad = sw.build_synth_iwad(1993)
-    scene = dg.Scene(wad, "e1m1")
-    route = rank_route(sw.synth_route(1993), rank, world)
+    if args.wad:
+        wad = open(args.wad, "rb").read()                 # a user-supplied IWAD (BASELINE configs verbatim); data = "file"
+    else:
+        wad = sw.build_synth_iwad(1993)
+    scene = dg.Scene(wad, args.map)
+    route = rank_route(cp.route_from_wad(wad, args.map) if args.wad else sw.synth_route(1993), rank, world)
     path = cp.make_camera_path(route, lambda x, y, d: scene.floor_height_at(x, y, d), 1000)
     n_slots = max(1, min(args.slots, (1000 + B - 1) // B))
     fe = dg.DG_FE_HOST if args.front_end == "host" else dg.DG_FE_DEVICE
@@ -237,7 +242,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import doomref
-        osc = doomref.Scene(wad, "e1m1")
+        osc = doomref.Scene(wad, args.map)
         idx = list(range(0, 1000, max(1, args.cpu_sample)))
         refs = []
         tc = time.perf_counter()
@@ -253,7 +258,7 @@ def main():
         try:
             import threading
             ncores = max(1, min(len(os.sched_getaffinity(0)), 64))
-            scenes = [doomref.Scene(wad, "e1m1") for _ in range(ncores)]
+            scenes = [doomref.Scene(wad, args.map) for _ in range(ncores)]
             bufs = [np.empty(3 * W * H, dtype=np.uint8) for _ in range(ncores)]
             for sc_t, bt in zip(scenes, bufs):
                 sc_t.render(W, H, path[0], out=bt.ctypes.data)    # warm the lazy caches outside the clock
@@ -289,8 +294,8 @@ def main():
         line = {
             "metric": "frames/sec (fixed e1m1 camera path)", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic e1m1-like IWAD (seed 1993), 1000-frame scripted camera path, {W}x{H} native, "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "file" if args.wad else "synthetic",
+            "config": {"workload": (f"{os.path.basename(args.wad)} {args.map}" if args.wad else "synthetic e1m1-like IWAD (seed 1993)") + f", 1000-frame scripted camera path, {W}x{H} native, "
                                    f"{B} frames per step, " + ("per-seg / per-sprite records" if stats.get("front_end") == dg.DG_FE_DEVICE else "span lists") +
                                    " resident in HBM", "front_end": "device column walk" if stats.get("front_end") == dg.DG_FE_DEVICE else "host span lists",
                        "width": W, "height": H, "frames_per_step": B,

@@ -57,3 +57,47 @@ def make_camera_path(route, floor_height_fn, n_frames: int = 1000) -> np.ndarray
         prev = fh
         recs[i] = view_record(x, y, ang, fh)
     return recs
+
+
+def route_from_wad(wad: bytes, map_name: str, max_points: int = 48):
+    """A closed walk for ANY map (bench.py --wad): the midpoints of its two-sided linedefs (doorways, steps, windows) sorted by
+    angle around their centroid, thinned to max_points, starting nearest to the Player-1 start.  Only a benchmark path: it may
+    cut through walls or the void, which the renderer handles like the reference does."""
+    import struct
+    n, off = struct.unpack_from("<II", wad, 4)
+    lumps = []
+    for i in range(n):
+        o, sz = struct.unpack_from("<II", wad, off + 16 * i)
+        lumps.append((wad[off + 16 * i + 8: off + 16 * i + 16].split(b"\0")[0].decode("ascii", "replace").upper(), o, sz))
+    idx = [i for i, (nm, _, _) in enumerate(lumps) if nm == map_name.upper()]
+    if not idx:
+        raise ValueError(f"map {map_name} not in WAD")
+    m = idx[0]                                         # map lumps follow the FIRST marker of that name (src/wad.rs:175-183)
+    def lump(k):
+        _, o, sz = lumps[m + k]
+        return wad[o:o + sz]
+    things, linedefs, vertexes = lump(1), lump(2), lump(4)
+    vx = np.frombuffer(vertexes, dtype="<i2").reshape(-1, 2).astype(np.float64)
+    pts = []
+    for i in range(len(linedefs) // 14):
+        v1, v2, _flags, _, _, _front, back = struct.unpack_from("<hhhhhhh", linedefs, i * 14)
+        if back >= 0 and 0 <= v1 < len(vx) and 0 <= v2 < len(vx):
+            pts.append((vx[v1] + vx[v2]) / 2.0)
+    if len(pts) < 4:                                   # hardly any openings: walk the vertex cloud's bounding box instead
+        lo, hi = vx.min(axis=0), vx.max(axis=0)
+        c, r = (lo + hi) / 2.0, (hi - lo) / 4.0
+        pts = [c + r * np.array([math.cos(t), math.sin(t)]) for t in np.linspace(0, 2 * math.pi, 12, endpoint=False)]
+    pts = np.array(pts)
+    c = pts.mean(axis=0)
+    pts = pts[np.argsort(np.arctan2(pts[:, 1] - c[1], pts[:, 0] - c[0]), kind="stable")]
+    if len(pts) > max_points:
+        pts = pts[np.linspace(0, len(pts), max_points, endpoint=False).astype(int)]
+    start = None
+    for i in range(len(things) // 10):
+        x, y, _a, t, _f = struct.unpack_from("<hhhhh", things, i * 10)
+        if t == 1:
+            start = np.array([x, y], dtype=np.float64)
+    if start is not None:
+        k = int(np.argmin(((pts - start) ** 2).sum(axis=1)))
+        pts = np.concatenate([pts[k:], pts[:k]])
+    return [(float(x), float(y)) for x, y in pts]

@@ -3,6 +3,7 @@ import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,3 +55,13 @@ def test_rank_routes_are_permutations_of_the_same_loop():
         for r in range(world):
             rr = bench.rank_route(route, r, world)
             assert sorted(rr) == sorted(route) and len(rr) == len(route)
+
+
+def test_route_from_wad_gives_a_closed_walk(synth, campath_mod):
+    """bench.py --wad: any map yields a route (midpoints of its two-sided lines around their centroid, from the FIRST marker)."""
+    for quirks in (False, True):
+        wad = synth.build_synth_iwad(1993, quirks=quirks)
+        r = campath_mod.route_from_wad(wad, "e1m1")
+        assert 8 <= len(r) <= 48 and len(set(r)) > 4
+        path = campath_mod.make_camera_path(r, lambda x, y, d: 0.0, 50)
+        assert path.shape == (50, 8) and np.isfinite(path).all()
