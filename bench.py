@@ -87,7 +87,17 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="gloo")     # timing barrier / MAX only; the data path has no collective
+        # gloo prints its "[Gloo] Rank r is connected to ..." banner on fd 1; stdout must carry only the JSON line
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo")     # timing barrier / MAX only; the data path has no collective
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     torch.cuda.set_device(device)
 
     import numpy as np
