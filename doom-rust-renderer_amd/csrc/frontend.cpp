@@ -310,7 +310,7 @@ struct Walker {
         // visibility was (segs.rs:341-344 runs for every column of the part).  A part lying entirely inside them can
         // neither draw, clip, add a visplane entry nor occlude anything new (segs.rs:211,337-341): it is dropped here.
         if (solid_cols.covers(bot.sx, bot.ex)) return;
-        if (!f.two_sided_mid && full_height) solid_cols.add(bot.sx, bot.ex);
+        if (!f.two_sided_mid && full_height && bot.sx <= bot.ex) solid_cols.add(bot.sx, bot.ex);
         if (parts_mode) {
             if (tex >= 0) {
                 const BitmapInfo &bi = sc.bitmaps[(size_t)tex];
