@@ -109,6 +109,7 @@ _SIGNATURES = {
     "dg_wait": (ctypes.c_int, [_P, ctypes.c_int]),
     "dg_slot_framebuffer": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(_P)]),
     "dg_readback": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "dg_frame_checksums": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     "dg_alloc_host": (_P, [ctypes.c_size_t]),
     "dg_free_host": (None, [_P]),
     "dg_prepare_views": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(DgView), ctypes.c_int]),
@@ -240,6 +241,12 @@ class Context:
         _check(lib().dg_readback(self._h, slot, first, count, out.ctypes.data_as(_P)))
         return out
 
+    def frame_checksums(self, slot: int, first: int, count: int) -> np.ndarray:
+        """One uint64 per frame, computed on the GPU (dg_frame_checksums); `frame_checksum` is the host-side twin."""
+        out = np.zeros(count, dtype=np.uint64)
+        _check(lib().dg_frame_checksums(self._h, slot, first, count, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+        return out
+
     def readback_into(self, slot: int, first: int, count: int, host_ptr: int):
         _check(lib().dg_readback(self._h, slot, first, count, _P(host_ptr)))
 
@@ -263,6 +270,15 @@ class Context:
         if self._h:
             lib().dg_destroy(self._h)
             self._h = None
+
+
+def frame_checksum(rgb24) -> int:
+    """dg_frame_checksums' formula on the host, for one frame given as bytes / uint8 array of length 3*W*H (W % 4 == 0)."""
+    d = np.frombuffer(rgb24, dtype="<u4") if not isinstance(rgb24, np.ndarray) else np.ascontiguousarray(rgb24).reshape(-1).view("<u4")
+    with np.errstate(over="ignore"):
+        i = np.arange(d.size, dtype=np.uint64)
+        m = (d.astype(np.uint64) ^ (i * np.uint64(0x9E3779B97F4A7C15))) * np.uint64(0xBF58476D1CE4E5B9)
+        return int((m ^ (m >> np.uint64(32))).sum(dtype=np.uint64))
 
 
 def declared_symbols() -> list[str]:

@@ -704,6 +704,31 @@ int dg_readback(dg_ctx *c, int slot, int first, int count, uint8_t *out) {
     return DG_OK;
 }
 
+int dg_frame_checksums(dg_ctx *c, int slot, int first, int count, uint64_t *out) {
+    int rc = check_slot(c, slot);
+    if (rc) return rc;
+    Slot &s = c->slots[(size_t)slot];
+    if (!out || first < 0 || count < 0 || first + count > s.n_frames) return set_err(DG_ERR_INVALID, "bad frame range");
+    if (count == 0) return DG_OK;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (s.fe_check) {
+        HIP_TRY(hipStreamSynchronize(s.stream));
+        rc = settle_slot(c, s);
+        if (rc) return rc;
+    }
+    const size_t fsz = (size_t)3 * (size_t)c->cfg.width * (size_t)c->cfg.height;
+    unsigned long long *d_sum = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_sum, (size_t)count * 8));
+    hipError_t e = hipMemsetAsync(d_sum, 0, (size_t)count * 8, s.stream);
+    if (e == hipSuccess) e = launch_checksums(s.d_fb + (size_t)first * fsz, fsz, count, d_sum, s.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_sum, (size_t)count * 8, hipMemcpyDeviceToHost, s.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+    (void)hipFree(d_sum);
+    if (e != hipSuccess) return set_err(DG_ERR_HIP, std::string("dg_frame_checksums: ") + hipGetErrorString(e));
+    s.busy = false;
+    return DG_OK;
+}
+
 void *dg_alloc_host(size_t bytes) {
     void *p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;

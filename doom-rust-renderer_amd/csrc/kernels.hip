@@ -25,6 +25,8 @@
 // divide expansion keeps its own internal FMAs, which is what makes it correctly rounded).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "raster_core.h"
 
@@ -250,6 +252,27 @@ __global__ void dg_row_table(DevScene scene, DevConsts k, uint2 *row_tab) {
     if (y >= k.H) return;
     const float vy = k.CFY - (float)y;
     row_tab[y] = make_uint2(f32_bits(prepare_rcp(vy)), (uint32_t)sky_row(scene, k, y));
+}
+
+// Order-independent per-frame checksum (dg_frame_checksums): every dword is mixed with its index, the mixes are summed.
+// Pure streaming read: 256 dwords per lane-iteration are coalesced, one 64-bit atomic add per wave.
+__global__ __launch_bounds__(256) void dg_checksum(const uint8_t *fb, size_t frame_bytes, unsigned long long *out) {
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(fb + (size_t)blockIdx.y * frame_bytes);
+    const size_t n = frame_bytes / 4;
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long m = ((unsigned long long)d[i] ^ (i * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull;
+        acc += m ^ (m >> 32);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&out[blockIdx.y], acc);
+}
+
+hipError_t launch_checksums(const uint8_t *fb, size_t frame_bytes, int count, unsigned long long *out, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>(256, (frame_bytes / 4 + 255) / 256);
+    hipLaunchKernelGGL(dg_checksum, dim3(blocks, (unsigned)count), dim3(256), 0, stream, fb, frame_bytes, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_row_table(const DevScene &scene, const DevConsts &k, uint2 *row_tab, hipStream_t stream) {

@@ -23,6 +23,8 @@ struct RasterParams {
 
 hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hipStream_t stream);
 hipError_t launch_raster(const RasterParams &P, hipStream_t stream);
+// out[k] = checksum (include/doomgpu.h: dg_frame_checksums) of frame k of `count` consecutive frames of `frame_bytes` bytes at fb; out must be zeroed.
+hipError_t launch_checksums(const uint8_t *fb, size_t frame_bytes, int count, unsigned long long *out, hipStream_t stream);
 // Fills row_tab[0 .. H) for the given scene / frame size (once per dg_upload_scene).
 hipError_t launch_row_table(const DevScene &scene, const DevConsts &k, uint2 *row_tab, hipStream_t stream);
 

@@ -112,6 +112,12 @@ void *dg_alloc_host(size_t bytes);
 void dg_free_host(void *p);
 /* D2H copy of frames [first, first+count) of a completed slot. */
 int dg_readback(dg_ctx *ctx, int slot, int first, int count, uint8_t *rgb24_out);
+/* Frame sink without the PCIe copy: one 64-bit checksum per frame of a finished slot, computed on the GPU over the frame's
+ * RGB24 bytes taken as little-endian dwords d[0 .. 3*W*H/4):
+ *     sum over i of  m ^ (m >> 32),   m = (d[i] ^ (i * 0x9E3779B97F4A7C15)) * 0xBF58476D1CE4E5B9    (all mod 2^64)
+ * so a host that holds reference frames (e.g. `pixels.pixels` dumps of the reference, src/game.rs:521-525) can compare
+ * thousands of large frames by 8 bytes each.  Waits for the slot like dg_readback. */
+int dg_frame_checksums(dg_ctx *ctx, int slot, int first, int count, uint64_t *out);
 
 /* Pre-built list path used by benchmarks that want the raster kernels alone: build + upload lists for n views
  * into the slot (untimed), then dg_replay_slot re-runs only the device work (setup + raster kernels). */

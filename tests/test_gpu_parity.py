@@ -393,3 +393,39 @@ def test_random_views_device_walk_equals_host_lists(dg, synth, campath_mod, orac
         for c in ctxs.values():
             c.close()
     scene.close()
+
+
+def test_device_frame_checksums(dg, scene1993, oracle_scene1993, path1993):
+    """dg_frame_checksums == the same formula on the host, for GPU frames and (through them) for oracle frames."""
+    W, H = 320, 200
+    idx = list(range(0, 1000, 25))
+    ctx = make_ctx(dg, scene1993, W, H, len(idx), slots=1)
+    out = ctx.render(dg.make_views(path1993[idx]))
+    sums = ctx.frame_checksums(0, 0, len(idx))
+    for k, i in enumerate(idx):
+        assert int(sums[k]) == dg.frame_checksum(out[k]) == dg.frame_checksum(oracle_scene1993.render(W, H, path1993[i])), f"frame {i}"
+    assert len(set(int(s) for s in sums)) == len(idx)                   # 40 different frames, 40 different sums
+    part = ctx.frame_checksums(0, 7, 5)
+    assert list(part) == list(sums[7:12])
+    with pytest.raises(dg.DoomGpuError):
+        ctx.frame_checksums(0, 38, 5)
+    ctx.close()
+
+
+def test_full_path_2560x1600_by_checksums(dg, scene1994, oracle_scene1994, path1994):
+    """BASELINE config 5 shape at full size: all 1 000 frames of the heavy map at 2560x1600 through both front ends, compared
+    by device checksums (8 bytes per 12 MB frame); every 125th frame also against the oracle's frame."""
+    W, H, B = 2560, 1600, 50
+    ctxs = {fe: make_ctx(dg, scene1994, W, H, B, slots=1, front_end=fe) for fe in (dg.DG_FE_HOST, dg.DG_FE_DEVICE)}
+    for b0 in range(0, 1000, B):
+        views = dg.make_views(path1994[b0:b0 + B])
+        sums = {}
+        for fe, ctx in ctxs.items():
+            ctx.submit(0, views)
+            ctx.wait(0)
+            sums[fe] = ctx.frame_checksums(0, 0, B)
+        assert list(sums[dg.DG_FE_HOST]) == list(sums[dg.DG_FE_DEVICE]), f"batch at {b0}"
+        if b0 % 125 == 0:
+            assert int(sums[dg.DG_FE_DEVICE][0]) == dg.frame_checksum(oracle_scene1994.render(W, H, path1994[b0])), f"frame {b0}"
+    for c in ctxs.values():
+        c.close()
