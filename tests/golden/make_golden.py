@@ -6,6 +6,8 @@ What is pinned and by what:
   * campath_*.f32        the 1000-frame camera paths: raw little-endian f32 [1000][8] =
                          x, y, angle, cos, sin, cos(-a), sin(-a), floor_height (camera_path.view_record)
   * frames_*.json        sha256 of ORACLE frames (oracle/doomref.c) at sampled path frames and sizes
+  * checksums_*.json     dg_frame_checksums value (include/doomgpu.h) of EVERY oracle frame of the 1000-frame paths at
+                         1280x800 (the bench size): the GPU tier compares all of them without moving a frame over PCIe
 
 The reference itself ships no fixtures and cannot be run here, so these vectors pin the in-repo CPU
 restatement against regressions ("parity unpinned" w.r.t. the Rust binary).
@@ -30,6 +32,30 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 SIZES = {"320x200": list(range(0, 1000, 25)), "1280x800": [0, 100, 297, 323, 623, 728], "1024x768": [5, 505], "2560x1600": [728]}
 
 
+def full_path_checksums(wad, path, W, H):
+    """Checksum (doom-rust-renderer_amd.frame_checksum = dg_frame_checksums' formula) of every oracle frame of the path, as hex
+    strings; the frames are sharded over threads, one oracle scene each (its lazy caches are per scene)."""
+    import threading
+    dgpy = importlib.import_module("doom-rust-renderer_amd")
+    n = min(8, os.cpu_count() or 1)
+    scenes = [doomref.Scene(wad, "e1m1") for _ in range(n)]
+    out = [None] * len(path)
+
+    def work(t):
+        buf = np.empty(3 * W * H, dtype=np.uint8)
+        for i in range(t, len(path), n):
+            scenes[t].render(W, H, path[i], out=buf.ctypes.data)
+            out[i] = f"{dgpy.frame_checksum(buf):016x}"
+    th = [threading.Thread(target=work, args=(t,)) for t in range(n)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for sc in scenes:
+        sc.close()
+    return out
+
+
 def main():
     wads = {}
     for seed, heavy in ((1993, False), (1994, True)):
@@ -48,6 +74,8 @@ def main():
         frames["320x200@t=0.4"] = {str(i): hashlib.sha256(sc.render(W, H, list(path[i]) + [0.4])).hexdigest() for i in (50, 240, 500)}
         json.dump(frames, open(os.path.join(OUT, f"frames_seed{seed}.json"), "w"), indent=1, sort_keys=True)
         sc.close()
+        json.dump({"size": "1280x800", "checksums": full_path_checksums(wad, path, 1280, 800)},
+                  open(os.path.join(OUT, f"checksums_seed{seed}_1280x800.json"), "w"))
     json.dump(wads, open(os.path.join(OUT, "synth_wad.json"), "w"), indent=1, sort_keys=True)
 
 

@@ -429,3 +429,23 @@ def test_full_path_2560x1600_by_checksums(dg, scene1994, oracle_scene1994, path1
             assert int(sums[dg.DG_FE_DEVICE][0]) == dg.frame_checksum(oracle_scene1994.render(W, H, path1994[b0])), f"frame {b0}"
     for c in ctxs.values():
         c.close()
+
+
+@pytest.mark.parametrize("seed", [1993, 1994])
+def test_every_frame_of_both_paths_at_1280x800_against_the_oracle_checksums(dg, scene1993, scene1994, path1993, path1994, seed):
+    """BASELINE configs 2 and 3/4 in full: all 1 000 frames at the bench size, both front ends, against the committed
+    checksums of the oracle's frames (tests/golden/checksums_seed*_1280x800.json) — no frame crosses PCIe."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"checksums_seed{seed}_1280x800.json")))["checksums"]
+    scene, path = (scene1993, path1993) if seed == 1993 else (scene1994, path1994)
+    W, H, B = 1280, 800, 250
+    for fe in (dg.DG_FE_DEVICE, dg.DG_FE_HOST):
+        ctx = make_ctx(dg, scene, W, H, B, slots=1, front_end=fe)
+        for b0 in range(0, 1000, B):
+            ctx.submit(0, dg.make_views(path[b0:b0 + B]))
+            ctx.wait(0)
+            got = [f"{int(v):016x}" for v in ctx.frame_checksums(0, 0, B)]
+            bad = [b0 + k for k in range(B) if got[k] != gold[b0 + k]]
+            assert not bad, f"front end {fe}: frames {bad[:10]} differ from the oracle"
+        ctx.close()
