@@ -111,6 +111,11 @@ struct Slot {
     DevRSpan *d_rspans = nullptr;
     uint8_t *d_fb = nullptr;
     size_t lists_cap = 0;
+    // strip path (dg_resolve_columns -> dg_raster_strips): segments [F][seg_cap][W], band index, overlay index, flags
+    DevSeg *d_segs = nullptr;
+    uint8_t *d_band_first = nullptr;
+    uint16_t *d_ov_first = nullptr;
+    uint32_t *d_strip_ovl = nullptr, *d_frame_flags = nullptr;
     // last submission
     RasterParams P{};
     uint32_t max_spans = 0;
@@ -149,6 +154,9 @@ struct dg_ctx {
     // device scene
     uint32_t *d_palette = nullptr;
     uint8_t *d_texel_idx = nullptr, *d_texel_opq = nullptr, *d_flats = nullptr;
+    uint8_t *d_pool = nullptr;          // row-major texel plane + flats, the strip rasteriser's texel source
+    bool strips = true;                 // dg_resolve_columns + dg_raster_strips + overlay (DOOMGPU_STRIPS=0: dg_raster_tiles alone)
+    int seg_cap = 32, band_rows = 1, n_bands = 1;
     uint2 *d_row_tab = nullptr;         // per-row constants of the flat / sky mappers (dg_row_table), rebuilt per scene upload
     DevScene dscene{};
     std::vector<Slot> slots;
@@ -183,6 +191,11 @@ void free_ctx(dg_ctx *c) {
         if (s.d_lists) (void)hipFree(s.d_lists);
         if (s.d_rspans) (void)hipFree(s.d_rspans);
         if (s.d_fb) (void)hipFree(s.d_fb);
+        if (s.d_segs) (void)hipFree(s.d_segs);
+        if (s.d_band_first) (void)hipFree(s.d_band_first);
+        if (s.d_ov_first) (void)hipFree(s.d_ov_first);
+        if (s.d_strip_ovl) (void)hipFree(s.d_strip_ovl);
+        if (s.d_frame_flags) (void)hipFree(s.d_frame_flags);
         if (s.h_fe) (void)hipHostFree(s.h_fe);
         if (s.d_fe) (void)hipFree(s.d_fe);
         if (s.d_fe_coloff) (void)hipFree(s.d_fe_coloff);
@@ -198,11 +211,17 @@ void free_ctx(dg_ctx *c) {
     if (c->d_texel_idx) (void)hipFree(c->d_texel_idx);
     if (c->d_texel_opq) (void)hipFree(c->d_texel_opq);
     if (c->d_flats) (void)hipFree(c->d_flats);
+    if (c->d_pool) (void)hipFree(c->d_pool);
     if (c->d_row_tab) (void)hipFree(c->d_row_tab);
     if (c->d_fe_cnt) (void)hipFree(c->d_fe_cnt);
     if (c->d_fe_cspans) (void)hipFree(c->d_fe_cspans);
     if (c->d_fe_recs) (void)hipFree(c->d_fe_recs);
     delete c;
+}
+
+void fill_strip_params(const dg_ctx *c, const Slot &s, RasterParams &P) {
+    P.segs = s.d_segs; P.band_first = s.d_band_first; P.ov_first = s.d_ov_first; P.strip_ovl = s.d_strip_ovl; P.frame_flags = s.d_frame_flags;
+    P.seg_cap = c->seg_cap; P.band_rows = c->band_rows; P.n_bands = c->n_bands; P.strips = c->strips ? 1 : 0;
 }
 
 // Build + bin the lists of n views in parallel, pack them into the slot's pinned slab, fill slot.P.
@@ -270,6 +289,7 @@ int build_batch_host(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_li
     P.fb = s.d_fb;
     P.row_tab = c->d_row_tab;
     P.n_frames = n;
+    fill_strip_params(c, s, P);
     s.max_spans = max_spans; s.n_spans = spans; s.covered = covered; s.n_frames = n; s.n_walls = walls; s.n_planes = planes;
     s.list_bytes = total;
     s.fe_mode = false; s.fe_check = false;
@@ -377,6 +397,7 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     P.fb = s.d_fb;
     P.row_tab = c->d_row_tab;
     P.n_frames = n;
+    fill_strip_params(c, s, P);
     s.max_spans = 0; s.n_spans = 0; s.covered = 0; s.n_frames = n; s.n_walls = parts; s.n_planes = sprites;
     s.list_bytes = total;
     s.fe_mode = true; s.fe_check = false;
@@ -564,6 +585,15 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     const size_t lists_cap = align_up(F * sizeof(DevFrame), 256) + align_up(F * (W + 1) * 4, 256) +
                              align_up(c->wall_cap_per_batch * sizeof(DevWallRec), 256) +
                              align_up(c->plane_cap_per_batch * sizeof(DevPlaneRec), 256) + c->span_cap_per_batch * sizeof(DevSpan) + 1024;
+    // Strip rasteriser: segment slots per screen column (a frame with a column that needs more is rendered by dg_raster_tiles
+    // alone; DOOMGPU_SEG_SLOTS trades HBM, 32 B x slots x width x max_batch per slot, against that), rows per band.
+    if (const char *e = std::getenv("DOOMGPU_STRIPS")) c->strips = std::strtol(e, nullptr, 10) != 0;
+    if (const char *e = std::getenv("DOOMGPU_SEG_SLOTS")) {
+        const long v = std::strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 255) c->seg_cap = (int)v;
+    }
+    c->band_rows = strip_band_rows(cfg->height);
+    c->n_bands = (cfg->height + c->band_rows - 1) / c->band_rows;
     c->fe_enabled = cfg->front_end != DG_FE_HOST;
     if (c->fe_enabled) {
         // Scratch slots per screen column (spans and wall-record columns).  A column that needs more sends its batch through
@@ -605,6 +635,13 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         CTX_TRY(hipMalloc((void **)&s.d_lists, lists_cap));
         CTX_TRY(hipMalloc((void **)&s.d_rspans, c->span_cap_per_batch * sizeof(DevRSpan)));
         CTX_TRY(hipMalloc((void **)&s.d_fb, F * 3 * W * H));
+        if (c->strips) {
+            CTX_TRY(hipMalloc((void **)&s.d_segs, F * (size_t)c->seg_cap * W * sizeof(DevSeg)));
+            CTX_TRY(hipMalloc((void **)&s.d_band_first, F * (size_t)c->n_bands * W));
+            CTX_TRY(hipMalloc((void **)&s.d_ov_first, F * W * 2));
+            CTX_TRY(hipMalloc((void **)&s.d_strip_ovl, F * ((W + 63) / 64) * 4));
+            CTX_TRY(hipMalloc((void **)&s.d_frame_flags, F * 4));
+        }
         if (c->fe_enabled) {
             CTX_TRY(hipHostMalloc((void **)&s.h_fe, c->fe_slab_cap, hipHostMallocDefault));
             CTX_TRY(hipMalloc((void **)&s.d_fe, c->fe_slab_cap));
@@ -631,6 +668,9 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     if (c->d_texel_idx) { (void)hipFree(c->d_texel_idx); c->d_texel_idx = nullptr; }
     if (c->d_texel_opq) { (void)hipFree(c->d_texel_opq); c->d_texel_opq = nullptr; }
     if (c->d_flats) { (void)hipFree(c->d_flats); c->d_flats = nullptr; }
+    if (c->d_pool) { (void)hipFree(c->d_pool); c->d_pool = nullptr; }
+    // the slots' prepared records point into the device scene that was just freed: nothing may be replayed from them
+    for (Slot &s : c->slots) { s.n_frames = 0; s.timed = false; s.fe_check = false; s.busy = false; }
     uint32_t pal[256];
     for (int i = 0; i < 256; i++) pal[i] = (uint32_t)sc.palette[3 * i] | ((uint32_t)sc.palette[3 * i + 1] << 8) | ((uint32_t)sc.palette[3 * i + 2] << 16);
     const size_t nt = std::max<size_t>(sc.texel_idx.size(), 16), nf = std::max<size_t>(sc.flat_pool.size(), 16);
@@ -644,8 +684,12 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
         HIP_TRY(hipMemcpy(c->d_texel_opq, sc.texel_opq.data(), sc.texel_opq.size(), hipMemcpyHostToDevice));
     }
     if (!sc.flat_pool.empty()) HIP_TRY(hipMemcpy(c->d_flats, sc.flat_pool.data(), sc.flat_pool.size(), hipMemcpyHostToDevice));
+    std::vector<uint8_t> pool;
+    const uint32_t pool_flats = sc.build_strip_pool(pool);
+    HIP_TRY(hipMalloc((void **)&c->d_pool, std::max<size_t>(pool.size(), 16)));
+    if (!pool.empty()) HIP_TRY(hipMemcpy(c->d_pool, pool.data(), pool.size(), hipMemcpyHostToDevice));
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
-    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
+    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, c->d_pool, pool_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
     if (!c->d_row_tab) HIP_TRY(hipMalloc((void **)&c->d_row_tab, (size_t)c->cfg.height * sizeof(uint2)));
     HIP_TRY(launch_row_table(c->dscene, c->dk, c->d_row_tab, nullptr));
     HIP_TRY(hipDeviceSynchronize());

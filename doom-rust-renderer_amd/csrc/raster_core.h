@@ -166,12 +166,12 @@ DG_HD DevRSpan resolve_wall_span(const DevSpan &sp, const DevWallRec &r) {
     DevRSpan o;
     o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_WALL, r.has_holes != 0);
     o.w[1] = f32_bits(d);
-    o.w[2] = r.texel_off + (uint32_t)tx * (uint32_t)h;
+    o.w[2] = r.texel_off;
     o.w[3] = f32_bits(light_factor(r.lightf, z));
     o.w[4] = d == 0.0f ? 0x7fc00000u : f32_bits(r.uy1);
     o.w[5] = (uint32_t)(uint16_t)sp.top_y | ((uint32_t)(uint16_t)r.off_y << 16);
-    o.w[6] = (uint32_t)SPAN_WALL | (r.has_holes ? 0x100u : 0u) | ((uint32_t)(uint16_t)h << 16);
-    o.w[7] = f32_bits(prepare_rcp(d));
+    o.w[6] = (uint32_t)(uint16_t)h | ((uint32_t)(uint16_t)r.w << 16);
+    o.w[7] = (uint32_t)tx;
     return o;
 }
 DG_HD DevRSpan resolve_flat_span(const DevSpan &sp, const DevPlaneRec &p, const DevConsts &k) {
@@ -184,7 +184,7 @@ DG_HD DevRSpan resolve_flat_span(const DevSpan &sp, const DevPlaneRec &p, const 
     o.w[3] = 0;
     o.w[4] = f32_bits(p.gwz);                                            // numerator of wx = GCFX * wz / vy (visplanes.rs:113)
     o.w[5] = f32_bits(p.lightf);
-    o.w[6] = (uint32_t)SPAN_FLAT | ((div_guard_ok(wzvx) && div_guard_ok(p.gwz)) ? 0x100u : 0u);
+    o.w[6] = (div_guard_ok(wzvx) && div_guard_ok(p.gwz)) ? 0x100u : 0u;
     o.w[7] = 0;
     return o;
 }
@@ -196,22 +196,26 @@ DG_HD DevRSpan resolve_sky_span(const DevSpan &sp, const DevScene &sc, const Dev
     o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_SKY, sc.sky_has_holes != 0);   // a sky bitmap with holes is evaluated in draw order
     o.w[1] = 0;
     o.w[2] = (tx < 0 || tx >= sc.sky_w) ? 0xffffffffu : sc.sky_texel_off + (uint32_t)tx * (uint32_t)sc.sky_h;
-    o.w[3] = o.w[4] = o.w[5] = 0;
-    o.w[6] = (uint32_t)SPAN_SKY;
-    o.w[7] = 0;
+    o.w[3] = o.w[4] = o.w[5] = o.w[6] = 0;
+    o.w[7] = (tx < 0 || tx >= sc.sky_w) ? 0xffffffffu : (uint32_t)tx;
     return o;
 }
 
 // ---- per pixel (all span words are wave-uniform on the GPU) ----------------------------------------------------------
 
-// Texel offset of one wall pixel (bitmap_render.rs:256-263).  fy = y as f32.
-DG_HD uint32_t wall_texel_offset(uint32_t w1, uint32_t w2, uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7, int32_t y) {
-    const int32_t top_y = lo_i16(w5), off_y = hi_i16(w5), h = (int32_t)(w6 >> 16);
-    const float ay = div_prepared((float)(y - top_y), bits_f32(w1), bits_f32(w7));
-    int32_t ty = f32_as_i16((float)h + ay * bits_f32(w4));
+// Texture row of one wall pixel (bitmap_render.rs:256-263): d, uy1, top_y | off_y << 16, h and the prepared reciprocal of d.
+DG_HD int32_t wall_texel_row(float d, float r_d, float uy1, uint32_t w5, int32_t h, int32_t y) {
+    const int32_t top_y = lo_i16(w5), off_y = hi_i16(w5);
+    const float ay = div_prepared((float)(y - top_y), d, r_d);
+    int32_t ty = f32_as_i16((float)h + ay * uy1);
     ty = wrap_i16(ty + off_y);
     const int32_t mask = (h & (h - 1)) == 0 ? h - 1 : 0;
-    return w2 + (uint32_t)floor_mod_fast(ty, h, mask, mask ? 0.0f : approx_rcp((float)h));
+    return floor_mod_fast(ty, h, mask, mask ? 0.0f : approx_rcp((float)h));
+}
+// Texel offset of one wall pixel in the column-major planes (DevRSpan words, dg_raster_tiles).
+DG_HD uint32_t wall_texel_offset(uint32_t w1, uint32_t w2, uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7, int32_t y) {
+    const int32_t h = (int32_t)(w6 & 0xffffu);
+    return w2 + w7 * (uint32_t)h + (uint32_t)wall_texel_row(bits_f32(w1), prepare_rcp(bits_f32(w1)), bits_f32(w4), w5, h, y);
 }
 
 // Texture coordinates of one floor / ceiling pixel and its light factor (visplanes.rs:108-126).

@@ -15,6 +15,7 @@
 #include "../../doom-rust-renderer_amd/csrc/frontend.hpp"
 #include "../../doom-rust-renderer_amd/csrc/raster_core.h"
 #include "../../doom-rust-renderer_amd/csrc/scene.hpp"
+#include "../../doom-rust-renderer_amd/csrc/strip_core.h"
 
 using namespace dg;
 
@@ -33,7 +34,7 @@ static void raster_spans(const DevScene &ds, const DevConsts &k, const DevFrame 
                 const uint32_t kind = w0_kind(w[0]);
                 if (kind == SPAN_WALL) {
                     uint32_t o = wall_texel_offset(w[1], w[2], w[4], w[5], w[6], w[7], y);
-                    if (!(w[6] & 0x100u) || ds.texel_opq[o]) { c = shade(pal[ds.texel_idx[o]], bits_f32(w[3])); wr = true; }
+                    if (!w0_immediate(w[0]) || ds.texel_opq[o]) { c = shade(pal[ds.texel_idx[o]], bits_f32(w[3])); wr = true; }
                 } else if (kind == SPAN_FLAT) {
                     float factor;
                     const float vy = k.CFY - (float)y;
@@ -50,6 +51,84 @@ static void raster_spans(const DevScene &ds, const DevConsts &k, const DevFrame 
             }
         }
     }
+}
+
+// The strip path (dg_resolve_columns + dg_raster_strips + dg_raster_tiles in overlay mode) on the same span lists:
+// resolve every column's opaque prefix into segments, walk them top to bottom (lane = column), then apply the overlay
+// spans in draw order.  Returns false (and says why) when the result differs from raster_spans' or when a band index is off.
+static bool raster_strips_check(const Scene &sc, DevScene ds, const DevConsts &k, const DevFrame &hdr, const uint32_t *pal, const uint32_t *col_off,
+                                const DevRSpan *rs, int W, int H, const uint8_t *expect) {
+    std::vector<uint8_t> pool;
+    ds.pool_flats = sc.build_strip_pool(pool);
+    ds.pool = pool.data();
+    int band_rows = std::max(1, (H + 8 * ((H + 511) / 512) - 1) / (8 * ((H + 511) / 512)));   // = strip_band_rows(H), kernels.hip
+    const int n_bands = (H + band_rows - 1) / band_rows;
+    const uint32_t cap = 255;
+    std::vector<DevSeg> segs((size_t)cap);
+    std::vector<uint8_t> bands((size_t)n_bands), rgb((size_t)3 * W * H, 0);
+    for (int x = 0; x < W; x++) {
+        const uint32_t n = col_off[x + 1] - col_off[x];
+        const DevRSpan *sp = rs + col_off[x];
+        const ResolveResult r = resolve_column(sp, n, ds, H, band_rows, cap, segs.data(), 1, bands.data(), 1);
+        if (r.n_segs == 0xffffffffu) { g_err = "strip path: more than 255 segments in a column"; return false; }
+        if (r.n_segs == 0 || seg_end(segs[r.n_segs - 1].w[0]) != H - 1) { g_err = "strip path: segments do not end at H - 1"; return false; }
+        int start = 0;
+        for (uint32_t s = 0; s < r.n_segs; s++) {                    // dg_raster_strips: one lane, all rows
+            const uint32_t *w = segs[s].w;
+            const int end = seg_end(w[0]);
+            if (end < start) { g_err = "strip path: empty or unsorted segment"; return false; }
+            for (int b = 0; b < n_bands; b++)
+                if (b * band_rows >= start && b * band_rows <= end && bands[(size_t)b] != s) { g_err = "strip path: band_first is wrong"; return false; }
+            for (int y = start; y <= end; y++) {
+                const uint32_t kind = seg_kind(w[0]);
+                uint32_t off = w[2];
+                float fac = bits_f32(w[3]);
+                const float vy = k.CFY - (float)y;
+                if (kind == SPAN_FLAT) off = seg_flat_offset(hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), fac);
+                else if (kind == SPAN_WALL) off = seg_wall_offset(w[1], w[2], w[4], w[5], w[6], w[7], y);
+                else if (kind == SPAN_SKY) {
+                    const int srow = sky_row(ds, k, y);
+                    if (srow >= 0) off = w[2] + (uint32_t)srow * (uint32_t)ds.sky_w; else { off = 0; fac = 0.0f; }
+                }
+                const uint32_t c = shade(pal[pool[off]], fac);
+                uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
+                p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
+            }
+            start = end + 1;
+        }
+        for (uint32_t i = r.n_base; i < n; i++) {                    // overlay: the spans from the first possibly-transparent one on
+            const uint32_t *w = sp[i].w;
+            if (w0_ctop(w[0]) < r.ov_lo || w0_cbot(w[0]) > r.ov_hi) { g_err = "strip path: overlay rows outside the reported range"; return false; }
+            for (int y = w0_ctop(w[0]); y <= w0_cbot(w[0]); y++) {
+                uint32_t c = 0;
+                bool wr = false;
+                const uint32_t kind = w0_kind(w[0]);
+                if (kind == SPAN_WALL) {
+                    uint32_t o = wall_texel_offset(w[1], w[2], w[4], w[5], w[6], w[7], y);
+                    if (!w0_immediate(w[0]) || ds.texel_opq[o]) { c = shade(pal[ds.texel_idx[o]], bits_f32(w[3])); wr = true; }
+                } else if (kind == SPAN_FLAT) {
+                    float factor;
+                    const float vy = k.CFY - (float)y;
+                    uint32_t o = flat_texel_offset(hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), factor);
+                    c = shade(pal[ds.flats[o]], factor); wr = true;
+                } else {
+                    uint32_t o = sky_texel_offset(w[2], sky_row(ds, k, y));
+                    if (o != 0xffffffffu && ds.texel_opq[o]) { c = pal[ds.texel_idx[o]]; wr = true; }
+                }
+                if (wr) {
+                    uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
+                    p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
+                }
+            }
+        }
+    }
+    if (std::memcmp(rgb.data(), expect, rgb.size()) != 0) {
+        size_t i = 0;
+        while (rgb[i] == expect[i]) i++;
+        g_err = "strip path: pixel (" + std::to_string(i / 3 % (size_t)W) + ", " + std::to_string(i / 3 / (size_t)W) + ") differs from the draw-order replay";
+        return false;
+    }
+    return true;
 }
 
 extern "C" {
@@ -101,6 +180,7 @@ int emul_render(void *scene, int W, int H, const dg_view *view_in, uint8_t *rgb,
                                      : resolve_sky_span(sp, ds, k, bf.hdr);
     }
     raster_spans(ds, k, bf.hdr, pal.data(), bf.col_off.data(), rs.data(), W, H, rgb);
+    if (!raster_strips_check(sc, ds, k, bf.hdr, pal.data(), bf.col_off.data(), rs.data(), W, H, rgb)) return DG_ERR_INVALID;
     if (stats) { stats[0] = bf.spans.size(); stats[1] = bf.walls.size(); stats[2] = bf.planes.size(); stats[3] = bf.covered_pixels; }
     return 0;
 }
@@ -223,6 +303,7 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
         same = std::memcmp(&r, &rspans[i], sizeof r) == 0;
     }
     raster_spans(ds, k, fr, pal.data(), col_off.data(), rspans.data(), W, H, rgb);
+    if (!raster_strips_check(sc, ds, k, fr, pal.data(), col_off.data(), rspans.data(), W, H, rgb)) return DG_ERR_INVALID;
     if (stats) { stats[0] = off; stats[1] = ff.n_parts; stats[2] = ff.n_sprites; stats[3] = flags[0]; stats[4] = same ? 1 : 0; stats[5] = n_gaps; }
     return 0;
 }
