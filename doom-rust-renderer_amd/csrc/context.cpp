@@ -115,7 +115,8 @@ struct Slot {
     DevSeg *d_segs = nullptr;
     uint8_t *d_band_first = nullptr;
     uint16_t *d_ov_first = nullptr;
-    uint32_t *d_strip_ovl = nullptr, *d_frame_flags = nullptr;
+    DevSeg *d_ov_inline = nullptr;
+    uint32_t *d_frame_flags = nullptr, *h_frame_flags = nullptr;   // device: [F] flags followed by the band overlay bytes [F][n_bands][strips]
     // last submission
     RasterParams P{};
     uint32_t max_spans = 0;
@@ -129,6 +130,7 @@ struct Slot {
     uint32_t *d_status = nullptr, *h_status = nullptr;   // [F] overflow flags, [F] spans per frame; on the device followed by the
                                                          // sky event bits (fe_event_words) so that one fill clears both
     FeParams FP{};
+    bool seg_check = false;       // the strip path ran and its per-frame "segment slots exceeded" flags have not been looked at yet
     bool fe_mode = false;         // the last submission went through the device column walk
     bool fe_check = false;        // ... and its overflow flags have not been looked at yet
     std::vector<dg_view> views;   // the views of that submission (to redo it on the host if a capacity overflowed)
@@ -157,7 +159,7 @@ struct dg_ctx {
     uint8_t *d_pool = nullptr;          // row-major texel plane + flats, the strip rasteriser's texel source
     bool strips = true;                 // dg_resolve_columns + dg_raster_strips + overlay (DOOMGPU_STRIPS=0: dg_raster_tiles alone)
     int seg_cap = 32, band_rows = 1, n_bands = 1;
-    uint2 *d_row_tab = nullptr;         // per-row constants of the flat / sky mappers (dg_row_table), rebuilt per scene upload
+    uint4 *d_row_tab = nullptr;         // per-row constants of the flat / sky mappers (dg_row_table), rebuilt per scene upload
     DevScene dscene{};
     std::vector<Slot> slots;
     hipEvent_t last_front = nullptr;    // end of the last column walk: the shared column scratch is free again
@@ -170,6 +172,7 @@ struct dg_ctx {
     // device column walk
     bool fe_enabled = false;            // cfg.front_end asks for it
     bool fe_scene_ok = false;           // ... and the uploaded scene allows it (sky bitmap >= 256x128, see bin_frame)
+    uint64_t fallbacks_fe = 0, fallbacks_seg = 0;   // batches redone because a device-side capacity was exceeded (dg_ctx_fallbacks)
     std::vector<FeFrameOut> fe_out;     // one per frame of a batch
     uint32_t fe_col_slots = FE_DEFAULT_COL_SLOTS;
     size_t fe_part_cap = 0, fe_sprite_cap = 0, fe_behind_cap = 0, fe_bin_cap = 0, fe_sbin_cap = 0, fe_slab_cap = 0;
@@ -194,8 +197,9 @@ void free_ctx(dg_ctx *c) {
         if (s.d_segs) (void)hipFree(s.d_segs);
         if (s.d_band_first) (void)hipFree(s.d_band_first);
         if (s.d_ov_first) (void)hipFree(s.d_ov_first);
-        if (s.d_strip_ovl) (void)hipFree(s.d_strip_ovl);
+        if (s.d_ov_inline) (void)hipFree(s.d_ov_inline);
         if (s.d_frame_flags) (void)hipFree(s.d_frame_flags);
+        if (s.h_frame_flags) (void)hipHostFree(s.h_frame_flags);
         if (s.h_fe) (void)hipHostFree(s.h_fe);
         if (s.d_fe) (void)hipFree(s.d_fe);
         if (s.d_fe_coloff) (void)hipFree(s.d_fe_coloff);
@@ -220,7 +224,9 @@ void free_ctx(dg_ctx *c) {
 }
 
 void fill_strip_params(const dg_ctx *c, const Slot &s, RasterParams &P) {
-    P.segs = s.d_segs; P.band_first = s.d_band_first; P.ov_first = s.d_ov_first; P.strip_ovl = s.d_strip_ovl; P.frame_flags = s.d_frame_flags;
+    P.segs = s.d_segs; P.band_first = s.d_band_first; P.ov_first = s.d_ov_first; P.ov_inline = s.d_ov_inline; P.frame_flags = s.d_frame_flags;
+    P.band_ovl = reinterpret_cast<uint8_t *>(s.d_frame_flags + c->cfg.max_batch);
+    P.band_inl = P.band_ovl + (size_t)c->cfg.max_batch * (size_t)c->n_bands * (size_t)((c->cfg.width + 63) / 64);
     P.seg_cap = c->seg_cap; P.band_rows = c->band_rows; P.n_bands = c->n_bands; P.strips = c->strips ? 1 : 0;
 }
 
@@ -292,7 +298,7 @@ int build_batch_host(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_li
     fill_strip_params(c, s, P);
     s.max_spans = max_spans; s.n_spans = spans; s.covered = covered; s.n_frames = n; s.n_walls = walls; s.n_planes = planes;
     s.list_bytes = total;
-    s.fe_mode = false; s.fe_check = false;
+    s.fe_mode = false; s.fe_check = false; s.seg_check = false;
     s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIP_TRY(hipMemcpyAsync(s.d_lists, s.h_lists, total, hipMemcpyHostToDevice, s.stream));
     return DG_OK;
@@ -400,7 +406,7 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     fill_strip_params(c, s, P);
     s.max_spans = 0; s.n_spans = 0; s.covered = 0; s.n_frames = n; s.n_walls = parts; s.n_planes = sprites;
     s.list_bytes = total;
-    s.fe_mode = true; s.fe_check = false;
+    s.fe_mode = true; s.fe_check = false; s.seg_check = false;
     s.views.assign(views, views + n);
     s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIP_TRY(hipMemcpyAsync(s.d_fe, s.h_fe, total, hipMemcpyHostToDevice, s.stream));
@@ -443,6 +449,10 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
         HIP_TRY(hipMemcpyAsync(s.h_status, s.d_status, (size_t)2 * (size_t)c->cfg.max_batch * 4, hipMemcpyDeviceToHost, s.stream));
         s.fe_check = true;
     }
+    if (s.P.strips) {
+        HIP_TRY(hipMemcpyAsync(s.h_frame_flags, s.d_frame_flags, (size_t)s.n_frames * 4, hipMemcpyDeviceToHost, s.stream));
+        s.seg_check = true;
+    }
     s.busy = true; s.timed = true;
     return DG_OK;
 }
@@ -450,22 +460,40 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
 // After the slot's stream has been synchronised: look at the overflow flags of a device-column-walk submission; a batch
 // that overflowed a per-column / per-frame capacity is redone through the host list path (which has the larger limits).
 int settle_slot(dg_ctx *c, Slot &s) {
-    if (!s.fe_check) return DG_OK;
-    s.fe_check = false;
-    bool overflow = false;
-    uint64_t spans = 0;
-    for (int i = 0; i < s.n_frames; i++) {
-        overflow |= s.h_status[i] != 0;
-        spans += s.h_status[c->cfg.max_batch + i];
+    if (s.fe_check) {
+        s.fe_check = false;
+        bool overflow = false;
+        uint64_t spans = 0;
+        for (int i = 0; i < s.n_frames; i++) {
+            overflow |= s.h_status[i] != 0;
+            spans += s.h_status[c->cfg.max_batch + i];
+        }
+        s.n_spans = spans;
+        if (overflow) {
+            c->fallbacks_fe++;
+            s.seg_check = false;
+            const std::vector<dg_view> views = s.views;
+            int rc = build_batch_host(c, s, views.data(), nullptr, (int)views.size());
+            if (rc) return rc;
+            rc = enqueue_kernels(c, s);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(s.stream));
+        }
     }
-    s.n_spans = spans;
-    if (!overflow) return DG_OK;
-    const std::vector<dg_view> views = s.views;
-    int rc = build_batch_host(c, s, views.data(), nullptr, (int)views.size());
-    if (rc) return rc;
-    rc = enqueue_kernels(c, s);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    // A column that needed more segment slots than the ctx was created with: dg_raster_strips skipped that frame; the batch
+    // is rasterised again from the same span lists by dg_raster_tiles, which has no such limit (same pixels either way).
+    if (s.seg_check) {
+        s.seg_check = false;
+        bool overflow = false;
+        for (int i = 0; i < s.n_frames; i++) overflow |= s.h_frame_flags[i] != 0;
+        if (overflow) {
+            c->fallbacks_seg++;
+            s.P.strips = 0;
+            hipError_t e = launch_raster(s.P, s.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+            if (e != hipSuccess) return set_err(DG_ERR_HIP, std::string("strip fallback: ") + hipGetErrorString(e));
+        }
+    }
     return DG_OK;
 }
 
@@ -639,8 +667,9 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
             CTX_TRY(hipMalloc((void **)&s.d_segs, F * (size_t)c->seg_cap * W * sizeof(DevSeg)));
             CTX_TRY(hipMalloc((void **)&s.d_band_first, F * (size_t)c->n_bands * W));
             CTX_TRY(hipMalloc((void **)&s.d_ov_first, F * W * 2));
-            CTX_TRY(hipMalloc((void **)&s.d_strip_ovl, F * ((W + 63) / 64) * 4));
-            CTX_TRY(hipMalloc((void **)&s.d_frame_flags, F * 4));
+            CTX_TRY(hipMalloc((void **)&s.d_ov_inline, F * W * sizeof(DevSeg)));
+            CTX_TRY(hipMalloc((void **)&s.d_frame_flags, F * 4 + 2 * F * (size_t)c->n_bands * ((W + 63) / 64)));
+            CTX_TRY(hipHostMalloc((void **)&s.h_frame_flags, F * 4, hipHostMallocDefault));
         }
         if (c->fe_enabled) {
             CTX_TRY(hipHostMalloc((void **)&s.h_fe, c->fe_slab_cap, hipHostMallocDefault));
@@ -670,7 +699,7 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     if (c->d_flats) { (void)hipFree(c->d_flats); c->d_flats = nullptr; }
     if (c->d_pool) { (void)hipFree(c->d_pool); c->d_pool = nullptr; }
     // the slots' prepared records point into the device scene that was just freed: nothing may be replayed from them
-    for (Slot &s : c->slots) { s.n_frames = 0; s.timed = false; s.fe_check = false; s.busy = false; }
+    for (Slot &s : c->slots) { s.n_frames = 0; s.timed = false; s.fe_check = false; s.seg_check = false; s.busy = false; }
     uint32_t pal[256];
     for (int i = 0; i < 256; i++) pal[i] = (uint32_t)sc.palette[3 * i] | ((uint32_t)sc.palette[3 * i + 1] << 8) | ((uint32_t)sc.palette[3 * i + 2] << 16);
     const size_t nt = std::max<size_t>(sc.texel_idx.size(), 16), nf = std::max<size_t>(sc.flat_pool.size(), 16);
@@ -685,12 +714,13 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     }
     if (!sc.flat_pool.empty()) HIP_TRY(hipMemcpy(c->d_flats, sc.flat_pool.data(), sc.flat_pool.size(), hipMemcpyHostToDevice));
     std::vector<uint8_t> pool;
-    const uint32_t pool_flats = sc.build_strip_pool(pool);
+    uint32_t pool_opq = 0;
+    const uint32_t pool_flats = sc.build_strip_pool(pool, pool_opq);
     HIP_TRY(hipMalloc((void **)&c->d_pool, std::max<size_t>(pool.size(), 16)));
     if (!pool.empty()) HIP_TRY(hipMemcpy(c->d_pool, pool.data(), pool.size(), hipMemcpyHostToDevice));
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
-    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, c->d_pool, pool_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
-    if (!c->d_row_tab) HIP_TRY(hipMalloc((void **)&c->d_row_tab, (size_t)c->cfg.height * sizeof(uint2)));
+    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, c->d_pool, pool_flats, pool_opq, sky.texel_off, sky.w, sky.h, sky.has_holes};
+    if (!c->d_row_tab) HIP_TRY(hipMalloc((void **)&c->d_row_tab, (size_t)c->cfg.height * sizeof(uint4)));
     HIP_TRY(launch_row_table(c->dscene, c->dk, c->d_row_tab, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     c->scene = &sc;
@@ -737,7 +767,7 @@ int dg_readback(dg_ctx *c, int slot, int first, int count, uint8_t *out) {
     if (!out || first < 0 || count < 0 || first + count > s.n_frames) return set_err(DG_ERR_INVALID, "bad readback range");
     HIP_TRY(hipSetDevice(c->cfg.device));
     const size_t fsz = (size_t)3 * (size_t)c->cfg.width * (size_t)c->cfg.height;
-    if (s.fe_check) {
+    if (s.fe_check || s.seg_check) {
         HIP_TRY(hipStreamSynchronize(s.stream));
         rc = settle_slot(c, s);
         if (rc) return rc;
@@ -755,7 +785,7 @@ int dg_frame_checksums(dg_ctx *c, int slot, int first, int count, uint64_t *out)
     if (!out || first < 0 || count < 0 || first + count > s.n_frames) return set_err(DG_ERR_INVALID, "bad frame range");
     if (count == 0) return DG_OK;
     HIP_TRY(hipSetDevice(c->cfg.device));
-    if (s.fe_check) {
+    if (s.fe_check || s.seg_check) {
         HIP_TRY(hipStreamSynchronize(s.stream));
         rc = settle_slot(c, s);
         if (rc) return rc;
@@ -812,11 +842,12 @@ int dg_replay_slot(dg_ctx *c, int slot) {
     Slot &s = c->slots[(size_t)slot];
     if (s.n_frames <= 0) return set_err(DG_ERR_INVALID, "slot has no prepared lists");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    if (s.fe_check) {             // a submission that was never waited for
+    if (s.fe_check || s.seg_check) {   // a submission that was never waited for
         HIP_TRY(hipStreamSynchronize(s.stream));
         rc = settle_slot(c, s);
         if (rc) return rc;
     }
+    s.P.strips = c->strips ? 1 : 0;   // (a settled overflow switched the slot to dg_raster_tiles: a replay of that batch overflows again)
     rc = enqueue_kernels(c, s);
     s.fe_check = false;           // same records as the run that was checked: the flags cannot differ
     return rc;
@@ -846,7 +877,7 @@ int dg_slot_timing(dg_ctx *c, int slot, dg_timing *out) {
     if (!s.timed) return set_err(DG_ERR_INVALID, "slot has not run yet");
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipEventSynchronize(s.ev_raster));
-    if (s.fe_check) {
+    if (s.fe_check || s.seg_check) {
         HIP_TRY(hipStreamSynchronize(s.stream));
         rc = settle_slot(c, s);
         if (rc) return rc;

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "kernels.hpp"
 #include "raster_core.h"
@@ -114,7 +115,8 @@ __device__ __forceinline__ uint32_t shade_winner(const RasterParams &P, const De
 // One screen column (64 rows of it) for one wavefront, any number of spans (lw0 = word 0 of every span, lsp = all 8 words):
 // lane i looks at span i, a ballot picks the spans touching these rows, one v_readlane per such span.
 __device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const DevFrame &fr, const uint32_t *pal, const uint32_t *lw0,
-                                                  const uint4 *lsp, uint32_t n, int lane, int y, int y0, float vy, float r_vy, int srow, uint32_t color) {
+                                                  const uint4 *lsp, uint32_t n, int lane, int y, int y0, float vy, float r_vy, int srow) {
+    uint32_t color = 0;
     uint32_t winner = 0xffffffffu;            // index (within the column) of the opaque span owning this row
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + (uint32_t)lane;
@@ -137,7 +139,8 @@ __device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const D
 // The same for a column with at most 8 spans whose row filter was done by the wave-level pre-filter (dg_raster_tiles):
 // hm = bit j set when span j touches these rows, its word 0 sits in lane `lane0 + j` of w0f.
 __device__ __forceinline__ uint32_t raster_column_small(const RasterParams &P, const DevFrame &fr, const uint32_t *pal, uint32_t hm, uint32_t w0f,
-                                                        int lane0, const uint4 *lsp, int y, float vy, float r_vy, int srow, uint32_t color) {
+                                                        int lane0, const uint4 *lsp, int y, float vy, float r_vy, int srow) {
+    uint32_t color = 0;
     uint32_t winner = 0xffffffffu;
     while (hm) {
         const int j = __builtin_ctz(hm);
@@ -153,55 +156,27 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
     __shared__ uint32_t lw0[SPAN_CAP];
     __shared__ uint32_t pal[256];
     __shared__ uint32_t lcoff[TILE_W + 1];
-    __shared__ uint32_t lskip[TILE_W];
 
     const int f = blockIdx.z;
+    const DevFrame fr = P.frames[f];
     const int W = P.k.W, H = P.k.H;
     const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
-    // Overlay mode: dg_raster_strips has already written every pixel of this frame from the resolved opaque spans; this kernel
-    // only applies, in draw order, the spans from each column's first possibly-transparent one on (masked walls, sprites).
-    // Tiles that no such span touches leave at once.  A frame whose columns did not fit the segment slots is rendered here
-    // from all of its spans, as is everything when the strip path is off.
-    const bool overlay = P.strips != 0 && P.frame_flags[f] == 0u;
-    if (overlay) {
-        const uint32_t bb = P.strip_ovl[(size_t)f * (size_t)gridDim.x + blockIdx.x];
-        const int lo = (int)(bb & 0xffffu), hi = (int)(bb >> 16);
-        if (lo > hi || hi < y0 || lo > y0 + (TILE_H - 1)) return;
-    }
-    const DevFrame fr = P.frames[f];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int y = y0 + lane;
     const float vy = P.k.CFY - (float)y;      // visplanes.rs:109, a per-row constant
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
     const uint4 *gspans = reinterpret_cast<const uint4 *>(P.rspans + fr.span_base);
-    uint8_t *fb = P.fb + (size_t)f * (size_t)3 * (size_t)W * (size_t)H;
 
-    // the prologue loads are issued together (addresses clamped instead of branching around the loads)
-    const uint2 rt = P.row_tab[y < H ? y : H - 1];                    // prepared reciprocal of vy and the sky row (dg_row_table)
+    // the three prologue loads are issued together (addresses clamped instead of branching around the loads)
+    const uint4 rt = P.row_tab[y < H ? y : H - 1];                    // prepared reciprocal of vy and the sky row (dg_row_table)
     const uint32_t pal_v = P.scene.palette[threadIdx.x & 255];
     const int xc = x0 + (int)(threadIdx.x <= TILE_W ? threadIdx.x : 0);
     const uint32_t coff_v = coff[xc < W ? xc : W];
-    uint32_t skip_v = 0;
-    if (overlay && threadIdx.x < TILE_W) skip_v = P.ov_first[(size_t)f * (size_t)W + (size_t)(xc < W ? xc : W - 1)];
     const float r_vy = bits_f32(rt.x);
     const int srow = (int)rt.y;
     if (threadIdx.x < 256) pal[threadIdx.x] = pal_v;
     if (threadIdx.x <= TILE_W) lcoff[threadIdx.x] = coff_v;
-    if (threadIdx.x < TILE_W) lskip[threadIdx.x] = skip_v;
-    if (overlay) {
-        // read-in: the tile's RGB24 bytes as the strip kernel left them, 12 bytes -> 4 RGBX pixels (the inverse of the read-out)
-        for (int g = threadIdx.x; g < TILE_H * (TILE_W / 4); g += THREADS) {
-            const int row = g >> 4, gc = g & 15;
-            const int yy = y0 + row, xx = x0 + 4 * gc;
-            if (yy < H && xx < W) {
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(fb + ((size_t)yy * (size_t)W + (size_t)xx) * 3);
-                const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
-                *reinterpret_cast<uint4 *>(&tile[row * TILE_STRIDE + 4 * gc]) =
-                    make_uint4(d0 & 0xffffffu, (d0 >> 24) | ((d1 & 0xffffu) << 8), (d1 >> 16) | ((d2 & 0xffu) << 16), d2 >> 8);
-            }
-        }
-    }
     __syncthreads();
 
     // The spans of adjacent columns are one contiguous range of the column-major span array.  Stage as many whole columns
@@ -230,9 +205,8 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
         uint32_t f_n0 = 0, f_n = 0, f_w0 = 0;
         bool f_hit = false;
         if (fcol < c_hi) {
-            const uint32_t skip = lskip[fcol];
-            f_n0 = lcoff[fcol] - t0 + skip;
-            f_n = lcoff[fcol + 1] - lcoff[fcol] - skip;
+            f_n0 = lcoff[fcol] - t0;
+            f_n = lcoff[fcol + 1] - lcoff[fcol];
             if ((uint32_t)fslot < f_n && f_n <= 8u) {
                 f_w0 = lw0[f_n0 + (uint32_t)fslot];
                 f_hit = w0_cbot(f_w0) >= y0 && w0_ctop(f_w0) <= y0 + (TILE_H - 1);
@@ -242,10 +216,9 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
         int k8 = 0;
         for (int c = c_lo + wave; c < c_hi; c += WAVES, k8 += 8) {
             const uint32_t n0 = bcast(f_n0, k8), n = bcast(f_n, k8);
-            const uint32_t base = overlay ? tile[lane * TILE_STRIDE + c] : 0u;     // pixels.rs:10-14: a fresh buffer is all zero
             uint32_t px;
-            if (n > 8u) px = raster_column(P, fr, pal, lw0 + n0, lspans + 2 * n0, n, lane, y, y0, vy, r_vy, srow, base);
-            else px = raster_column_small(P, fr, pal, (uint32_t)(hitm >> k8) & 0xffu, f_w0, k8, lspans + 2 * n0, y, vy, r_vy, srow, base);
+            if (n > 8u) px = raster_column(P, fr, pal, lw0 + n0, lspans + 2 * n0, n, lane, y, y0, vy, r_vy, srow);
+            else px = raster_column_small(P, fr, pal, (uint32_t)(hitm >> k8) & 0xffu, f_w0, k8, lspans + 2 * n0, y, vy, r_vy, srow);
             tile[lane * TILE_STRIDE + c] = px;
         }
 
@@ -256,6 +229,7 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
 
     // Read-out: groups of 4 pixels (16 B of RGBX in LDS -> 12 B of RGB24 in HBM); 16 groups per tile row, so the lanes of
     // a wave cover four tile rows = 4 x 192 contiguous bytes.
+    uint8_t *fb = P.fb + (size_t)f * (size_t)3 * (size_t)W * (size_t)H;
     for (int g = threadIdx.x; g < TILE_H * (TILE_W / 4); g += THREADS) {
         const int row = g >> 4, gc = g & 15;
         const int yy = y0 + row, xx = x0 + 4 * gc;
@@ -274,128 +248,398 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
 
 // ---- strip path ---------------------------------------------------------------------------------------------------------
 
-// One lane per (frame, screen column): strip_core.h resolve_column.  The w0 words it scans are 32 bytes apart in the
-// column's span list; real columns hold 2-8 spans, so the quadratic scan is a few dozen L1-resident loads.  Negligible next
-// to the raster kernels (320 000 columns per launch against 256 M pixels).
+constexpr int RES_STAGE = 48;     // row-range words of a column staged in LDS by dg_resolve_columns (longer columns read HBM)
+
+// One lane per (frame, screen column): strip_core.h resolve_column.  The row-range words (w0) of the column's spans are
+// staged in LDS first (independent loads, all in flight at once), then the scan over boundaries x spans runs out of LDS.
+// Real columns hold 2-8 spans.  Negligible next to the raster kernels (320 000 columns per launch against 256 M pixels).
 __global__ __launch_bounds__(64) void dg_resolve_columns(RasterParams P) {
+    __shared__ uint32_t lw0[RES_STAGE * 64];
     const int f = blockIdx.y;
     const int W = P.k.W, H = P.k.H;
     const int lane = threadIdx.x;
     const int x = (int)blockIdx.x * 64 + lane;
     const DevFrame fr = P.frames[f];
-    int lo = 0x7fff, hi = -1;
-    if (x < W) {
-        const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
-        const uint32_t o = coff[x], n = coff[x + 1] - o;
-        const ResolveResult r = resolve_column(P.rspans + fr.span_base + o, n, P.scene, H, P.band_rows, (uint32_t)P.seg_cap,
-                                               P.segs + (size_t)f * (size_t)P.seg_cap * (size_t)W + (size_t)x, (size_t)W,
-                                               P.band_first + (size_t)f * (size_t)P.n_bands * (size_t)W + (size_t)x, (size_t)W);
-        if (r.n_segs == 0xffffffffu) atomicOr(&P.frame_flags[f], 1u);
-        P.ov_first[(size_t)f * (size_t)W + (size_t)x] = (uint16_t)r.n_base;
-        lo = r.ov_lo; hi = r.ov_hi;
+    if (x >= W) return;                               // no barrier below: the staging area is private to a lane
+    const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
+    const uint32_t o = coff[x], n = coff[x + 1] - o;
+    const DevRSpan *spans = P.rspans + fr.span_base + o;
+    const uint32_t ns = min(n, (uint32_t)RES_STAGE);
+    for (uint32_t j = 0; j < ns; j += 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) v[q] = spans[min(j + q, ns - 1)].w[0];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) if (j + q < ns) lw0[(j + q) * 64 + (uint32_t)lane] = v[q];
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = min(lo, __shfl_xor(lo, o));
-        hi = max(hi, __shfl_xor(hi, o));
+    auto w0_at = [&](uint32_t j) { return j < (uint32_t)RES_STAGE ? lw0[j * 64 + (uint32_t)lane] : spans[j].w[0]; };
+    const ResolveResult r = resolve_column(w0_at, spans, n, P.scene, H, P.band_rows, (uint32_t)P.seg_cap,
+                                           P.segs + (size_t)f * (size_t)P.seg_cap * (size_t)W + (size_t)x, (size_t)W,
+                                           P.band_first + (size_t)f * (size_t)P.n_bands * (size_t)W + (size_t)x, (size_t)W);
+    if (r.n_segs == 0xffffffffu) atomicOr(&P.frame_flags[f], 1u);
+    P.ov_first[(size_t)f * (size_t)W + (size_t)x] = (uint16_t)r.n_base;
+    // Overlay spans.  The common case — exactly one, a masked wall or sprite column — travels with the strip kernel as one
+    // 32-byte record per column (ov_inline) and is applied in the same pass.  Columns with more go to dg_overlay_strips: the
+    // bands their spans touch are flagged (same value from every writer).
+    DevSeg ov = seg_none(0);
+    ov.w[0] = 0x3fffu;                                // first row > last row: no inline overlay
+    if (overlay_is_inline(n - r.n_base, n > r.n_base ? w0_at(r.n_base) : 0u)) {
+        ov = seg_from_span(spans[r.n_base], 0, P.scene);
+        ov.w[0] = w0_at(r.n_base);
+        uint8_t *bi = P.band_inl + (size_t)f * (size_t)P.n_bands * (size_t)gridDim.x + blockIdx.x;
+        for (int b = w0_ctop(ov.w[0]) / P.band_rows; b <= w0_cbot(ov.w[0]) / P.band_rows; b++) bi[(size_t)b * (size_t)gridDim.x] = 1;
+    } else {
+        uint8_t *bo = P.band_ovl + (size_t)f * (size_t)P.n_bands * (size_t)gridDim.x + blockIdx.x;
+        for (uint32_t j = r.n_base; j < n; j++) {
+            const uint32_t w0 = w0_at(j);
+            for (int b = w0_ctop(w0) / P.band_rows; b <= w0_cbot(w0) / P.band_rows; b++) bo[(size_t)b * (size_t)gridDim.x] = 1;
+        }
     }
-    if (lane == 0) P.strip_ovl[(size_t)f * (size_t)gridDim.x + blockIdx.x] = hi < 0 ? 0x0000ffffu : (uint32_t)lo | ((uint32_t)hi << 16);
+    uint4 *od = reinterpret_cast<uint4 *>(P.ov_inline + (size_t)f * (size_t)W + (size_t)x);
+    od[0] = make_uint4(ov.w[0], ov.w[1], ov.w[2], ov.w[3]);
+    od[1] = make_uint4(ov.w[4], ov.w[5], ov.w[6], ov.w[7]);
 }
+
+// What a lane of dg_raster_strips keeps about its column's current segment: the DevSeg words it needs per pixel, unpacked
+// once when the column enters the segment.  q0..q2 mean different things for walls and flats (never both at once).
+enum : uint32_t { CLS_NONE = 0, CLS_FLAT = 1, CLS_WALL = 2, CLS_SKY = 3, CLS_FLAT_SLOW = 4, CLS_WALL_MOD = 5 };
+struct SegRegs {
+    int32_t end;                  // last row of the segment
+    uint32_t cls;                 // CLS_*: kind + which mapper variant is exact for it
+    uint32_t base;                // w2: pool offset (flat / bitmap row 0 + tx / sky row 0 + tx)
+    float fac;                    // w3: light factor of a wall column; 1 for sky, 0 for "nothing drawn"
+    float q0, q1, q2;             // WALL: d, uy1, prepared 1/d          FLAT: wz*vx, gwz, light/255
+    int32_t top_y, off_y;         // WALL
+    float hf;                     // WALL: h as f32
+    int32_t hmask;                // WALL: h - 1 (CLS_WALL: h is a power of two > 1) or h (CLS_WALL_MOD)
+    uint32_t wst;                 // WALL: bitmap width = row stride in the pool
+};
+__device__ __forceinline__ void seg_unpack(const uint4 a, const uint4 b, SegRegs &s) {
+    const uint32_t kind = seg_kind(a.x);
+    s.end = seg_end(a.x); s.base = a.z; s.fac = bits_f32(a.w);
+    s.q0 = bits_f32(a.y); s.q1 = bits_f32(b.x);
+    const int32_t h = (int32_t)(b.z & 0xffffu);
+    const bool pow2 = h > 1 && (h & (h - 1)) == 0;
+    s.top_y = lo_i16(b.y); s.off_y = hi_i16(b.y); s.hf = (float)h; s.wst = b.z >> 16;
+    s.hmask = pow2 ? h - 1 : h;
+    if (kind == SPAN_WALL) { s.q2 = bits_f32(b.w); s.cls = pow2 ? CLS_WALL : CLS_WALL_MOD; }
+    else if (kind == SPAN_FLAT) { s.q2 = bits_f32(b.y); s.cls = (b.z & 1u) ? CLS_FLAT : CLS_FLAT_SLOW; }
+    else { s.q2 = 0.0f; s.cls = kind == SPAN_SKY ? CLS_SKY : CLS_NONE; }
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const u32x4 __attribute__((address_space(4))) *RowTabPtr;   // "constant" address space: wave-uniform reads become scalar loads
 
 // One wavefront per (frame, 64-column strip, band of rows), lane = column.  Every lane keeps its column's current segment in
 // registers (and the next one, prefetched), so a pixel costs its texture mapper and nothing else: no ownership test, no
-// per-pixel parameter fetch, no LDS tile.  The row is wave-uniform: vy, its prepared reciprocal and the sky row come from
-// scalar loads.  Two rows are in flight: the texel of row y + 1 is requested before row y is shaded and stored.  A row of the
-// strip leaves as one 192-byte store: quads of lanes pack their four RGBX pixels into three dwords with one DPP move and one
-// byte permute.  Texels are row-major here (pool), so 64 adjacent columns of a wall row read a handful of cache lines.
-__global__ __launch_bounds__(64) void dg_raster_strips(RasterParams P) {
-    __shared__ uint32_t pal[256];
+// per-pixel parameter fetch, no LDS tile.  The row is wave-uniform; its constants (vy, the prepared 1/vy, the sky row) arrive
+// by scalar loads.  When all 64 columns are inside floors / ceilings, or all inside walls — which is what most rows of most
+// strips look like — the row runs a straight-line mapper without any per-lane kind test (`mode` changes only on rows where
+// some column enters its next segment).  Two rows are in flight: the texel of row y + 1 is requested before row y is shaded.
+// Finished rows are packed to RGB24 by quads of lanes (one DPP move, one byte permute), parked in LDS and leave four at a
+// time, 16 contiguous bytes per lane.  Texels are row-major here (pool), so the 64 adjacent columns of a wall row read a
+// handful of cache lines.
+//
+// OV = this (strip, band) has columns with an inline overlay span (a masked wall or sprite column, strip_core.h): the second
+// instantiation carries that span per lane and applies it in the same pass.  Each (strip, band) is rendered by exactly one
+// of the two kernels (band_inl), so the common one keeps 8 wavefronts per SIMD.
+template <bool OV>
+__device__ __forceinline__ void strips_body(const RasterParams &P, float4 *palf, uint32_t *rowbuf) {
     const int f = blockIdx.z;
-    if (P.frame_flags[f] != 0u) return;               // segment slots exceeded: dg_raster_tiles renders this frame
+    if (P.frame_flags[f] != 0u) return;               // segment slots exceeded: the batch is redone by dg_raster_tiles
+    if ((P.band_inl[((size_t)f * (size_t)P.n_bands + blockIdx.y) * (size_t)gridDim.x + blockIdx.x] != 0) != OV) return;
     const int lane = threadIdx.x;
     const int W = P.k.W, H = P.k.H;
     const int x0 = (int)blockIdx.x * 64;
     const int y_lo = (int)blockIdx.y * P.band_rows;
     const int y_hi = min(H, y_lo + P.band_rows) - 1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) pal[lane + 64 * k] = P.scene.palette[lane + 64 * k];
+    for (int k = 0; k < 4; k++) {
+        const uint32_t c = P.scene.palette[lane + 64 * k];
+        palf[lane + 64 * k] = make_float4((float)(c & 255u), (float)((c >> 8) & 255u), (float)((c >> 16) & 255u), 0.0f);
+    }
     const DevFrame fr = P.frames[f];
     const bool in_w = x0 + lane < W;
-    const int x = in_w ? x0 + lane : W - 1;
+    const int x = in_w ? x0 + lane : W - 1;           // lanes past the right edge shadow the last column and store nothing
     const uint32_t s0 = P.band_first[((size_t)f * (size_t)P.n_bands + blockIdx.y) * (size_t)W + (size_t)x];
-    const uint4 *sp = reinterpret_cast<const uint4 *>(P.segs + ((size_t)f * (size_t)P.seg_cap + s0) * (size_t)W + (size_t)x);
-    const size_t seg_step = (size_t)W * 2;
-    uint4 ca = sp[0], cb = sp[1];
-    uint4 na = ca, nb = cb;
-    sp += seg_step;
-    if (seg_end(ca.x) < H - 1) { na = sp[0]; nb = sp[1]; }
+    const uint8_t *segs_f = reinterpret_cast<const uint8_t *>(P.segs + (size_t)f * (size_t)P.seg_cap * (size_t)W);   // wave-uniform
+    const uint32_t seg_step = (uint32_t)W * 32u;
+    uint32_t seg_at = (s0 * (uint32_t)W + (uint32_t)x) * 32u;       // byte offset of the lane's NEXT segment
+    SegRegs S;
+    uint4 na, nb;
+    {
+        const uint4 ca = *reinterpret_cast<const uint4 *>(segs_f + seg_at), cb = *reinterpret_cast<const uint4 *>(segs_f + seg_at + 16);
+        seg_unpack(ca, cb, S);
+        na = ca; nb = cb;
+        seg_at += seg_step;
+        if (S.end < H - 1) { na = *reinterpret_cast<const uint4 *>(segs_f + seg_at); nb = *reinterpret_cast<const uint4 *>(segs_f + seg_at + 16); }
+    }
     __syncthreads();
     const uint8_t *pool = P.scene.pool;
     const uint32_t sky_w = (uint32_t)P.scene.sky_w;
+    const RowTabPtr rows = (RowTabPtr)(uintptr_t)P.row_tab;
     // lane 4q + j (j < 3) stores dword j of its quad's 12 bytes; selector of v_perm_b32 over {next pixel, own pixel}
     const uint32_t perm_sel = (lane & 3) == 0 ? 0x04020100u : (lane & 3) == 1 ? 0x05040201u : 0x06050402u;
-    const uint32_t st_off = (uint32_t)(lane - (lane >> 2)) * 4u;
-    const bool st_on = in_w && (lane & 3) != 3;
+    // Rows leave four at a time: lane 4q + j (j < 3) parks dword 3q + j of its row in LDS; then lane L < 48 stores 16
+    // contiguous bytes (chunk L % 12 of row L / 12) — one vector-memory instruction per four rows instead of four, which
+    // matters because the texture/store address unit takes ~16 clocks per wave instruction whatever its width.
+    const uint32_t park_at = (uint32_t)(lane - (lane >> 2));
+    const bool park_on = (lane & 3) != 3;
+    const int st_row = lane / 12, st_chunk = lane % 12;
+    const bool st_lane = lane < 48 && x0 + st_chunk * 16 / 3 < W;      // W % 4 == 0: a 16-byte chunk (5 1/3 pixels) lies inside the frame iff its first pixel does
+    const uint32_t st_off = (uint32_t)st_row * (uint32_t)W * 3u + (uint32_t)st_chunk * 16u;
     uint8_t *rowp = P.fb + (((size_t)f * (size_t)H + (size_t)y_lo) * (size_t)W + (size_t)x0) * 3;
+    int parked = 0;                                   // rows in rowbuf
 
-    // per-row constants of this band: lane r holds those of row y_lo + r (band_rows <= 64), broadcast with v_readlane
-    const uint2 rt_l = P.row_tab[min(y_lo + lane, H - 1)];
-
-    // Row y, first half: move to the column's next segment when the row leaves the current one, then the texture mapper of
-    // the segment's kind -> pool offset of the texel and the light factor; the texel load is issued and NOT waited for.
-    auto row_a = [&](int y, uint32_t &tex, float &fac) {
-        if (y > seg_end(ca.x)) {
-            ca = na; cb = nb;
-            if (seg_end(ca.x) < H - 1) { sp += seg_step; na = sp[0]; nb = sp[1]; }
-        }
-        const float r_vy = bits_f32((uint32_t)__builtin_amdgcn_readlane((int)rt_l.x, y - y_lo));
-        const int srow = __builtin_amdgcn_readlane((int)rt_l.y, y - y_lo);
-        const float vy = P.k.CFY - (float)y;
-        const uint32_t kind = seg_kind(ca.x);
-        uint32_t off = ca.z;                          // SEG_NONE: offset 0, factor 0 -> black
-        fac = bits_f32(ca.w);
-        if (kind == SPAN_FLAT) off = seg_flat_offset(fr, ca.y, ca.z, cb.x, cb.y, cb.z, vy, r_vy, fac);
-        else if (kind == SPAN_WALL) off = seg_wall_offset(ca.y, ca.z, cb.x, cb.y, cb.z, cb.w, y);
-        else if (kind == SPAN_SKY) {
-            if (srow >= 0) off = ca.z + (uint32_t)srow * sky_w;
-            else { off = 0; fac = 0.0f; }             // row outside the sky bitmap: nothing is drawn
-        }
-        tex = pool[off];
-    };
-    // Row y, second half: palette, lighting, and the strip's 192 bytes of this row.
-    auto row_b = [&](uint32_t tex, float fac) {
-        const uint32_t px = shade(pal[tex], fac);
-        const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)px, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
-        const uint32_t out = __builtin_amdgcn_perm(nx, px, perm_sel);
-        if (st_on) *reinterpret_cast<uint32_t *>(rowp + st_off) = out;
-        rowp += (size_t)W * 3;
-    };
-    uint32_t tex_a, tex_b = 0;
-    float fac_a, fac_b = 0.0f;
-    row_a(y_lo, tex_a, fac_a);
-    int y = y_lo;
-    for (; y + 2 <= y_hi; y += 2) {                   // two rows per trip so that the in-flight texel needs no register move
-        row_a(y + 1, tex_b, fac_b);
-        row_b(tex_a, fac_a);
-        row_a(y + 2, tex_a, fac_a);
-        row_b(tex_b, fac_b);
+    // the column's inline overlay span, clipped to this band (o_t > o_b: none)
+    uint4 oa = make_uint4(0x3fffu, 0, 0, 0), ob = make_uint4(0, 0, 0, 0);
+    if constexpr (OV) {
+        oa = reinterpret_cast<const uint4 *>(P.ov_inline + (size_t)f * (size_t)W + (size_t)x)[0];
+        ob = reinterpret_cast<const uint4 *>(P.ov_inline + (size_t)f * (size_t)W + (size_t)x)[1];
     }
-    if (y < y_hi) {                                   // rows y, y + 1 left
-        row_a(y + 1, tex_b, fac_b);
-        row_b(tex_a, fac_a);
-        row_b(tex_b, fac_b);
-    } else {
-        row_b(tex_a, fac_a);
+    const int o_t = max(w0_ctop(oa.x), y_lo), o_b = min(w0_cbot(oa.x), y_hi);
+    const bool o_holes = w0_immediate(oa.x);
+    int ov_lo = o_t, ov_hi = o_b;                     // rows of this band on which some column of the strip has overlay pixels
+    if constexpr (OV) {
+        for (int o = 32; o > 0; o >>= 1) { ov_lo = min(ov_lo, __shfl_xor(ov_lo, o)); ov_hi = max(ov_hi, __shfl_xor(ov_hi, o)); }
+        ov_lo = __builtin_amdgcn_readfirstlane(ov_lo); ov_hi = __builtin_amdgcn_readfirstlane(ov_hi);
+    }
+
+    // Which mapper the next rows run (wave-uniform; recomputed only on rows where a column changes segment).
+    enum { MODE_GENERIC = 0, MODE_FLAT = 1, MODE_WALL = 2, MODE_MIXED = 3 };
+    auto classify = [&]() {
+        if (__builtin_amdgcn_ballot_w64(S.cls == CLS_FLAT) == ~0ull) return (int)MODE_FLAT;
+        if (__builtin_amdgcn_ballot_w64(S.cls == CLS_WALL) == ~0ull) return (int)MODE_WALL;
+        return __builtin_amdgcn_ballot_w64(S.cls >= CLS_FLAT_SLOW) == 0ull ? (int)MODE_MIXED : (int)MODE_GENERIC;
+    };
+    int mode = classify();
+
+    // What one row has in flight between its two halves.  The loads are issued with inline assembly and waited for with an
+    // explicit s_waitcnt in row_b: hipcc's own wait insertion would also wait for the row buffer's STORE before it lets the
+    // texel be used, which serialises the rows.
+    struct Row { uint32_t tex; float fac; uint32_t otex, oopq; float ofac; };
+
+    // visplanes.rs:108-126 for a floor / ceiling pixel within the divide shortcut's verified domain
+    auto flat_px = [&](float vy, float r_vy, float &fac) {
+        const float wx = div_prepared(S.q1, vy, r_vy), wy = div_prepared(S.q0, vy, r_vy);
+        const float rx = wx * fr.cos_a - wy * fr.sin_a;
+        const float ry = wy * fr.cos_a + wx * fr.sin_a;
+        const int32_t tx = (f32_as_i16(rx) + fr.pos_x_i16) & 63;
+        const int32_t ty = (f32_as_i16(ry) + fr.pos_y_i16) & 63;
+        fac = __builtin_fmaf(-(float)f32_as_i16(wx), 1.0f / (16.0f * 256.0f), S.q2);   // strip_core.h seg_flat_offset: exact product
+        return S.base + (uint32_t)(ty * 64 + tx);
+    };
+    // bitmap_render.rs:256-263 for a wall pixel whose bitmap height is a power of two (mask instead of modulus)
+    auto wall_px = [&](int y) {
+        const float ay = div_prepared((float)(y - S.top_y), S.q0, S.q2);
+        const int32_t ty = (f32_as_i16(S.hf + ay * S.q1) + S.off_y) & S.hmask;
+        return S.base + (uint32_t)ty * S.wst;
+    };
+
+    // Row y, first half: columns whose segment ended on the previous row move to their next one; then the texture mapper
+    // -> pool offset of the texel and the light factor; the texel load is issued and NOT waited for.
+    auto row_a = [&](int y, Row &R) {
+        const u32x4 rc = rows[y];                     // scalar load: prepared 1/vy, sky row, vy (dg_row_table)
+        if (__builtin_amdgcn_ballot_w64(y > S.end) != 0ull) {      // wave-uniform: rows without a segment change skip all of this
+            if (y > S.end) {
+                seg_unpack(na, nb, S);
+                if (S.end < H - 1) {
+                    seg_at += seg_step;
+                    na = *reinterpret_cast<const uint4 *>(segs_f + seg_at); nb = *reinterpret_cast<const uint4 *>(segs_f + seg_at + 16);
+                }
+            }
+            mode = classify();
+        }
+        const float r_vy = bits_f32(rc.x), vy = bits_f32(rc.z);   // visplanes.rs:109
+        uint32_t off;
+        if (mode == MODE_FLAT) {
+            off = flat_px(vy, r_vy, R.fac);
+        } else if (mode == MODE_WALL) {
+            R.fac = S.fac;
+            off = wall_px(y);
+        } else {
+            off = S.base;                             // CLS_NONE: offset 0, factor 0 -> black
+            R.fac = S.fac;
+            if (mode == MODE_MIXED) {                 // floors / ceilings, power-of-two walls, sky, nothing: one masked pass each
+                if (S.cls == CLS_FLAT) off = flat_px(vy, r_vy, R.fac);
+                if (S.cls == CLS_WALL) off = wall_px(y);
+            } else {
+                if (S.cls == CLS_FLAT || S.cls == CLS_FLAT_SLOW)
+                    off = seg_flat_offset(fr, f32_bits(S.q0), S.base, f32_bits(S.q1), f32_bits(S.q2), S.cls == CLS_FLAT ? 1u : 0u, vy, r_vy, R.fac);
+                else if (S.cls == CLS_WALL || S.cls == CLS_WALL_MOD) {
+                    const int32_t h = (int32_t)S.hf;
+                    off = S.base + (uint32_t)wall_texel_row(S.q0, S.q2, S.q1, (uint32_t)(uint16_t)S.top_y | ((uint32_t)(uint16_t)S.off_y << 16), h, y) * S.wst;
+                }
+            }
+            if (S.cls == CLS_SKY) {
+                const int srow = (int)rc.y;
+                if (srow >= 0) off = S.base + (uint32_t)srow * sky_w;
+                else { off = 0; R.fac = 0.0f; }       // row outside the sky bitmap: nothing is drawn
+            }
+        }
+        asm volatile("global_load_ubyte %0, %1, %2" : "=v"(R.tex) : "v"(off), "s"(pool) : "memory");
+        // the column's masked-wall / sprite pixel of this row, if any (bitmap_render.rs:256-265): texel and opacity
+        if constexpr (OV) {
+            R.otex = 0; R.oopq = 0; R.ofac = -1.0f;   // a negative factor marks "no overlay pixel here"
+            if (y >= ov_lo && y <= ov_hi) {           // wave-uniform
+                const bool on = y >= o_t && y <= o_b;
+                uint32_t oo = 0;
+                if (on) oo = seg_wall_offset(oa.y, oa.z, ob.x, ob.y, ob.z, ob.w, y);
+                asm volatile("global_load_ubyte %0, %1, %2" : "=v"(R.otex) : "v"(oo), "s"(pool) : "memory");
+                asm volatile("global_load_ubyte %0, %1, %2" : "=v"(R.oopq) : "v"(oo), "s"(pool + P.scene.pool_opq) : "memory");
+                if (on) R.ofac = bits_f32(oa.w);
+            }
+        }
+    };
+    // `n` parked rows (192 bytes each) -> HBM.
+    auto flush_rows = [&](int n) {
+        if (st_lane && st_row < n) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(&rowbuf[st_row * 48 + st_chunk * 4]);
+            asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(st_off), "v"(v), "s"(rowp) : "memory");
+        }
+        rowp += (size_t)n * (size_t)W * 3;
+        parked = 0;
+    };
+    // Row y, second half: palette, lighting (bitmap_render.rs:202-207), RGB24 packing, park.
+    // The texel of this row must have arrived.  vmcnt counts loads and stores together, but only loads return in issue order
+    // among themselves (a store may complete before an older load), so the only operation that may stay in flight is the one
+    // load known to be younger than this row's: the next row's texel.  Anything else issued in between — segment prefetches,
+    // overlay texels, the row buffer's store — only makes the wait stricter.
+    auto row_b = [&](Row &R, bool keep) {
+        if constexpr (OV) asm volatile("s_waitcnt vmcnt(1)" : "+v"(R.tex), "+v"(R.otex), "+v"(R.oopq) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" : "+v"(R.tex) : : "memory");
+        uint32_t tex = R.tex;
+        float fac = R.fac;
+        if constexpr (OV) {
+            if (R.ofac >= 0.0f && (R.oopq != 0u || !o_holes)) { tex = R.otex; fac = R.ofac; }   // an opaque overlay texel wins
+        }
+        const float4 c = palf[tex];
+        uint32_t px;
+        {
+            const float r = __builtin_truncf(c.x * fac), g = __builtin_truncf(c.y * fac), b = __builtin_truncf(c.z * fac);
+            asm("v_cvt_pk_u8_f32 %0, %1, 0, 0" : "=v"(px) : "v"(r));
+            asm("v_cvt_pk_u8_f32 %0, %1, 1, %2" : "=v"(px) : "v"(g), "v"(px));
+            asm("v_cvt_pk_u8_f32 %0, %1, 2, %2" : "=v"(px) : "v"(b), "v"(px));
+        }
+        const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)px, (int)px, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
+        const uint32_t out = __builtin_amdgcn_perm(nx, px, perm_sel);
+        if (!keep) return;                            // wave-uniform: the look-ahead past the band's last row
+        if (park_on) rowbuf[parked * 48 + park_at] = out;
+        if (++parked == 4) flush_rows(4);
+    };
+    // Order of the vector-memory operations:  L(y+1)  [wait L(y)]  (S)  L(y+2)  [wait L(y+1)]  (S) ...
+    // The loop has ONE shape for every trip — an odd last row is loaded twice rather than handled by a peeled tail — so that
+    // a texel in flight always sits in the register its load was issued into: a register copy inserted on a loop-exit edge
+    // would read the register before the load has landed (tests/test_isa_checks.py looks for such reads in the built ISA).
+    Row A, B;
+    row_a(y_lo, A);
+    for (int y = y_lo; y <= y_hi; y += 2) {           // two rows per trip so that the in-flight texel needs no register move
+        row_a(min(y + 1, y_hi), B);
+        row_b(A, true);
+        row_a(min(y + 2, y_hi), A);
+        row_b(B, y + 1 <= y_hi);
+    }
+    if constexpr (OV) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A.tex), "+v"(A.otex), "+v"(A.oopq) : : "memory");   // the last, unused look-ahead
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(A.tex) : : "memory");
+    if (parked) flush_rows(parked);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(64) void dg_raster_strips(RasterParams P) {
+    __shared__ float4 palf[256];                      // palette as f32 triples: shading needs no v_cvt_f32_ubyte
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[4 * 48];   // four finished rows of the strip (RGB24, 192 B each)
+    strips_body<false>(P, palf, rowbuf);
+}
+__global__ __launch_bounds__(64) void dg_raster_strips_ov(RasterParams P) {
+    __shared__ float4 palf[256];
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[4 * 48];
+    strips_body<true>(P, palf, rowbuf);
+}
+
+// The spans dg_resolve_columns left in draw order (from a column's first possibly-transparent span on: masked walls and
+// sprites, whose texels decide whether they write: bitmap_render.rs:265) on top of what dg_raster_strips stored.  One
+// wavefront per (frame, 64-column strip, band) that such a span touches, lane = column.  Layer j = the j-th overlay span of
+// every column; layers run in order, a layer's rows run top to bottom with the row wave-uniform, and a lane stores its 3
+// bytes only where the texel is opaque — so "later draw call wins" is simply the order of this wave's stores, and nothing
+// has to be read back.
+__global__ __launch_bounds__(64) void dg_overlay_strips(RasterParams P) {
+    __shared__ uint32_t pal[256];
+    const int f = blockIdx.z;
+    if (P.frame_flags[f] != 0u) return;
+    if (!P.band_ovl[((size_t)f * (size_t)P.n_bands + blockIdx.y) * (size_t)gridDim.x + blockIdx.x]) return;
+    const int lane = threadIdx.x;
+    const int W = P.k.W, H = P.k.H;
+    const int x = (int)blockIdx.x * 64 + lane;
+    const int y_lo = (int)blockIdx.y * P.band_rows;
+    const int y_hi = min(H, y_lo + P.band_rows) - 1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) pal[lane + 64 * k] = P.scene.palette[lane + 64 * k];
+    __syncthreads();
+    const DevFrame fr = P.frames[f];
+    uint32_t k_spans = 0;
+    const DevRSpan *spans = P.rspans;
+    if (x < W) {
+        const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
+        const uint32_t first = P.ov_first[(size_t)f * (size_t)W + (size_t)x];
+        const uint32_t o = coff[x], n = coff[x + 1] - o;
+        k_spans = n - first;
+        spans = P.rspans + fr.span_base + o + first;
+        if (k_spans && overlay_is_inline(k_spans, spans[0].w[0])) k_spans = 0;      // dg_raster_strips applied it
+    }
+    const uint8_t *pool = P.scene.pool;
+    uint8_t *fbx = P.fb + ((size_t)f * (size_t)H * (size_t)W + (size_t)(x < W ? x : 0)) * 3;
+    for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j < k_spans) != 0ull; j++) {
+        uint4 a = make_uint4(0, 0, 0, 0), b = a;
+        int t = 0x7fff, bt = -1;
+        if (j < k_spans) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(spans + j);
+            a = q[0]; b = q[1];
+            t = max(w0_ctop(a.x), y_lo); bt = min(w0_cbot(a.x), y_hi);
+        }
+        int lo = t, hi = bt;
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        const uint32_t kind = w0_kind(a.x);
+        const bool holes = w0_immediate(a.x);
+        const float r_d = prepare_rcp(bits_f32(a.y));
+        for (int y = lo; y <= hi; y++) {
+            if (y < t || y > bt) continue;
+            uint32_t color = 0;
+            bool opaque = false;
+            if (kind == SPAN_WALL) {
+                const int32_t h = (int32_t)(b.z & 0xffffu), w = (int32_t)(b.z >> 16);
+                const uint32_t o = a.z + b.w + (uint32_t)(wall_texel_row(bits_f32(a.y), r_d, bits_f32(b.x), b.y, h, y) * w);
+                opaque = holes ? pool[P.scene.pool_opq + o] != 0 : true;
+                color = shade(pal[pool[o]], bits_f32(a.w));
+            } else if (kind == SPAN_FLAT) {
+                const float vy = P.k.CFY - (float)y;
+                float factor;
+                const uint32_t o = flat_texel_offset(fr, a.y, a.z, b.x, b.y, b.z, vy, bits_f32(P.row_tab[y].x), factor);
+                color = shade(pal[pool[P.scene.pool_flats + o]], factor);
+                opaque = true;
+            } else {
+                const int srow = (int)P.row_tab[y].y;
+                if (b.w != 0xffffffffu && srow >= 0) {
+                    const uint32_t o = P.scene.sky_texel_off + (uint32_t)srow * (uint32_t)P.scene.sky_w + b.w;
+                    opaque = holes ? pool[P.scene.pool_opq + o] != 0 : true;
+                    color = pal[pool[o]];
+                }
+            }
+            if (opaque) {
+                uint8_t *p = fbx + (size_t)y * (size_t)W * 3;
+                p[0] = (uint8_t)color; p[1] = (uint8_t)(color >> 8); p[2] = (uint8_t)(color >> 16);
+            }
+        }
     }
 }
 
 // Per-row constants of the flat and sky mappers for one frame size: the prepared reciprocal of vy = CFY - y (visplanes.rs:109)
 // and the sky texture row (visplanes.rs:68-72).  Same device code as the per-lane computation it replaces, run once per
 // scene upload instead of once per wavefront (~35 VALU instructions of every raster wave).
-__global__ void dg_row_table(DevScene scene, DevConsts k, uint2 *row_tab) {
+__global__ void dg_row_table(DevScene scene, DevConsts k, uint4 *row_tab) {
     const int y = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (y >= k.H) return;
     const float vy = k.CFY - (float)y;
-    row_tab[y] = make_uint2(f32_bits(prepare_rcp(vy)), (uint32_t)sky_row(scene, k, y));
+    row_tab[y] = make_uint4(f32_bits(prepare_rcp(vy)), (uint32_t)sky_row(scene, k, y), f32_bits(vy), 0u);
 }
 
 // Order-independent per-frame checksum (dg_frame_checksums): every dword is mixed with its index, the mixes are summed.
@@ -419,7 +663,7 @@ hipError_t launch_checksums(const uint8_t *fb, size_t frame_bytes, int count, un
     return hipGetLastError();
 }
 
-hipError_t launch_row_table(const DevScene &scene, const DevConsts &k, uint2 *row_tab, hipStream_t stream) {
+hipError_t launch_row_table(const DevScene &scene, const DevConsts &k, uint4 *row_tab, hipStream_t stream) {
     hipLaunchKernelGGL(dg_row_table, dim3((unsigned)((k.H + 255) / 256)), dim3(256), 0, stream, scene, k, row_tab);
     return hipGetLastError();
 }
@@ -441,10 +685,15 @@ hipError_t launch_raster(const RasterParams &P, hipStream_t stream) {
     if (P.n_frames <= 0) return hipSuccess;
     const unsigned strips = (unsigned)((P.k.W + TILE_W - 1) / TILE_W);
     if (P.strips) {
-        hipError_t e = hipMemsetAsync(P.frame_flags, 0, (size_t)P.n_frames * 4, stream);
+        // frame_flags [max_batch] is followed by band_ovl and band_inl, [F][n_bands][strips] each: one fill clears all three
+        hipError_t e = hipMemsetAsync(P.frame_flags, 0, (size_t)(reinterpret_cast<uint8_t *>(P.band_inl) - reinterpret_cast<uint8_t *>(P.frame_flags)) +
+                                                           (size_t)P.n_frames * (size_t)P.n_bands * strips, stream);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(dg_resolve_columns, dim3(strips, (unsigned)P.n_frames), dim3(64), 0, stream, P);
         hipLaunchKernelGGL(dg_raster_strips, dim3(strips, (unsigned)P.n_bands, (unsigned)P.n_frames), dim3(64), 0, stream, P);
+        hipLaunchKernelGGL(dg_raster_strips_ov, dim3(strips, (unsigned)P.n_bands, (unsigned)P.n_frames), dim3(64), 0, stream, P);
+        hipLaunchKernelGGL(dg_overlay_strips, dim3(strips, (unsigned)P.n_bands, (unsigned)P.n_frames), dim3(64), 0, stream, P);
+        return hipGetLastError();
     }
     dim3 grid(strips, (unsigned)((P.k.H + TILE_H - 1) / TILE_H), (unsigned)P.n_frames);
     hipLaunchKernelGGL(dg_raster_tiles, grid, dim3(THREADS), 0, stream, P);

@@ -17,26 +17,30 @@ struct RasterParams {
     const DevWallRec *walls;
     const DevPlaneRec *planes;
     uint8_t *fb;                 // n_frames x 3*W*H, RGB24
-    const uint2 *row_tab;        // [H] per screen row: x = bits of prepare_rcp(CFY - y), y = sky texture row (or -1); dg_row_table
+    const uint4 *row_tab;        // [H] per screen row: x = bits of prepare_rcp(CFY - y), y = sky texture row (or -1), z = bits of CFY - y; dg_row_table
     int32_t n_frames;
     // strip path (strip_core.h): written by dg_resolve_columns, read by dg_raster_strips and dg_raster_tiles (overlay mode)
     DevSeg *segs;                // [n_frames][seg_cap][W]
     uint8_t *band_first;         // [n_frames][n_bands][W] slot of the segment that contains the first row of a band
     uint16_t *ov_first;          // [n_frames][W] index (within the column's draw-ordered spans) of the first overlay span
-    uint32_t *strip_ovl;         // [n_frames][ceil(W / 64)] rows touched by the overlay spans of a 64-column strip: lo | hi << 16 (lo > hi: none)
-    uint32_t *frame_flags;       // [n_frames] != 0: a column needed more than seg_cap segments; dg_raster_tiles renders that frame alone
+    DevSeg *ov_inline;           // [n_frames][W] the column's overlay span when it has exactly one (DevSeg words 1-7 of a wall, word 0 = the
+                                 // span's DevRSpan word 0); first row > last row: none
+    uint32_t *frame_flags;       // [n_frames] != 0: a column needed more than seg_cap segments; the batch is redone with strips = 0
+    uint8_t *band_ovl;           // [n_frames][n_bands][ceil(W / 64)] != 0: an overlay span touches that band of that 64-column strip
+    uint8_t *band_inl;           // same shape: a column of that strip has an INLINE overlay span (strip_core.h) in that band -> dg_raster_strips_ov
+                                 // (both directly behind frame_flags [max_batch]: one fill clears all three)
     int32_t seg_cap, band_rows, n_bands;
     int32_t strips;              // 0: dg_raster_tiles alone renders everything (no resolve, no strips)
 };
 
 hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hipStream_t stream);
-// dg_resolve_columns + dg_raster_strips + dg_raster_tiles (overlay mode) when P.strips, else dg_raster_tiles alone.
+// dg_resolve_columns + dg_raster_strips + dg_overlay_strips when P.strips, else dg_raster_tiles.
 hipError_t launch_raster(const RasterParams &P, hipStream_t stream);
 // Rows per band of dg_raster_strips for a frame height (one wavefront renders 64 columns x band_rows rows).
 int strip_band_rows(int H);
 // out[k] = checksum (include/doomgpu.h: dg_frame_checksums) of frame k of `count` consecutive frames of `frame_bytes` bytes at fb; out must be zeroed.
 hipError_t launch_checksums(const uint8_t *fb, size_t frame_bytes, int count, unsigned long long *out, hipStream_t stream);
 // Fills row_tab[0 .. H) for the given scene / frame size (once per dg_upload_scene).
-hipError_t launch_row_table(const DevScene &scene, const DevConsts &k, uint2 *row_tab, hipStream_t stream);
+hipError_t launch_row_table(const DevScene &scene, const DevConsts &k, uint4 *row_tab, hipStream_t stream);
 
 }  // namespace dg

@@ -291,14 +291,19 @@ static inline bool left_of_partition(const NodeRec &n, float px, float py) {
     return ax * by - ay * bx <= 0.0f;
 }
 
-uint32_t Scene::build_strip_pool(std::vector<uint8_t> &pool) const {
+uint32_t Scene::build_strip_pool(std::vector<uint8_t> &pool, uint32_t &opq_at_out) const {
     const size_t flats_at = (texel_idx.size() + 255) / 256 * 256;
-    pool.assign(flats_at + flat_pool.size(), 0);
+    const size_t opq_at = (flats_at + flat_pool.size() + 255) / 256 * 256;
+    pool.assign(opq_at + texel_opq.size(), 0);
     for (const BitmapInfo &b : bitmaps)
         for (int x = 0; x < b.w; x++)
-            for (int y = 0; y < b.h; y++)
-                pool[(size_t)b.texel_off + (size_t)y * (size_t)b.w + (size_t)x] = texel_idx[(size_t)b.texel_off + (size_t)x * (size_t)b.h + (size_t)y];
+            for (int y = 0; y < b.h; y++) {
+                const size_t cm = (size_t)b.texel_off + (size_t)x * (size_t)b.h + (size_t)y, rm = (size_t)b.texel_off + (size_t)y * (size_t)b.w + (size_t)x;
+                pool[rm] = texel_idx[cm];
+                pool[opq_at + rm] = texel_opq[cm];
+            }
     std::copy(flat_pool.begin(), flat_pool.end(), pool.begin() + (long)flats_at);
+    opq_at_out = (uint32_t)opq_at;
     return (uint32_t)flats_at;
 }
 

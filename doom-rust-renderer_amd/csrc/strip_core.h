@@ -1,4 +1,4 @@
-// strip_core.h — bodies of the strip rasteriser (dg_resolve_columns + dg_raster_strips, kernels.hip) as host/device inline
+// strip_core.h — bodies of the strip rasteriser (dg_resolve_columns, dg_raster_strips, dg_overlay_strips: kernels.hip) as host/device inline
 // functions, so that tests/emul can run the same code on the CPU.
 //
 // The reference's final pixel is "the last Pixels::set wins" over draw calls whose row ranges overlap by design (inclusive
@@ -9,7 +9,7 @@
 // Pixels::new, pixels.rs:10-14).  dg_raster_strips then walks a column top to bottom with the current segment in registers
 // and evaluates every pixel exactly once, with no per-pixel ownership test.  The spans from the first possibly-transparent
 // one on (masked walls, sprites: whether they write depends on the texel, bitmap_render.rs:265) stay in draw order and are
-// applied on top by dg_raster_tiles in overlay mode.
+// applied on top by dg_overlay_strips.
 #pragma once
 #include "raster_core.h"
 
@@ -55,6 +55,10 @@ DG_HD DevSeg seg_none(int32_t end) {
     return o;
 }
 
+// A column whose overlay is exactly one wall-kind span (a masked wall or a sprite column) is handled inside
+// dg_raster_strips; everything else goes through dg_overlay_strips.  w0 = word 0 of the column's first overlay span.
+DG_HD bool overlay_is_inline(uint32_t n_overlay, uint32_t w0) { return n_overlay == 1u && w0_kind(w0) == SPAN_WALL; }
+
 struct ResolveResult {
     uint32_t n_segs;      // segments written (0xffffffff: more than `cap`, nothing usable was written)
     uint32_t n_base;      // spans [0, n_base) were resolved; spans [n_base, n) are the overlay, still in draw order
@@ -63,16 +67,18 @@ struct ResolveResult {
 
 // One screen column.  spans[0 .. n): the column's DevRSpans in draw order.  Segments go to seg_out[slot * seg_stride], the
 // slot of the segment containing row b * band_rows to band_out[b * band_stride] for every band b.
-DG_HD ResolveResult resolve_column(const DevRSpan *spans, uint32_t n, const DevScene &sc, int32_t H, int32_t band_rows, uint32_t cap,
+// w0_at(j) returns word 0 (row range, flags) of span j — the kernel keeps those in LDS.
+template <typename W0At>
+DG_HD ResolveResult resolve_column(W0At w0_at, const DevRSpan *spans, uint32_t n, const DevScene &sc, int32_t H, int32_t band_rows, uint32_t cap,
                                    DevSeg *seg_out, size_t seg_stride, uint8_t *band_out, size_t band_stride) {
     ResolveResult res;
     uint32_t nb = n;
     for (uint32_t j = 0; j < n; j++)
-        if (w0_immediate(spans[j].w[0])) { nb = j; break; }
+        if (w0_immediate(w0_at(j))) { nb = j; break; }
     res.n_base = nb;
     res.ov_lo = 0x7fff; res.ov_hi = -1;
     for (uint32_t j = nb; j < n; j++) {
-        const uint32_t w0 = spans[j].w[0];
+        const uint32_t w0 = w0_at(j);
         res.ov_lo = w0_ctop(w0) < res.ov_lo ? w0_ctop(w0) : res.ov_lo;
         res.ov_hi = w0_cbot(w0) > res.ov_hi ? w0_cbot(w0) : res.ov_hi;
     }
@@ -84,7 +90,7 @@ DG_HD ResolveResult resolve_column(const DevRSpan *spans, uint32_t n, const DevS
         int32_t owner = -1, next = H;
         if (row < H) {
             for (uint32_t j = 0; j < nb; j++) {
-                const uint32_t w0 = spans[j].w[0];
+                const uint32_t w0 = w0_at(j);
                 const int32_t t = w0_ctop(w0), b = w0_cbot(w0);
                 if (t <= row && row <= b) owner = (int32_t)j;
                 if (t > row && t < next) next = t;

@@ -20,6 +20,8 @@
 using namespace dg;
 
 static std::string g_err;
+static uint64_t g_ov_stats[6];
+static uint64_t g_ov_hist[16], g_ov_px[16];   // columns by overlay span count: 0, 1 inline, 1 not inline, 2, 3+; [5] = overlay pixels of k >= 2 columns
 
 // What dg_raster_tiles does for every column: spans in order, every row of the span (lane = row), later span overwrites.
 static void raster_spans(const DevScene &ds, const DevConsts &k, const DevFrame &hdr, const uint32_t *pal, const uint32_t *col_off,
@@ -59,7 +61,7 @@ static void raster_spans(const DevScene &ds, const DevConsts &k, const DevFrame 
 static bool raster_strips_check(const Scene &sc, DevScene ds, const DevConsts &k, const DevFrame &hdr, const uint32_t *pal, const uint32_t *col_off,
                                 const DevRSpan *rs, int W, int H, const uint8_t *expect) {
     std::vector<uint8_t> pool;
-    ds.pool_flats = sc.build_strip_pool(pool);
+    ds.pool_flats = sc.build_strip_pool(pool, ds.pool_opq);
     ds.pool = pool.data();
     int band_rows = std::max(1, (H + 8 * ((H + 511) / 512) - 1) / (8 * ((H + 511) / 512)));   // = strip_band_rows(H), kernels.hip
     const int n_bands = (H + band_rows - 1) / band_rows;
@@ -69,7 +71,7 @@ static bool raster_strips_check(const Scene &sc, DevScene ds, const DevConsts &k
     for (int x = 0; x < W; x++) {
         const uint32_t n = col_off[x + 1] - col_off[x];
         const DevRSpan *sp = rs + col_off[x];
-        const ResolveResult r = resolve_column(sp, n, ds, H, band_rows, cap, segs.data(), 1, bands.data(), 1);
+        const ResolveResult r = resolve_column([&](uint32_t j) { return sp[j].w[0]; }, sp, n, ds, H, band_rows, cap, segs.data(), 1, bands.data(), 1);
         if (r.n_segs == 0xffffffffu) { g_err = "strip path: more than 255 segments in a column"; return false; }
         if (r.n_segs == 0 || seg_end(segs[r.n_segs - 1].w[0]) != H - 1) { g_err = "strip path: segments do not end at H - 1"; return false; }
         int start = 0;
@@ -96,24 +98,47 @@ static bool raster_strips_check(const Scene &sc, DevScene ds, const DevConsts &k
             }
             start = end + 1;
         }
-        for (uint32_t i = r.n_base; i < n; i++) {                    // overlay: the spans from the first possibly-transparent one on
+        {
+            const uint32_t k = n - r.n_base;
+            const bool inl = overlay_is_inline(k, k ? sp[r.n_base].w[0] : 0u);
+            g_ov_stats[k == 0 ? 0 : k == 1 ? (inl ? 1 : 2) : k == 2 ? 3 : 4]++;
+            g_ov_hist[k < 15 ? k : 15]++;
+            for (uint32_t i = r.n_base; i < n; i++) g_ov_px[k < 15 ? k : 15] += (uint64_t)(w0_cbot(sp[i].w[0]) - w0_ctop(sp[i].w[0]) + 1);
+            if (k >= 2) for (uint32_t i = r.n_base; i < n; i++) g_ov_stats[5] += (uint64_t)(w0_cbot(sp[i].w[0]) - w0_ctop(sp[i].w[0]) + 1);
+        }
+        if (overlay_is_inline(n - r.n_base, n > r.n_base ? sp[r.n_base].w[0] : 0u)) {   // dg_raster_strips: the single overlay span, as a segment
+            DevSeg ov = seg_from_span(sp[r.n_base], 0, ds);
+            const uint32_t w0 = sp[r.n_base].w[0];
+            for (int y = w0_ctop(w0); y <= w0_cbot(w0); y++) {
+                const uint32_t o = seg_wall_offset(ov.w[1], ov.w[2], ov.w[4], ov.w[5], ov.w[6], ov.w[7], y);
+                if (w0_immediate(w0) && !pool[ds.pool_opq + o]) continue;
+                const uint32_t c = shade(pal[pool[o]], bits_f32(ov.w[3]));
+                uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
+                p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
+            }
+        } else
+        for (uint32_t i = r.n_base; i < n; i++) {                    // dg_overlay_strips: the spans from the first possibly-transparent one on
             const uint32_t *w = sp[i].w;
             if (w0_ctop(w[0]) < r.ov_lo || w0_cbot(w[0]) > r.ov_hi) { g_err = "strip path: overlay rows outside the reported range"; return false; }
             for (int y = w0_ctop(w[0]); y <= w0_cbot(w[0]); y++) {
                 uint32_t c = 0;
                 bool wr = false;
                 const uint32_t kind = w0_kind(w[0]);
-                if (kind == SPAN_WALL) {
-                    uint32_t o = wall_texel_offset(w[1], w[2], w[4], w[5], w[6], w[7], y);
-                    if (!w0_immediate(w[0]) || ds.texel_opq[o]) { c = shade(pal[ds.texel_idx[o]], bits_f32(w[3])); wr = true; }
+                if (kind == SPAN_WALL) {                                  // dg_overlay_strips: row-major planes of the pool
+                    const int32_t h = (int32_t)(w[6] & 0xffffu), bw = (int32_t)(w[6] >> 16);
+                    const uint32_t o = w[2] + w[7] + (uint32_t)(wall_texel_row(bits_f32(w[1]), prepare_rcp(bits_f32(w[1])), bits_f32(w[4]), w[5], h, y) * bw);
+                    if (!w0_immediate(w[0]) || pool[ds.pool_opq + o]) { c = shade(pal[pool[o]], bits_f32(w[3])); wr = true; }
                 } else if (kind == SPAN_FLAT) {
                     float factor;
                     const float vy = k.CFY - (float)y;
                     uint32_t o = flat_texel_offset(hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), factor);
-                    c = shade(pal[ds.flats[o]], factor); wr = true;
+                    c = shade(pal[pool[ds.pool_flats + o]], factor); wr = true;
                 } else {
-                    uint32_t o = sky_texel_offset(w[2], sky_row(ds, k, y));
-                    if (o != 0xffffffffu && ds.texel_opq[o]) { c = pal[ds.texel_idx[o]]; wr = true; }
+                    const int srow = sky_row(ds, k, y);
+                    if (w[7] != 0xffffffffu && srow >= 0) {
+                        const uint32_t o = ds.sky_texel_off + (uint32_t)srow * (uint32_t)ds.sky_w + w[7];
+                        if (!w0_immediate(w[0]) || pool[ds.pool_opq + o]) { c = pal[pool[o]]; wr = true; }
+                    }
                 }
                 if (wr) {
                     uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
@@ -134,6 +159,8 @@ static bool raster_strips_check(const Scene &sc, DevScene ds, const DevConsts &k
 extern "C" {
 
 const char *emul_last_error() { return g_err.c_str(); }
+void emul_overlay_hist(uint64_t *cols, uint64_t *px) { for (int i = 0; i < 16; i++) { cols[i] = g_ov_hist[i]; px[i] = g_ov_px[i]; g_ov_hist[i] = g_ov_px[i] = 0; } }
+void emul_overlay_stats(uint64_t *out, int reset) { for (int i = 0; i < 6; i++) { out[i] = g_ov_stats[i]; if (reset) g_ov_stats[i] = 0; } }
 
 void *emul_load(const uint8_t *wad, size_t len, const char *map_name) {
     return load_scene_from_wad(wad, len, map_name, g_err);

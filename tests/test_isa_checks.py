@@ -1,0 +1,177 @@
+"""Static checks on the gfx950 ISA hipcc produces for the hand-scheduled parts of kernels.hip (no GPU needed: hipcc
+cross-compiles here).
+
+dg_raster_strips issues its texel loads with inline assembly and waits for them with explicit `s_waitcnt vmcnt(N)` so that a
+row's texel can be in flight while the previous row is shaded and stored (hipcc's own wait insertion would drain the store
+first).  The compiler does not know those registers are written asynchronously: were it to copy, spill or overwrite one between
+the load and the wait, the kernel would read or lose a value that has not landed.  This test runs a forward data-flow analysis
+over the kernel's control-flow graph and fails if any instruction reads or overwrites a VGPR whose load may still be in flight.
+
+Model (MI355X_MICROARCH.md, `s_waitcnt vmcnt`, and what hipcc itself assumes on gfx9): vmcnt counts vector loads and stores
+together; loads return in issue order among themselves, a store may complete before an older load.  Hence after
+`s_waitcnt vmcnt(N)` a load is known to have landed iff at least N vector LOADS were issued after it.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "doom-rust-renderer_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"]   # = csrc/Makefile
+
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def regs(operand: str):
+    out = set()
+    for m in REG.finditer(operand):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def kernel_body(asm: str, mangled: str):
+    lines = asm.splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith(mangled + ":"))
+    end = next(i for i in range(start, len(lines)) if ".amdhsa_kernel" in lines[i] or lines[i].startswith(".Lfunc_end"))
+    return lines[start + 1:end]
+
+
+def parse(body):
+    """-> list of basic blocks: {label, insts: [(mnemonic, [operands])], succ: [block index]}"""
+    blocks, cur = [], {"label": None, "insts": []}
+    for raw in body:
+        l = raw.split(";")[0].strip()
+        if not l or l.startswith(".") and not l.endswith(":"):
+            continue
+        if l.endswith(":"):
+            if cur["insts"] or cur["label"]:
+                blocks.append(cur)
+            cur = {"label": l[:-1], "insts": []}
+            continue
+        mnem, _, rest = l.partition(" ")
+        ops = [o.strip() for o in rest.split(",")] if rest else []
+        cur["insts"].append((mnem, ops))
+        if mnem.startswith("s_cbranch") or mnem in ("s_branch", "s_endpgm"):
+            blocks.append(cur)
+            cur = {"label": None, "insts": []}
+    if cur["insts"] or cur["label"]:
+        blocks.append(cur)
+    by_label = {b["label"]: i for i, b in enumerate(blocks) if b["label"]}
+    for i, b in enumerate(blocks):
+        succ = []
+        last = b["insts"][-1] if b["insts"] else None
+        if last and last[0] == "s_endpgm":
+            pass
+        elif last and last[0] == "s_branch":
+            succ.append(by_label[last[1][0]])
+        else:
+            if last and last[0].startswith("s_cbranch"):
+                succ.append(by_label[last[1][0]])
+            if i + 1 < len(blocks):
+                succ.append(i + 1)
+        b["succ"] = succ
+    return blocks
+
+
+def is_vload(m):
+    return (m.startswith("global_load") or m.startswith("buffer_load") or m.startswith("flat_load")) and "lds" not in m
+
+
+def is_vstore(m):
+    return m.startswith("global_store") or m.startswith("buffer_store") or m.startswith("flat_store") or m.startswith("global_atomic")
+
+
+def check(blocks):
+    """state: dict reg -> min number of vector loads issued after the load that targets reg (over all paths)."""
+    n = len(blocks)
+    state_in = [None] * n
+    state_in[0] = {}
+    work = [0]
+    violations = []
+    seen = set()
+    while work:
+        i = work.pop()
+        st = dict(state_in[i])
+        for (m, ops) in blocks[i]["insts"]:
+            if m == "s_waitcnt":
+                txt = " ".join(ops)
+                mm = re.search(r"vmcnt\((\d+)\)", txt)
+                if mm:
+                    nmax = int(mm.group(1))
+                    st = {r: k for r, k in st.items() if k < nmax}
+                continue
+            if is_vload(m):
+                dst = regs(ops[0])
+                src = set().union(*[regs(o) for o in ops[1:]]) if len(ops) > 1 else set()
+                for r in (src | dst) & set(st):
+                    violations.append((blocks[i]["label"], m, " ".join(ops), f"v{r} may still be in flight"))
+                st = {r: k + 1 for r, k in st.items()}
+                for r in dst:
+                    st[r] = 0
+                continue
+            if is_vstore(m):
+                used = set().union(*[regs(o) for o in ops]) if ops else set()
+            elif m.startswith("s_") and not m.startswith("s_waitcnt"):
+                used = set().union(*[regs(o) for o in ops]) if ops else set()      # e.g. v_readlane results feed scalars; scalar ops name no VGPR
+            else:
+                used = set().union(*[regs(o) for o in ops]) if ops else set()      # reads and the destination alike
+            for r in used & set(st):
+                violations.append((blocks[i]["label"], m, " ".join(ops), f"v{r} may still be in flight"))
+        for s in blocks[i]["succ"]:
+            old = state_in[s]
+            if old is None:
+                new = dict(st)
+            else:
+                new = dict(old)
+                for r, k in st.items():
+                    new[r] = min(k, new[r]) if r in new else k
+            if new != old:
+                state_in[s] = new
+                work.append(s)
+        seen.add(i)
+    return violations
+
+
+@pytest.fixture(scope="module")
+def kernels_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "kernels.s"
+    subprocess.check_call([HIPCC, *FLAGS, "-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "kernels.hip")], stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def test_checker_catches_a_premature_read():
+    body = """
+    global_load_ubyte v5, v1, s[0:1]
+    global_load_ubyte v6, v2, s[0:1]
+    s_waitcnt vmcnt(1)
+    v_mov_b32_e32 v7, v5
+    v_mov_b32_e32 v8, v6
+    s_endpgm
+    """.splitlines()
+    v = check(parse(body))
+    assert len(v) == 1 and "v6" in v[0][3]
+
+
+def test_checker_does_not_count_stores_as_younger_loads():
+    body = """
+    global_load_ubyte v5, v1, s[0:1]
+    global_store_dword v2, v3, s[0:1]
+    s_waitcnt vmcnt(1)
+    v_mov_b32_e32 v7, v5
+    s_endpgm
+    """.splitlines()
+    assert len(check(parse(body))) == 1
+
+
+@pytest.mark.parametrize("mangled", ["_ZN2dg16dg_raster_stripsENS_12RasterParamsE", "_ZN2dg19dg_raster_strips_ovENS_12RasterParamsE"])
+def test_raster_strips_never_touches_a_texel_in_flight(kernels_asm, mangled):
+    blocks = parse(kernel_body(kernels_asm, mangled))
+    assert sum(1 for b in blocks for (m, _) in b["insts"] if m == "global_load_ubyte") >= 2, "the asm texel loads are gone?"
+    v = check(blocks)
+    assert not v, "\n".join(f"{lab}: {m} {ops}: {why}" for (lab, m, ops, why) in v[:20])
