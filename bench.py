@@ -8,24 +8,30 @@ Workload (config.workload): BASELINE config 2 — the 1 000-frame scripted camer
 map, rendered natively at 1280x800 (the size the ">= 10 000 fps" target is quoted on), one MI355X per rank.  No id
 WAD can be shipped, so the map is the committed synthetic IWAD (seed 1993) and `data` says "synthetic".
 
-A *step* is one pass of the hot path over one batch of `--batch` consecutive path frames whose per-seg / per-sprite
-records (the output of the BSP walk, clip and projection) are already resident in HBM (4 slots x 250 frames = the whole
-path).  `value` = frames / time over exactly K steps: device column walk (dg_fe_columns, dg_fe_gaps, dg_fe_scan,
-dg_fe_scatter) + tile raster (dg_raster_tiles) producing K*batch RGB24 frames in HBM.  With `--front-end host` the
-resident input is the finished column-major span lists instead (span setup + tile raster), the round-1 first definition.
-The PCIe-inclusive number (host record generation on T threads + H2D + the same kernels, double-buffered) is reported
-next to it as `e2e` and is never `value`.
+A *step* is ONE PASS OVER THE WHOLE 1 000-FRAME PATH: four batches of `--batch` consecutive frames, each going through
+the complete hot path of SURVEY.md §8(d) — host BSP walk / clip / projection / record generation on the ctx's host
+threads, pinned staging, H2D, the device column walk (dg_fe_*), dg_resolve_columns and the strip rasteriser
+(dg_raster_strips, dg_raster_strips_ov, dg_overlay_strips) — leaving 1 000 RGB24 frames in HBM.  The batches are
+pipelined over the ctx's slots: the host builds batch i + 1 while the GPU renders batch i.  `value` = frames / time over
+exactly K steps.  This is what the reference's `Renderer::render()` (src/renderer/mod.rs:118-136) does per frame, with
+`pixels.pixels` left in device memory; the rate with every frame also copied to host memory is `e2e_host_frames` (PCIe
+bound, never `value`), the rate of the kernels alone on records already resident in HBM is `resident_replay`.
 
-Multi-GPU: the path shards with no exchange step — rank r renders its own camera path (same map, route rotated by
-r/N and reversed for odd r) on GPU LOCAL_RANK; there is NO data-path collective and no RCCL.  torch.distributed (gloo,
-CPU tensors) is used only for the timing barrier and the MAX over ranks; value = sum of frames / max time (weak scaling).
+Multi-GPU: the path shards with no exchange step — rank r renders its own camera path (seed 1993 + r: the same closed
+route entered at another room, odd seeds walk it backwards) and the ranks alternate between two maps (seeds 1993 / 1994,
+the stand-ins for BASELINE config 4's map01 + map07) on GPU LOCAL_RANK; there is NO data-path collective and no RCCL.
+torch.distributed (gloo, CPU tensors) is used only for the timing barrier, the MAX over ranks and gathering the per-rank
+report; value = sum of frames / max time (weak scaling).  Each rank pins its host threads to its share of the CPUs
+(the NUMA node of its GPU when the topology is readable) before anything touches HIP.
 
-roofline: dominant kernel dg_raster_tiles, HBM-bound model.  achieved = algorithmic bytes per launch / mean launch
-duration from HIP events recorded on the kernel's own stream during the timed steps (dg_slot_timing).  Algorithmic
-bytes per frame = 3*W*H (RGB24 stored once) + W*H (one texel byte per pixel) + list bytes the kernel reads (32 B per
-span, 4*(W+1) column index) — SURVEY.md §8d, DESIGN.md "Roofline accounting".
+roofline: the strip rasteriser (dg_resolve_columns + dg_raster_strips + dg_raster_strips_ov + dg_overlay_strips, launched
+back to back by one call), HBM-bound model.  achieved = algorithmic bytes per launch / mean duration from HIP events recorded
+on the kernels' own stream during the timed steps (dg_slot_timing).  Algorithmic bytes per frame = 3*W*H (RGB24 stored
+once) + W*H (one texel byte per pixel) + list bytes read (32 B per span, 4*(W+1) column index) — SURVEY.md §8d,
+DESIGN.md "Roofline accounting".
 cpu_baseline: the CPU oracle (oracle/doomref.c, a port of the reference renderer) on 1 host core over a bounded
-sample of the same frames at the same size (rank 0, N = 1 only).
+sample of the same frames at the same size (rank 0, N = 1 only); the frames the timed steps left in HBM are compared with
+it byte for byte.
 """
 import argparse
 import importlib
@@ -37,13 +43,32 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PATH_FRAMES = 1000
+MAP_SEEDS = (1993, 1994)          # two maps, alternated across ranks (BASELINE config 4: map01 + map07)
 
-def rank_route(route, rank: int, world: int):
-    """Camera path of one rank: same closed route, start rotated by rank/world, direction reversed for odd ranks."""
+
+def xorshift32(x: int) -> int:
+    x &= 0xFFFFFFFF
+    x ^= (x << 13) & 0xFFFFFFFF
+    x ^= x >> 17
+    x ^= (x << 5) & 0xFFFFFFFF
+    return x & 0xFFFFFFFF
+
+
+def seeded_route(route, path_seed: int):
+    """Camera path `path_seed` (seeds 1993 ... 2000 = different start room / direction): the same closed route,
+    entered at a seed-dependent waypoint; odd seeds above 1993 walk it backwards.  Seed 1993 is the route itself."""
     n = len(route)
-    k = (rank * n) // max(world, 1)
-    r = route[k:] + route[:k]
-    return r[::-1] if rank % 2 else r
+    if path_seed == 1993 or n == 0:
+        return list(route)
+    k = xorshift32(path_seed * 2654435761) % n
+    r = list(route[k:]) + list(route[:k])
+    return r[::-1] if (path_seed - 1993) % 2 else r
+
+
+def rank_plan(rank: int, world: int):
+    """(map seed, path seed) of a rank: paths 1993 + rank, maps alternating."""
+    return MAP_SEEDS[rank % len(MAP_SEEDS)] if world > 1 else MAP_SEEDS[0], 1993 + rank
 
 
 def aggregate_fps(frames_per_rank: int, world: int, max_seconds: float) -> float:
@@ -59,28 +84,114 @@ def dist_max(seconds: float, dist) -> float:
     return float(t.item())
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--height", type=int, default=800)
-    ap.add_argument("--batch", type=int, default=250)
-    ap.add_argument("--slots", type=int, default=4)
-    ap.add_argument("--host-threads", type=int, default=0)
-    ap.add_argument("--front-end", choices=["device", "host"], default="device", help="where the per-column half of the seg / sprite processing runs")
-    ap.add_argument("--cpu-sample", type=int, default=4, help="cpu_baseline renders every n-th path frame")
-    ap.add_argument("--wad", default=None, help="IWAD file to render instead of the synthetic one (e.g. doom1.wad); the camera path is derived from the map")
-    ap.add_argument("--map", default="e1m1")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true")
-    args = ap.parse_args()
+def gather_reports(report: dict, dist, world: int):
+    if dist is None:
+        return [report]
+    out = [None] * world
+    dist.all_gather_object(out, report)
+    return out
 
+
+def _parse_cpulist(txt: str):
+    cpus = []
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus += list(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_nodes():
+    """NUMA node of every GPU in KFD enumeration order (= HIP ordinal order on a default box), read from sysfs without
+    touching HIP; [] when the topology cannot be read."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    nodes = []
+    try:
+        for d in sorted(os.listdir(base), key=int):
+            props = dict(l.split() for l in open(os.path.join(base, d, "properties")) if len(l.split()) == 2)
+            if int(props.get("simd_count", "0")) == 0:
+                continue
+            loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+            bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
+            try:
+                nodes.append(int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read()))
+            except OSError:
+                nodes.append(-1)
+    except (OSError, ValueError):
+        return []
+    return nodes
+
+
+def bind_rank_cpus(local_rank: int, local_world: int):
+    """Pin this process (and the threads it will create) to its share of the host CPUs BEFORE any HIP call: the CPUs of the
+    GPU's NUMA node split among the ranks whose GPUs sit on that node, else an even split of the allowed CPUs."""
+    allowed = sorted(os.sched_getaffinity(0))
+    if local_world <= 1 or len(allowed) < local_world:
+        return allowed, "all allowed CPUs"
+    share, how = None, ""
+    numa = gpu_numa_nodes()
+    if len(numa) >= local_world and numa[local_rank] >= 0:
+        node = numa[local_rank]
+        try:
+            node_cpus = [c for c in _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) if c in set(allowed)]
+            peers = [r for r in range(local_world) if numa[r] == node]
+            if len(node_cpus) >= len(peers):
+                i, n = peers.index(local_rank), len(peers)
+                share = node_cpus[i * len(node_cpus) // n:(i + 1) * len(node_cpus) // n]
+                how = f"NUMA node {node} shared by {n} rank(s)"
+        except OSError:
+            share = None
+    if not share:
+        share = allowed[local_rank * len(allowed) // local_world:(local_rank + 1) * len(allowed) // local_world]
+        how = "even split of the allowed CPUs"
+    os.sched_setaffinity(0, share)
+    return share, how
+
+
+class DoomGpuBackend:
+    """The real thing: libdoomgpu through the ctypes binding, synthetic IWADs, the camera-path generator."""
+
+    def __init__(self, args, device: int):
+        self.dg = importlib.import_module("doom-rust-renderer_amd")
+        self.sw = importlib.import_module("doom-rust-renderer_amd.synth_wad")
+        self.cp = importlib.import_module("doom-rust-renderer_amd.camera_path")
+        self.args, self.device = args, device
+
+    def load(self, map_seed: int, path_seed: int):
+        import numpy as np
+        a = self.args
+        if a.wad:
+            self.wad = open(a.wad, "rb").read()          # a user-supplied IWAD (BASELINE configs verbatim); data = "file"
+            route = self.cp.route_from_wad(self.wad, a.map)
+        else:
+            self.wad = self.sw.build_synth_iwad(map_seed)
+            route = self.sw.synth_route(map_seed)
+        self.scene = self.dg.Scene(self.wad, a.map)
+        self.path = self.cp.make_camera_path(seeded_route(route, path_seed), lambda x, y, d: self.scene.floor_height_at(x, y, d), PATH_FRAMES)
+        B = a.batch
+        self.n_slots = max(1, min(a.slots, (PATH_FRAMES + B - 1) // B))
+        fe = self.dg.DG_FE_HOST if a.front_end == "host" else self.dg.DG_FE_DEVICE
+        self.ctx = self.dg.Context(a.width, a.height, max_batch=B, slots=self.n_slots, device=self.device, host_threads=a.host_threads, front_end=fe)
+        self.ctx.upload_scene(self.scene)
+        loop = np.concatenate([self.path, self.path])
+        self.batch_first = [s * B % PATH_FRAMES for s in range(self.n_slots)]
+        self.views = [self.dg.make_views(loop[b0:b0 + B]) for b0 in self.batch_first]
+        return self.ctx
+
+    def oracle(self):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import doomref
+        return doomref
+
+
+def run(args, backend_factory=DoomGpuBackend):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     device = int(os.environ.get("DOOMGPU_BENCH_DEVICE", local_rank))   # override only to rehearse N > 1 on a 1-GPU box
+    cpus, cpu_how = bind_rank_cpus(local_rank, local_world)           # before torch / HIP are touched
 
     # torch first: its bundled HIP runtime must be the one libdoomgpu.so binds to (same soname, loaded once).
     import torch
@@ -92,230 +203,281 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend="gloo")     # timing barrier / MAX only; the data path has no collective
+            if not dist.is_initialized():
+                dist.init_process_group(backend="gloo")     # timing barrier / MAX / report gather only; the data path has no collective
             dist.barrier()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-    torch.cuda.set_device(device)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(device)
 
     import numpy as np
-    dg = importlib.import_module("doom-rust-renderer_amd")
-    sw = importlib.import_module("doom-rust-renderer_amd.synth_wad")
-    cp = importlib.import_module("doom-rust-renderer_amd.camera_path")
-
     W, H, B = args.width, args.height, args.batch
-    if args.wad:
-        wad = open(args.wad, "rb").read()                 # a user-supplied IWAD (BASELINE configs verbatim); data = "file"
-    else:
-        wad = sw.build_synth_iwad(1993)
-    scene = dg.Scene(wad, args.map)
-    route = rank_route(cp.route_from_wad(wad, args.map) if args.wad else sw.synth_route(1993), rank, world)
-    path = cp.make_camera_path(route, lambda x, y, d: scene.floor_height_at(x, y, d), 1000)
-    n_slots = max(1, min(args.slots, (1000 + B - 1) // B))
-    fe = dg.DG_FE_HOST if args.front_end == "host" else dg.DG_FE_DEVICE
-    ctx = dg.Context(W, H, max_batch=B, slots=n_slots, device=device, host_threads=args.host_threads, front_end=fe)
-    ctx.upload_scene(scene)
-
-    batches = [np.concatenate([path, path])[b0:b0 + B] for b0 in range(0, n_slots * B, B)]
-    views = [dg.make_views(b) for b in batches]
-    for s in range(n_slots):                         # lists resident in HBM before any timed region
-        ctx.prepare(s, views[s])
+    map_seed, path_seed = rank_plan(rank, world)
+    be = backend_factory(args, device)
+    ctx = be.load(map_seed, path_seed)
+    n_slots, views = be.n_slots, be.views
+    batches_per_step = (PATH_FRAMES + B - 1) // B
+    frames_per_step = batches_per_step * B
 
     def sync_all():
         for s in range(n_slots):
             ctx.wait(s)
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    # ---- resident-list steps: warmup, then exactly K timed steps -------------------------------------------------
-    for i in range(args.warmup):
-        ctx.replay(i % n_slots)
+    def one_pass(collect=None):
+        """One step: the whole path, batch by batch, through the complete hot path."""
+        for b in range(batches_per_step):
+            s = b % n_slots
+            if collect is not None and ctx_ran[s]:
+                ctx.wait(s)
+                collect(s)
+            ctx.submit(s, views[s])               # host record generation (blocking) + H2D + kernels (queued); waits only if the slot is still busy
+            ctx_ran[s] = True
+
+    # ---- the headline: warmup, then exactly K timed steps ------------------------------------------------------------
+    ctx_ran = [False] * n_slots
+    for _ in range(args.warmup):
+        one_pass()
     sync_all()
     barrier()
     sync_all()
-    raster_ms, setup_ms, alg_bytes = [], [], []
+    raster_ms, strips_ms, setup_ms, host_ms, alg_bytes = [], [], [], [], []
     stats = {}
 
     def collect(slot):
         t = ctx.timing(slot)
         raster_ms.append(t["raster_ms"])
+        strips_ms.append(t.get("strips_ms", 0.0))
         setup_ms.append(t["setup_ms"])
+        host_ms.append(t["host_ms"])
         nf = t["n_frames"]
         alg_bytes.append(nf * (3 * W * H + W * H + 4 * (W + 1)) + 32 * t["n_spans"])
         stats.update(t)
 
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        s = i % n_slots
-        if i >= n_slots:
-            ctx.wait(s)
-            collect(s)
-        ctx.replay(s)
+    for _ in range(args.steps):
+        one_pass(collect)
     sync_all()
+    elapsed_local = time.perf_counter() - t0
     barrier()
     sync_all()
-    elapsed = time.perf_counter() - t0
-    for i in range(max(0, args.steps - n_slots), args.steps):
-        collect(i % n_slots)
-    elapsed = dist_max(elapsed, dist)
-    frames_per_rank = args.steps * B
-    value = aggregate_fps(frames_per_rank, world, elapsed)
+    for s in range(n_slots):
+        if ctx_ran[s]:
+            collect(s)
+    elapsed = dist_max(elapsed_local, dist)
+    value = aggregate_fps(args.steps * frames_per_step, world, elapsed)
+    fallbacks = ctx.fallbacks() if hasattr(ctx, "fallbacks") else None
 
-    # ---- the dominant kernel alone: a few replays with a wait in between, so that no column walk of the next step overlaps it
-    iso_ms = []
-    for i in range(2 * n_slots):
-        ctx.replay(i % n_slots)
-        ctx.wait(i % n_slots)
-        iso_ms.append(ctx.timing(i % n_slots)["raster_ms"])
-    iso_ms = iso_ms[n_slots:]
+    # ---- CPU baseline + parity of the frames the timed steps left in HBM (rank 0, N = 1 only) -----------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, be, ctx, n_slots, np)
 
-    # ---- PCIe-inclusive end-to-end (host list generation + H2D + kernels), double-buffered ----------------------
-    e2e = None
-    if not args.no_e2e:
-        nb = max(4, min(24, args.steps))
-        for i in range(2):
-            ctx.submit(i % n_slots, views[i % n_slots])
+    # ---- the kernels alone: records resident in HBM, replayed (no host work, no H2D) --------------------------------
+    resident = None
+    iso_ms, iso_strips = [], []
+    if not args.no_resident:
+        for s in range(n_slots):
+            ctx.prepare(s, views[s])
+        for i in range(n_slots):
+            ctx.replay(i)
         sync_all()
         barrier()
-        host_ms = []
         t1 = time.perf_counter()
-        for i in range(nb):
+        nrep = max(2 * n_slots, min(args.steps * batches_per_step, 80))
+        for i in range(nrep):
             s = i % n_slots
-            ctx.submit(s, views[s])           # returns once the batch is queued; waits only if the slot is still busy
+            if i >= n_slots:
+                ctx.wait(s)
+            ctx.replay(s)
         sync_all()
-        barrier()
-        e2e_s = dist_max(time.perf_counter() - t1, dist)
-        host_ms = [ctx.timing(s)["host_ms"] for s in range(min(n_slots, nb))]   # after the clock: dg_slot_timing synchronises
-        e2e = {"value": aggregate_fps(nb * B, world, e2e_s), "unit": "frames/s",
-               "includes": "host BSP walk / record generation + pinned staging + H2D + all kernels, frames left in HBM",
-               "host_threads": ctx.host_threads, "host_ms_per_batch": float(np.mean(host_ms)),
-               "list_bytes_per_frame": int(stats.get("list_bytes", 0) // max(1, stats.get("n_frames", 1)))}
+        rs = dist_max(time.perf_counter() - t1, dist)
+        resident = {"value": aggregate_fps(nrep * B, world, rs), "unit": "frames/s",
+                    "includes": "device column walk + resolve + strip rasteriser on per-seg / per-sprite records already resident in HBM"}
+        # the rasteriser with nothing else on the GPU: replays with a wait in between
+        for i in range(2 * n_slots):
+            ctx.replay(i % n_slots)
+            ctx.wait(i % n_slots)
+            t = ctx.timing(i % n_slots)
+            iso_ms.append(t["raster_ms"])
+            iso_strips.append(t.get("strips_ms", 0.0))
+        iso_ms, iso_strips = iso_ms[n_slots:], iso_strips[n_slots:]
 
-    # ---- the same, with every frame copied back to page-locked host memory (what dg_render_views(.., rgb24_out) does) ----
+    # ---- every frame also copied to page-locked host memory (what the reference's `pixels.pixels` literally is) -------
     e2e_host = None
-    if not args.no_e2e:
-        nb = max(4, min(8, args.steps))
-        hbuf = dg.lib().dg_alloc_host(B * ctx.frame_bytes)
-        if hbuf:
-            barrier()
-            t2 = time.perf_counter()
-            for i in range(nb):
-                s = i % n_slots
-                ctx.submit(s, views[s])
-                ctx.readback_into(s, 0, B, hbuf)
-            sync_all()
-            barrier()
-            h_s = dist_max(time.perf_counter() - t2, dist)
-            dg.lib().dg_free_host(hbuf)
-            e2e_host = {"value": aggregate_fps(nb * B, world, h_s), "unit": "frames/s",
-                        "includes": "e2e + D2H of every RGB24 frame to pinned host memory (serialised per batch)",
-                        "d2h_GBps": nb * B * ctx.frame_bytes / h_s / 1e9}
+    if not args.no_host_frames and hasattr(ctx, "readback_async"):
+        e2e_host = host_frames_rate(args, be, ctx, n_slots, views, B, batches_per_step, barrier, dist, world)
 
-    # ---- roofline of the dominant kernel ----------------------------------------------------------------------------
+    # ---- roofline of the rasteriser --------------------------------------------------------------------------------
     mean_raster_s = float(np.mean(raster_ms)) / 1e3
     achieved = float(np.mean(alg_bytes)) / mean_raster_s / 1e9
     traffic = None
-    valu = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            key = f"{W}x{H}x{B}"
-            if key in tj:
-                traffic = tj[key]["hbm_bytes_per_launch"]
-                n_valu = tj[key].get("valu_wave_instructions_per_launch")
-                if n_valu:
-                    # what actually bounds the kernel: the vector ALU issue rate (one wave64 instruction per 4 clocks per SIMD)
-                    model_ms = n_valu * 4.0 / (1024 * 2.4e9) * 1e3
-                    valu = {"wave_instructions_per_launch": n_valu, "clocks_per_instruction": 4, "simds": 1024, "clock_GHz": 2.4,
-                            "issue_limited_ms": model_ms, "frac_of_issue_limit": model_ms / (float(np.mean(iso_ms))),
-                            "source": "SQ_INSTS_VALU (rocprofv3 --pmc), profiles/traffic.json"}
+            traffic = json.load(open(tpath)).get(f"{W}x{H}x{B}", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"kernel": "dg_raster_tiles", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": traffic, "algorithmic_bytes_per_launch": float(np.mean(alg_bytes)),
-                "mean_launch_ms": mean_raster_s * 1e3, "front_end_kernels_mean_ms": float(np.mean(setup_ms)),
+    roofline = {"kernel": "strip rasteriser: dg_resolve_columns + dg_raster_strips + dg_raster_strips_ov + dg_overlay_strips (one launch group)",
+                "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                "algorithmic_bytes_per_launch": float(np.mean(alg_bytes)), "mean_launch_ms": mean_raster_s * 1e3,
+                "strip_kernels_only_ms": float(np.mean(strips_ms)), "front_end_kernels_mean_ms": float(np.mean(setup_ms)),
                 "frames_per_launch": B, "pixels_per_s": B * W * H / mean_raster_s,
-                "note": "achieved/frac are measured over the timed steps, where the next step's column-walk kernels overlap this kernel; "
-                        "isolated_* is the same launch measured with nothing else on the GPU",
-                "isolated_launch_ms": float(np.mean(iso_ms)), "isolated_achieved": float(np.mean(alg_bytes)) / (float(np.mean(iso_ms)) / 1e3) / 1e9,
-                "isolated_frac": float(np.mean(alg_bytes)) / (float(np.mean(iso_ms)) / 1e3) / 1e9 / 8000.0,
-                "valu_issue": valu}
+                "note": "achieved/frac are measured over the timed steps, where the next batch's column-walk kernels and H2D overlap these kernels; "
+                        "isolated_* is the same launch group measured with nothing else on the GPU"}
+    if iso_ms:
+        iso = float(np.mean(iso_ms)) / 1e3
+        roofline.update({"isolated_launch_ms": iso * 1e3, "isolated_strip_kernels_only_ms": float(np.mean(iso_strips)),
+                         "isolated_achieved": float(np.mean(alg_bytes)) / iso / 1e9, "isolated_frac": float(np.mean(alg_bytes)) / iso / 1e9 / 8000.0})
 
-    # ---- CPU baseline (oracle = port of the reference renderer), rank 0, N = 1 only ---------------------------------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import doomref
-        osc = doomref.Scene(wad, args.map)
-        idx = list(range(0, 1000, max(1, args.cpu_sample)))
-        refs = []
-        tc = time.perf_counter()
-        for i in idx:
-            refs.append(osc.render(W, H, path[i]))
-        dt = time.perf_counter() - tc
-        cpu = {"value": len(idx) / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"every {args.cpu_sample}th frame of the same 1000-frame path at {W}x{H} ({len(idx)} frames, {dt:.1f} s), "
-                         "oracle/doomref.c -O2 -ffp-contract=off, cos/sin hoisted per frame",
-               "host_cpus": os.cpu_count()}
-        # the same oracle with the sampled frames sharded over the host cores this process may use (one scene per thread: the
-        # oracle's lazy texture caches are per scene; ctypes releases the GIL around dr_render)
-        try:
-            import threading
-            ncores = max(1, min(len(os.sched_getaffinity(0)), 64))
-            scenes = [doomref.Scene(wad, args.map) for _ in range(ncores)]
-            bufs = [np.empty(3 * W * H, dtype=np.uint8) for _ in range(ncores)]
-            for sc_t, bt in zip(scenes, bufs):
-                sc_t.render(W, H, path[0], out=bt.ctypes.data)    # warm the lazy caches outside the clock
+    report = {"rank": rank, "map_seed": map_seed, "path_seed": path_seed, "frames_per_s": args.steps * frames_per_step / elapsed_local,
+              "host_ms_per_batch": float(np.mean(host_ms)), "host_threads": getattr(ctx, "host_threads", None), "cpus": len(cpus), "cpu_binding": cpu_how}
+    reports = gather_reports(report, dist, world)
 
-            def work(t):
-                for i in idx[t::ncores]:
-                    scenes[t].render(W, H, path[i], out=bufs[t].ctypes.data)
-            th = [threading.Thread(target=work, args=(t,)) for t in range(ncores)]
-            tm = time.perf_counter()
-            for x in th:
-                x.start()
-            for x in th:
-                x.join()
-            dtm = time.perf_counter() - tm
-            cpu["all_cores"] = {"value": len(idx) / dtm, "unit": "frames/s", "cores": ncores,
-                                "sample": f"the same {len(idx)} frames sharded over {ncores} threads ({dtm:.2f} s)"}
-        except Exception as e:                            # the single-core figure above is the contract; this one is extra
-            cpu["all_cores"] = {"error": str(e)}
-        # parity of the frames the timed steps produced: every sampled frame, byte for byte, against the oracle
-        bad = 0
-        for s in range(n_slots):
-            ctx.replay(s)
-            ctx.wait(s)
-            got = ctx.readback(s, 0, B)
-            for k, i in enumerate(idx):
-                if s * B <= i < (s + 1) * B:
-                    ref = np.frombuffer(refs[k], dtype=np.uint8).reshape(H, W, 3)
-                    bad += not np.array_equal(got[i - s * B], ref)
-        cpu["gpu_frames_checked"] = sum(1 for i in idx if i < n_slots * B)
-        cpu["gpu_frames_bit_exact"] = bool(bad == 0)
-
+    line = None
     if rank == 0:
+        fe_name = "device column walk" if stats.get("front_end", 2) == 2 else "host span lists"
         line = {
             "metric": "frames/sec (fixed e1m1 camera path)", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "file" if args.wad else "synthetic",
-            "config": {"workload": (f"{os.path.basename(args.wad)} {args.map}" if args.wad else "synthetic e1m1-like IWAD (seed 1993)") + f", 1000-frame scripted camera path, {W}x{H} native, "
-                                   f"{B} frames per step, " + ("per-seg / per-sprite records" if stats.get("front_end") == dg.DG_FE_DEVICE else "span lists") +
-                                   " resident in HBM", "front_end": "device column walk" if stats.get("front_end") == dg.DG_FE_DEVICE else "host span lists",
-                       "width": W, "height": H, "frames_per_step": B,
-                       "slots": n_slots, "parallelism": f"{world} independent camera path(s), one per GPU, no collective"},
-            "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "e2e_host_frames": e2e_host,
+            "config": {"workload": (f"{os.path.basename(args.wad)} {args.map}" if args.wad else "synthetic e1m1-like IWAD (seed 1993)") +
+                                   f", 1000-frame scripted camera path, {W}x{H} native; one step = the whole path in {batches_per_step} batches of {B} frames through "
+                                   "host record generation + H2D + all kernels, frames left in HBM (SURVEY 8d)",
+                       "front_end": fe_name, "width": W, "height": H, "frames_per_step": frames_per_step, "frames_per_batch": B, "slots": n_slots,
+                       "parallelism": f"{world} independent camera path(s) (seeds 1993..{1993 + world - 1}), one per GPU, maps alternating {list(MAP_SEEDS[:min(world, 2)])}, no collective"},
+            "roofline": roofline, "cpu_baseline": cpu, "resident_replay": resident, "e2e_host_frames": e2e_host,
+            "host": {"ms_per_batch": float(np.mean(host_ms)), "threads": getattr(ctx, "host_threads", None),
+                     "list_bytes_per_frame": int(stats.get("list_bytes", 0) // max(1, stats.get("n_frames", 1)))},
+            "fallbacks": fallbacks, "per_rank": reports,
         }
         print(json.dumps(line))
     ctx.close()
     if dist is not None:
-        dist.destroy_process_group()
+        dist.barrier()
+    return line
+
+
+def cpu_baseline(args, be, ctx, n_slots, np):
+    W, H, B = args.width, args.height, args.batch
+    doomref = be.oracle()
+    path = be.path
+    osc = doomref.Scene(be.wad, args.map)
+    idx = list(range(0, PATH_FRAMES, max(1, args.cpu_sample)))
+    refs = []
+    tc = time.perf_counter()
+    for i in idx:
+        refs.append(osc.render(W, H, path[i]))
+    dt = time.perf_counter() - tc
+    cpu = {"value": len(idx) / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"every {args.cpu_sample}th frame of the same 1000-frame path at {W}x{H} ({len(idx)} frames, {dt:.1f} s), "
+                     "oracle/doomref.c -O2 -ffp-contract=off, cos/sin hoisted per frame",
+           "host_cpus": os.cpu_count()}
+    # the same oracle with the sampled frames sharded over the host cores this process may use (one scene per thread: the
+    # oracle's lazy texture caches are per scene; ctypes releases the GIL around dr_render)
+    try:
+        import threading
+        ncores = max(1, min(len(os.sched_getaffinity(0)), 64))
+        scenes = [doomref.Scene(be.wad, args.map) for _ in range(ncores)]
+        bufs = [np.empty(3 * W * H, dtype=np.uint8) for _ in range(ncores)]
+        for sc_t, bt in zip(scenes, bufs):
+            sc_t.render(W, H, path[0], out=bt.ctypes.data)    # warm the lazy caches outside the clock
+
+        def work(t):
+            for i in idx[t::ncores]:
+                scenes[t].render(W, H, path[i], out=bufs[t].ctypes.data)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(ncores)]
+        tm = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dtm = time.perf_counter() - tm
+        cpu["all_cores"] = {"value": len(idx) / dtm, "unit": "frames/s", "cores": ncores,
+                            "sample": f"the same {len(idx)} frames sharded over {ncores} threads ({dtm:.2f} s)"}
+    except Exception as e:                            # the single-core figure above is the contract; this one is extra
+        cpu["all_cores"] = {"error": str(e)}
+    # parity of the frames the timed, pipelined steps left in the slots: every sampled frame, byte for byte
+    bad = checked = 0
+    for s in range(n_slots):
+        ctx.wait(s)
+        got = ctx.readback(s, 0, B)
+        first = be.batch_first[s]
+        for k, i in enumerate(idx):
+            j = (i - first) % PATH_FRAMES
+            if j < B:
+                ref = np.frombuffer(refs[k], dtype=np.uint8).reshape(H, W, 3)
+                bad += not np.array_equal(got[j], ref)
+                checked += 1
+    cpu["gpu_frames_checked"] = checked
+    cpu["gpu_frames_bit_exact"] = bool(bad == 0)
+    cpu["gpu_frames_source"] = "the slots as the timed pipelined steps left them"
+    return cpu
+
+
+def host_frames_rate(args, be, ctx, n_slots, views, B, batches_per_step, barrier, dist, world):
+    """Every frame to page-locked host memory, D2H of batch i overlapped with the kernels of batch i + 1."""
+    dg = be.dg
+    nb = max(2 * n_slots, min(4 * batches_per_step, 16))
+    bufs = [dg.lib().dg_alloc_host(B * ctx.frame_bytes) for _ in range(n_slots)]
+    if not all(bufs):
+        return None
+    try:
+        for s in range(n_slots):
+            ctx.wait(s)
+        barrier()
+        t2 = time.perf_counter()
+        for i in range(nb):
+            s = i % n_slots
+            ctx.submit(s, views[s])                   # waits for the slot's previous readback if it is still in flight
+            ctx.readback_async(s, 0, B, bufs[s])      # queued behind the slot's kernels on its copy stream
+        for s in range(n_slots):
+            ctx.wait(s)
+        h_s = dist_max(time.perf_counter() - t2, dist)
+    finally:
+        for b in bufs:
+            dg.lib().dg_free_host(b)
+    return {"value": aggregate_fps(nb * B, world, h_s), "unit": "frames/s",
+            "includes": "the headline path + D2H of every RGB24 frame to pinned host memory, copy of batch i overlapped with the kernels of batch i + 1",
+            "d2h_GBps": nb * B * ctx.frame_bytes / h_s / 1e9}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--batch", type=int, default=250)
+    ap.add_argument("--slots", type=int, default=4)
+    ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--front-end", choices=["device", "host"], default="device", help="where the per-column half of the seg / sprite processing runs")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="cpu_baseline renders every n-th path frame")
+    ap.add_argument("--wad", default=None, help="IWAD file to render instead of the synthetic one (e.g. doom1.wad); the camera path is derived from the map")
+    ap.add_argument("--map", default="e1m1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-resident", action="store_true")
+    ap.add_argument("--no-host-frames", action="store_true")
+    return ap.parse_args(argv)
+
+
+def main(argv=None, backend_factory=DoomGpuBackend):
+    args = parse_args(argv)
+    import torch.distributed as dist
+    try:
+        return run(args, backend_factory)
+    finally:
+        if dist.is_available() and dist.is_initialized() and backend_factory is DoomGpuBackend:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -32,6 +32,7 @@
 #include "frontend.hpp"
 #include "kernels.hpp"
 #include "scene.hpp"
+#include "strip_core.h"
 
 using namespace dg;
 
@@ -115,7 +116,8 @@ struct Slot {
     DevSeg *d_segs = nullptr;
     uint8_t *d_band_first = nullptr;
     uint16_t *d_ov_first = nullptr;
-    DevSeg *d_ov_inline = nullptr;
+    DevSeg *d_ov_inline = nullptr;   // [F][OV_INLINE_MAX][W]
+    uint8_t *d_ov_cnt = nullptr;     // [F][W]
     uint32_t *d_frame_flags = nullptr, *h_frame_flags = nullptr;   // device: [F] flags followed by the band overlay bytes [F][n_bands][strips]
     // last submission
     RasterParams P{};
@@ -198,6 +200,7 @@ void free_ctx(dg_ctx *c) {
         if (s.d_band_first) (void)hipFree(s.d_band_first);
         if (s.d_ov_first) (void)hipFree(s.d_ov_first);
         if (s.d_ov_inline) (void)hipFree(s.d_ov_inline);
+        if (s.d_ov_cnt) (void)hipFree(s.d_ov_cnt);
         if (s.d_frame_flags) (void)hipFree(s.d_frame_flags);
         if (s.h_frame_flags) (void)hipHostFree(s.h_frame_flags);
         if (s.h_fe) (void)hipHostFree(s.h_fe);
@@ -224,7 +227,7 @@ void free_ctx(dg_ctx *c) {
 }
 
 void fill_strip_params(const dg_ctx *c, const Slot &s, RasterParams &P) {
-    P.segs = s.d_segs; P.band_first = s.d_band_first; P.ov_first = s.d_ov_first; P.ov_inline = s.d_ov_inline; P.frame_flags = s.d_frame_flags;
+    P.segs = s.d_segs; P.band_first = s.d_band_first; P.ov_first = s.d_ov_first; P.ov_inline = s.d_ov_inline; P.ov_cnt = s.d_ov_cnt; P.frame_flags = s.d_frame_flags;
     P.band_ovl = reinterpret_cast<uint8_t *>(s.d_frame_flags + c->cfg.max_batch);
     P.band_inl = P.band_ovl + (size_t)c->cfg.max_batch * (size_t)c->n_bands * (size_t)((c->cfg.width + 63) / 64);
     P.seg_cap = c->seg_cap; P.band_rows = c->band_rows; P.n_bands = c->n_bands; P.strips = c->strips ? 1 : 0;
@@ -667,7 +670,8 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
             CTX_TRY(hipMalloc((void **)&s.d_segs, F * (size_t)c->seg_cap * W * sizeof(DevSeg)));
             CTX_TRY(hipMalloc((void **)&s.d_band_first, F * (size_t)c->n_bands * W));
             CTX_TRY(hipMalloc((void **)&s.d_ov_first, F * W * 2));
-            CTX_TRY(hipMalloc((void **)&s.d_ov_inline, F * W * sizeof(DevSeg)));
+            CTX_TRY(hipMalloc((void **)&s.d_ov_inline, F * W * OV_INLINE_MAX * sizeof(DevSeg)));
+            CTX_TRY(hipMalloc((void **)&s.d_ov_cnt, F * W));
             CTX_TRY(hipMalloc((void **)&s.d_frame_flags, F * 4 + 2 * F * (size_t)c->n_bands * ((W + 63) / 64)));
             CTX_TRY(hipHostMalloc((void **)&s.h_frame_flags, F * 4, hipHostMallocDefault));
         }
@@ -714,12 +718,12 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     }
     if (!sc.flat_pool.empty()) HIP_TRY(hipMemcpy(c->d_flats, sc.flat_pool.data(), sc.flat_pool.size(), hipMemcpyHostToDevice));
     std::vector<uint8_t> pool;
-    uint32_t pool_opq = 0;
-    const uint32_t pool_flats = sc.build_strip_pool(pool, pool_opq);
+    uint32_t pool_opq = 0, pool_tx16 = 0, pool_tx16_flats = 0;
+    const uint32_t pool_flats = sc.build_strip_pool(pool, pool_opq, pool_tx16, pool_tx16_flats);
     HIP_TRY(hipMalloc((void **)&c->d_pool, std::max<size_t>(pool.size(), 16)));
     if (!pool.empty()) HIP_TRY(hipMemcpy(c->d_pool, pool.data(), pool.size(), hipMemcpyHostToDevice));
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
-    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, c->d_pool, pool_flats, pool_opq, sky.texel_off, sky.w, sky.h, sky.has_holes};
+    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, c->d_pool, pool_flats, pool_opq, pool_tx16, pool_tx16_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
     if (!c->d_row_tab) HIP_TRY(hipMalloc((void **)&c->d_row_tab, (size_t)c->cfg.height * sizeof(uint4)));
     HIP_TRY(launch_row_table(c->dscene, c->dk, c->d_row_tab, nullptr));
     HIP_TRY(hipDeviceSynchronize());

@@ -248,17 +248,19 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
 
 // ---- strip path ---------------------------------------------------------------------------------------------------------
 
-constexpr int RES_STAGE = 48;     // row-range words of a column staged in LDS by dg_resolve_columns (longer columns read HBM)
+constexpr int RES_STAGE = 24;     // row-range words of a column staged in LDS by dg_resolve_columns (longer columns read HBM)
 
 // One lane per (frame, screen column): strip_core.h resolve_column.  The row-range words (w0) of the column's spans are
 // staged in LDS first (independent loads, all in flight at once), then the scan over boundaries x spans runs out of LDS.
 // Real columns hold 2-8 spans.  Negligible next to the raster kernels (320 000 columns per launch against 256 M pixels).
-__global__ __launch_bounds__(64) void dg_resolve_columns(RasterParams P) {
-    __shared__ uint32_t lw0[RES_STAGE * 64];
+__global__ __launch_bounds__(256) void dg_resolve_columns(RasterParams P) {
+    __shared__ uint32_t lw0_all[4][RES_STAGE * 64];
     const int f = blockIdx.y;
     const int W = P.k.W, H = P.k.H;
-    const int lane = threadIdx.x;
-    const int x = (int)blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x & 63;
+    const uint32_t strip = blockIdx.x * 4 + (threadIdx.x >> 6), n_strips = (uint32_t)(W + 63) / 64;
+    uint32_t *lw0 = lw0_all[threadIdx.x >> 6];
+    const int x = (int)strip * 64 + lane;
     const DevFrame fr = P.frames[f];
     if (x >= W) return;                               // no barrier below: the staging area is private to a lane
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
@@ -278,26 +280,22 @@ __global__ __launch_bounds__(64) void dg_resolve_columns(RasterParams P) {
                                            P.band_first + (size_t)f * (size_t)P.n_bands * (size_t)W + (size_t)x, (size_t)W);
     if (r.n_segs == 0xffffffffu) atomicOr(&P.frame_flags[f], 1u);
     P.ov_first[(size_t)f * (size_t)W + (size_t)x] = (uint16_t)r.n_base;
-    // Overlay spans.  The common case — exactly one, a masked wall or sprite column — travels with the strip kernel as one
-    // 32-byte record per column (ov_inline) and is applied in the same pass.  Columns with more go to dg_overlay_strips: the
-    // bands their spans touch are flagged (same value from every writer).
-    DevSeg ov = seg_none(0);
-    ov.w[0] = 0x3fffu;                                // first row > last row: no inline overlay
-    if (overlay_is_inline(n - r.n_base, n > r.n_base ? w0_at(r.n_base) : 0u)) {
-        ov = seg_from_span(spans[r.n_base], 0, P.scene);
-        ov.w[0] = w0_at(r.n_base);
-        uint8_t *bi = P.band_inl + (size_t)f * (size_t)P.n_bands * (size_t)gridDim.x + blockIdx.x;
-        for (int b = w0_ctop(ov.w[0]) / P.band_rows; b <= w0_cbot(ov.w[0]) / P.band_rows; b++) bi[(size_t)b * (size_t)gridDim.x] = 1;
-    } else {
-        uint8_t *bo = P.band_ovl + (size_t)f * (size_t)P.n_bands * (size_t)gridDim.x + blockIdx.x;
-        for (uint32_t j = r.n_base; j < n; j++) {
-            const uint32_t w0 = w0_at(j);
-            for (int b = w0_ctop(w0) / P.band_rows; b <= w0_cbot(w0) / P.band_rows; b++) bo[(size_t)b * (size_t)gridDim.x] = 1;
+    // Overlay spans (strip_core.h overlay_inline_count): up to OV_INLINE_MAX of them go to dg_raster_strips_ov as
+    // per-column records; anything else to dg_overlay_strips.  Either way the bands they touch are flagged (same value from
+    // every writer).
+    const uint32_t k_inl = overlay_inline_count(n - r.n_base);
+    P.ov_cnt[(size_t)f * (size_t)W + (size_t)x] = (uint8_t)k_inl;
+    uint8_t *bflag = (k_inl ? P.band_inl : P.band_ovl) + (size_t)f * (size_t)P.n_bands * (size_t)n_strips + strip;
+    for (uint32_t j = r.n_base; j < n; j++) {
+        const uint32_t w0 = w0_at(j);
+        for (int b = w0_ctop(w0) / P.band_rows; b <= w0_cbot(w0) / P.band_rows; b++) bflag[(size_t)b * (size_t)n_strips] = 1;
+        if (k_inl) {
+            const DevSeg ov = overlay_record(spans[j], P.scene);
+            uint4 *od = reinterpret_cast<uint4 *>(P.ov_inline + ((size_t)f * OV_INLINE_MAX + (j - r.n_base)) * (size_t)W + (size_t)x);
+            od[0] = make_uint4(ov.w[0], ov.w[1], ov.w[2], ov.w[3]);
+            od[1] = make_uint4(ov.w[4], ov.w[5], ov.w[6], ov.w[7]);
         }
     }
-    uint4 *od = reinterpret_cast<uint4 *>(P.ov_inline + (size_t)f * (size_t)W + (size_t)x);
-    od[0] = make_uint4(ov.w[0], ov.w[1], ov.w[2], ov.w[3]);
-    od[1] = make_uint4(ov.w[4], ov.w[5], ov.w[6], ov.w[7]);
 }
 
 // What a lane of dg_raster_strips keeps about its column's current segment: the DevSeg words it needs per pixel, unpacked
@@ -343,25 +341,19 @@ typedef const u32x4 __attribute__((address_space(4))) *RowTabPtr;   // "constant
 // OV = this (strip, band) has columns with an inline overlay span (a masked wall or sprite column, strip_core.h): the second
 // instantiation carries that span per lane and applies it in the same pass.  Each (strip, band) is rendered by exactly one
 // of the two kernels (band_inl), so the common one keeps 8 wavefronts per SIMD.
+// band: the band this wavefront renders; ov_tab / ov_w0: the strip's inline overlay records in LDS ([layer][lane], OV only).
 template <bool OV>
-__device__ __forceinline__ void strips_body(const RasterParams &P, float4 *palf, uint32_t *rowbuf) {
+__device__ __forceinline__ void strips_body(const RasterParams &P, int band, const float4 *palf, uint32_t *rowbuf, const uint4 *ov_tab, uint32_t ov_n) {
     const int f = blockIdx.z;
-    if (P.frame_flags[f] != 0u) return;               // segment slots exceeded: the batch is redone by dg_raster_tiles
-    if ((P.band_inl[((size_t)f * (size_t)P.n_bands + blockIdx.y) * (size_t)gridDim.x + blockIdx.x] != 0) != OV) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int W = P.k.W, H = P.k.H;
     const int x0 = (int)blockIdx.x * 64;
-    const int y_lo = (int)blockIdx.y * P.band_rows;
+    const int y_lo = band * P.band_rows;
     const int y_hi = min(H, y_lo + P.band_rows) - 1;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t c = P.scene.palette[lane + 64 * k];
-        palf[lane + 64 * k] = make_float4((float)(c & 255u), (float)((c >> 8) & 255u), (float)((c >> 16) & 255u), 0.0f);
-    }
     const DevFrame fr = P.frames[f];
     const bool in_w = x0 + lane < W;
     const int x = in_w ? x0 + lane : W - 1;           // lanes past the right edge shadow the last column and store nothing
-    const uint32_t s0 = P.band_first[((size_t)f * (size_t)P.n_bands + blockIdx.y) * (size_t)W + (size_t)x];
+    const uint32_t s0 = P.band_first[((size_t)f * (size_t)P.n_bands + (size_t)band) * (size_t)W + (size_t)x];
     const uint8_t *segs_f = reinterpret_cast<const uint8_t *>(P.segs + (size_t)f * (size_t)P.seg_cap * (size_t)W);   // wave-uniform
     const uint32_t seg_step = (uint32_t)W * 32u;
     uint32_t seg_at = (s0 * (uint32_t)W + (uint32_t)x) * 32u;       // byte offset of the lane's NEXT segment
@@ -374,7 +366,6 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, float4 *palf,
         seg_at += seg_step;
         if (S.end < H - 1) { na = *reinterpret_cast<const uint4 *>(segs_f + seg_at); nb = *reinterpret_cast<const uint4 *>(segs_f + seg_at + 16); }
     }
-    __syncthreads();
     const uint8_t *pool = P.scene.pool;
     const uint32_t sky_w = (uint32_t)P.scene.sky_w;
     const RowTabPtr rows = (RowTabPtr)(uintptr_t)P.row_tab;
@@ -391,16 +382,14 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, float4 *palf,
     uint8_t *rowp = P.fb + (((size_t)f * (size_t)H + (size_t)y_lo) * (size_t)W + (size_t)x0) * 3;
     int parked = 0;                                   // rows in rowbuf
 
-    // the column's inline overlay span, clipped to this band (o_t > o_b: none)
-    uint4 oa = make_uint4(0x3fffu, 0, 0, 0), ob = make_uint4(0, 0, 0, 0);
+    // Inline overlay spans of this column (ov_n layers at most in this strip): rows of the band on which some column of the
+    // strip has an overlay pixel, wave-uniform.
+    int ov_lo = 0x7fff, ov_hi = -1;
     if constexpr (OV) {
-        oa = reinterpret_cast<const uint4 *>(P.ov_inline + (size_t)f * (size_t)W + (size_t)x)[0];
-        ob = reinterpret_cast<const uint4 *>(P.ov_inline + (size_t)f * (size_t)W + (size_t)x)[1];
-    }
-    const int o_t = max(w0_ctop(oa.x), y_lo), o_b = min(w0_cbot(oa.x), y_hi);
-    const bool o_holes = w0_immediate(oa.x);
-    int ov_lo = o_t, ov_hi = o_b;                     // rows of this band on which some column of the strip has overlay pixels
-    if constexpr (OV) {
+        for (uint32_t j = 0; j < ov_n; j++) {
+            const uint32_t w0 = ov_tab[(j * 64 + (uint32_t)lane) * 2].x;      // first row > last row in unused slots
+            ov_lo = min(ov_lo, max(w0_ctop(w0), y_lo)); ov_hi = max(ov_hi, min(w0_cbot(w0), y_hi));
+        }
         for (int o = 32; o > 0; o >>= 1) { ov_lo = min(ov_lo, __shfl_xor(ov_lo, o)); ov_hi = max(ov_hi, __shfl_xor(ov_hi, o)); }
         ov_lo = __builtin_amdgcn_readfirstlane(ov_lo); ov_hi = __builtin_amdgcn_readfirstlane(ov_hi);
     }
@@ -417,7 +406,7 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, float4 *palf,
     // What one row has in flight between its two halves.  The loads are issued with inline assembly and waited for with an
     // explicit s_waitcnt in row_b: hipcc's own wait insertion would also wait for the row buffer's STORE before it lets the
     // texel be used, which serialises the rows.
-    struct Row { uint32_t tex; float fac; uint32_t otex, oopq; float ofac; };
+    struct Row { uint32_t tex; float fac; };
 
     // visplanes.rs:108-126 for a floor / ceiling pixel within the divide shortcut's verified domain
     auto flat_px = [&](float vy, float r_vy, float &fac) {
@@ -478,18 +467,6 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, float4 *palf,
             }
         }
         asm volatile("global_load_ubyte %0, %1, %2" : "=v"(R.tex) : "v"(off), "s"(pool) : "memory");
-        // the column's masked-wall / sprite pixel of this row, if any (bitmap_render.rs:256-265): texel and opacity
-        if constexpr (OV) {
-            R.otex = 0; R.oopq = 0; R.ofac = -1.0f;   // a negative factor marks "no overlay pixel here"
-            if (y >= ov_lo && y <= ov_hi) {           // wave-uniform
-                const bool on = y >= o_t && y <= o_b;
-                uint32_t oo = 0;
-                if (on) oo = seg_wall_offset(oa.y, oa.z, ob.x, ob.y, ob.z, ob.w, y);
-                asm volatile("global_load_ubyte %0, %1, %2" : "=v"(R.otex) : "v"(oo), "s"(pool) : "memory");
-                asm volatile("global_load_ubyte %0, %1, %2" : "=v"(R.oopq) : "v"(oo), "s"(pool + P.scene.pool_opq) : "memory");
-                if (on) R.ofac = bits_f32(oa.w);
-            }
-        }
     };
     // `n` parked rows (192 bytes each) -> HBM.
     auto flush_rows = [&](int n) {
@@ -505,13 +482,40 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, float4 *palf,
     // among themselves (a store may complete before an older load), so the only operation that may stay in flight is the one
     // load known to be younger than this row's: the next row's texel.  Anything else issued in between — segment prefetches,
     // overlay texels, the row buffer's store — only makes the wait stricter.
-    auto row_b = [&](Row &R, bool keep) {
-        if constexpr (OV) asm volatile("s_waitcnt vmcnt(1)" : "+v"(R.tex), "+v"(R.otex), "+v"(R.oopq) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(1)" : "+v"(R.tex) : : "memory");
+    auto row_b = [&](Row &R, int y, bool keep) {
+        asm volatile("s_waitcnt vmcnt(1)" : "+v"(R.tex) : : "memory");
         uint32_t tex = R.tex;
         float fac = R.fac;
         if constexpr (OV) {
-            if (R.ofac >= 0.0f && (R.oopq != 0u || !o_holes)) { tex = R.otex; fac = R.ofac; }   // an opaque overlay texel wins
+            // The column's masked-wall / sprite pixels of this row, in draw order (bitmap_render.rs:256-265): an opaque texel
+            // replaces what is there.  All layers' texels are requested before the first is looked at.
+            if (y >= ov_lo && y <= ov_hi) {           // wave-uniform
+                const u32x4 rc = rows[y];             // floors / ceilings and sky among the overlay spans need the row constants
+                const uint16_t *tx16 = reinterpret_cast<const uint16_t *>(pool + P.scene.pool_tx16);
+                for (uint32_t g = 0; g < ov_n; g += 4) {          // four layers at a time: their texels are requested together
+                    uint32_t o_off[4], o_t16[4], o_w0[4];
+                    float o_fac[4];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; q++) {
+                        const uint32_t j = g + q;
+                        o_off[q] = 0; o_fac[q] = 0.0f; o_w0[q] = 0x3fffu;          // first row > last row: not here
+                        if (j < ov_n) {               // wave-uniform
+                            const uint4 a = ov_tab[(j * 64 + (uint32_t)lane) * 2];
+                            if (y >= w0_ctop(a.x) && y <= w0_cbot(a.x)) {
+                                const uint4 b = ov_tab[(j * 64 + (uint32_t)lane) * 2 + 1];
+                                const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+                                if (overlay_texel(P.scene, fr, aw, bw, y, bits_f32(rc.z), bits_f32(rc.x), (int32_t)rc.y, o_off[q], o_fac[q])) o_w0[q] = a.x;
+                                else o_off[q] = 0;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; q++) o_t16[q] = g + q < ov_n ? (uint32_t)tx16[o_off[q]] : 0u;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; q++)
+                        if (g + q < ov_n && w0_ctop(o_w0[q]) <= w0_cbot(o_w0[q]) && ((o_t16[q] >> 8) != 0u || !w0_immediate(o_w0[q]))) { tex = o_t16[q] & 255u; fac = o_fac[q]; }
+                }
+            }
         }
         const float4 c = palf[tex];
         uint32_t px;
@@ -535,25 +539,74 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, float4 *palf,
     row_a(y_lo, A);
     for (int y = y_lo; y <= y_hi; y += 2) {           // two rows per trip so that the in-flight texel needs no register move
         row_a(min(y + 1, y_hi), B);
-        row_b(A, true);
+        row_b(A, y, true);
         row_a(min(y + 2, y_hi), A);
-        row_b(B, y + 1 <= y_hi);
+        row_b(B, y + 1, y + 1 <= y_hi);
     }
-    if constexpr (OV) asm volatile("s_waitcnt vmcnt(0)" : "+v"(A.tex), "+v"(A.otex), "+v"(A.oopq) : : "memory");   // the last, unused look-ahead
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(A.tex) : : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(A.tex) : : "memory");   // the last, unused look-ahead
     if (parked) flush_rows(parked);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(64) void dg_raster_strips(RasterParams P) {
-    __shared__ float4 palf[256];                      // palette as f32 triples: shading needs no v_cvt_f32_ubyte
-    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[4 * 48];   // four finished rows of the strip (RGB24, 192 B each)
-    strips_body<false>(P, palf, rowbuf);
+__device__ __forceinline__ void stage_palette(const RasterParams &P, float4 *palf, int tid, int nthreads) {
+    for (int i = tid; i < 256; i += nthreads) {
+        const uint32_t c = P.scene.palette[i];
+        palf[i] = make_float4((float)(c & 255u), (float)((c >> 8) & 255u), (float)((c >> 16) & 255u), 0.0f);
+    }
 }
-__global__ __launch_bounds__(64) void dg_raster_strips_ov(RasterParams P) {
+
+// Bands without inline overlay spans.  Four wavefronts = four consecutive bands of one strip per workgroup: the wavefronts
+// are independent, but the workgroup dispatcher launches only ~0.3 workgroups per ns, so 80 000 one-wave workgroups would
+// cost more than the rendering itself.
+__global__ __launch_bounds__(256) void dg_raster_strips(RasterParams P) {
+    __shared__ float4 palf[256];                      // palette as f32 triples: shading needs no v_cvt_f32_ubyte
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[4][4 * 48];   // per wave: four finished rows of the strip (RGB24, 192 B each)
+    const int f = blockIdx.z;
+    if (P.frame_flags[f] != 0u) return;               // segment slots exceeded: the batch is redone by dg_raster_tiles
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    stage_palette(P, palf, threadIdx.x, 256);
+    __syncthreads();
+    const int band = (int)blockIdx.y * 4 + wave;
+    if (band >= P.n_bands || P.band_inl[((size_t)f * (size_t)P.n_bands + (size_t)band) * (size_t)gridDim.x + blockIdx.x] != 0) return;   // dg_raster_strips_ov
+    strips_body<false>(P, band, palf, rowbuf[wave], nullptr, 0u);
+}
+
+// Bands with inline overlay spans: four wavefronts = four consecutive bands of one strip per workgroup, which share the
+// strip's overlay records (OV_INLINE_MAX x 64 columns x 32 bytes) and the palette in LDS.
+__global__ __launch_bounds__(256) void dg_raster_strips_ov(RasterParams P) {
     __shared__ float4 palf[256];
-    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[4 * 48];
-    strips_body<true>(P, palf, rowbuf);
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[4][4 * 48];
+    __shared__ __attribute__((aligned(16))) uint4 ov_tab[OV_INLINE_MAX * 64 * 2];
+    const int f = blockIdx.z;
+    if (P.frame_flags[f] != 0u) return;
+    const int W = P.k.W;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int band0 = (int)blockIdx.y * 4;
+    const uint8_t *binl = P.band_inl + (size_t)f * (size_t)P.n_bands * (size_t)gridDim.x + blockIdx.x;
+    bool any = false;
+    for (int b = band0; b < min(band0 + 4, P.n_bands); b++) any |= binl[(size_t)b * (size_t)gridDim.x] != 0;
+    if (!any) return;                                 // workgroup-uniform
+    stage_palette(P, palf, threadIdx.x, 256);
+    // layer `wave` of the strip's 64 columns (slots beyond a column's count read as "first row > last row")
+    const int x = (int)blockIdx.x * 64 + lane;
+    const uint32_t cnt = x < W ? P.ov_cnt[(size_t)f * (size_t)W + (size_t)x] : 0u;
+    uint32_t n_layers = cnt;
+    for (int o = 32; o > 0; o >>= 1) n_layers = max(n_layers, (uint32_t)__shfl_xor((int)n_layers, o));
+    for (uint32_t j = (uint32_t)wave; j < OV_INLINE_MAX; j += 4) {
+        uint4 a = make_uint4(0x3fffu, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+        if (j < cnt) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(P.ov_inline + ((size_t)f * OV_INLINE_MAX + j) * (size_t)W + (size_t)x);
+            a = src[0]; b = src[1];
+        }
+        if (j < n_layers) {
+            ov_tab[(j * 64 + (uint32_t)lane) * 2] = a;
+            ov_tab[(j * 64 + (uint32_t)lane) * 2 + 1] = b;
+        }
+    }
+    __syncthreads();
+    const int band = band0 + wave;
+    if (band >= P.n_bands || binl[(size_t)band * (size_t)gridDim.x] == 0) return;     // that band belongs to dg_raster_strips
+    strips_body<true>(P, band, palf, rowbuf[wave], ov_tab, __builtin_amdgcn_readfirstlane(n_layers));
 }
 
 // The spans dg_resolve_columns left in draw order (from a column's first possibly-transparent span on: masked walls and
@@ -562,19 +615,23 @@ __global__ __launch_bounds__(64) void dg_raster_strips_ov(RasterParams P) {
 // every column; layers run in order, a layer's rows run top to bottom with the row wave-uniform, and a lane stores its 3
 // bytes only where the texel is opaque — so "later draw call wins" is simply the order of this wave's stores, and nothing
 // has to be read back.
-__global__ __launch_bounds__(64) void dg_overlay_strips(RasterParams P) {
+__global__ __launch_bounds__(256) void dg_overlay_strips(RasterParams P) {
     __shared__ uint32_t pal[256];
-    const int f = blockIdx.z;
+    const int f = blockIdx.y;
     if (P.frame_flags[f] != 0u) return;
-    if (!P.band_ovl[((size_t)f * (size_t)P.n_bands + blockIdx.y) * (size_t)gridDim.x + blockIdx.x]) return;
-    const int lane = threadIdx.x;
+    const uint8_t *bovl = P.band_ovl + (size_t)f * (size_t)P.n_bands * (size_t)gridDim.x + blockIdx.x;
+    bool any = false;
+    for (int b = 0; b < P.n_bands; b++) any |= bovl[(size_t)b * (size_t)gridDim.x] != 0;
+    if (!any) return;                                 // workgroup-uniform: the usual case (real columns have few overlay spans)
+    const int lane = threadIdx.x & 63;
     const int W = P.k.W, H = P.k.H;
     const int x = (int)blockIdx.x * 64 + lane;
-    const int y_lo = (int)blockIdx.y * P.band_rows;
-    const int y_hi = min(H, y_lo + P.band_rows) - 1;
-#pragma unroll
-    for (int k = 0; k < 4; k++) pal[lane + 64 * k] = P.scene.palette[lane + 64 * k];
+    pal[threadIdx.x] = P.scene.palette[threadIdx.x];
     __syncthreads();
+    for (int band = (int)(threadIdx.x >> 6); band < P.n_bands; band += 4) {
+    if (!bovl[(size_t)band * (size_t)gridDim.x]) continue;
+    const int y_lo = band * P.band_rows;
+    const int y_hi = min(H, y_lo + P.band_rows) - 1;
     const DevFrame fr = P.frames[f];
     uint32_t k_spans = 0;
     const DevRSpan *spans = P.rspans;
@@ -584,7 +641,7 @@ __global__ __launch_bounds__(64) void dg_overlay_strips(RasterParams P) {
         const uint32_t o = coff[x], n = coff[x + 1] - o;
         k_spans = n - first;
         spans = P.rspans + fr.span_base + o + first;
-        if (k_spans && overlay_is_inline(k_spans, spans[0].w[0])) k_spans = 0;      // dg_raster_strips applied it
+        if (P.ov_cnt[(size_t)f * (size_t)W + (size_t)x] != 0) k_spans = 0;        // dg_raster_strips_ov applied them
     }
     const uint8_t *pool = P.scene.pool;
     uint8_t *fbx = P.fb + ((size_t)f * (size_t)H * (size_t)W + (size_t)(x < W ? x : 0)) * 3;
@@ -629,6 +686,7 @@ __global__ __launch_bounds__(64) void dg_overlay_strips(RasterParams P) {
                 p[0] = (uint8_t)color; p[1] = (uint8_t)(color >> 8); p[2] = (uint8_t)(color >> 16);
             }
         }
+    }
     }
 }
 
@@ -689,10 +747,10 @@ hipError_t launch_raster(const RasterParams &P, hipStream_t stream) {
         hipError_t e = hipMemsetAsync(P.frame_flags, 0, (size_t)(reinterpret_cast<uint8_t *>(P.band_inl) - reinterpret_cast<uint8_t *>(P.frame_flags)) +
                                                            (size_t)P.n_frames * (size_t)P.n_bands * strips, stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(dg_resolve_columns, dim3(strips, (unsigned)P.n_frames), dim3(64), 0, stream, P);
-        hipLaunchKernelGGL(dg_raster_strips, dim3(strips, (unsigned)P.n_bands, (unsigned)P.n_frames), dim3(64), 0, stream, P);
-        hipLaunchKernelGGL(dg_raster_strips_ov, dim3(strips, (unsigned)P.n_bands, (unsigned)P.n_frames), dim3(64), 0, stream, P);
-        hipLaunchKernelGGL(dg_overlay_strips, dim3(strips, (unsigned)P.n_bands, (unsigned)P.n_frames), dim3(64), 0, stream, P);
+        hipLaunchKernelGGL(dg_resolve_columns, dim3((strips + 3) / 4, (unsigned)P.n_frames), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL(dg_raster_strips, dim3(strips, (unsigned)((P.n_bands + 3) / 4), (unsigned)P.n_frames), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL(dg_raster_strips_ov, dim3(strips, (unsigned)((P.n_bands + 3) / 4), (unsigned)P.n_frames), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL(dg_overlay_strips, dim3(strips, (unsigned)P.n_frames), dim3(256), 0, stream, P);
         return hipGetLastError();
     }
     dim3 grid(strips, (unsigned)((P.k.H + TILE_H - 1) / TILE_H), (unsigned)P.n_frames);

@@ -23,8 +23,8 @@ struct RasterParams {
     DevSeg *segs;                // [n_frames][seg_cap][W]
     uint8_t *band_first;         // [n_frames][n_bands][W] slot of the segment that contains the first row of a band
     uint16_t *ov_first;          // [n_frames][W] index (within the column's draw-ordered spans) of the first overlay span
-    DevSeg *ov_inline;           // [n_frames][W] the column's overlay span when it has exactly one (DevSeg words 1-7 of a wall, word 0 = the
-                                 // span's DevRSpan word 0); first row > last row: none
+    DevSeg *ov_inline;           // [n_frames][OV_INLINE_MAX][W] the column's inline overlay spans in draw order (strip_core.h overlay_record)
+    uint8_t *ov_cnt;             // [n_frames][W] how many of them (0: none, or the column goes through dg_overlay_strips)
     uint32_t *frame_flags;       // [n_frames] != 0: a column needed more than seg_cap segments; the batch is redone with strips = 0
     uint8_t *band_ovl;           // [n_frames][n_bands][ceil(W / 64)] != 0: an overlay span touches that band of that 64-column strip
     uint8_t *band_inl;           // same shape: a column of that strip has an INLINE overlay span (strip_core.h) in that band -> dg_raster_strips_ov

@@ -55,10 +55,18 @@ DG_HD DevSeg seg_none(int32_t end) {
     return o;
 }
 
-// A column whose overlay is exactly one wall-kind span (a masked wall or a sprite column) is handled inside
-// dg_raster_strips; everything else goes through dg_overlay_strips.  w0 = word 0 of the column's first overlay span.
-DG_HD bool overlay_is_inline(uint32_t n_overlay, uint32_t w0) { return n_overlay == 1u && w0_kind(w0) == SPAN_WALL; }
-
+// Overlay spans of a column (the draw-ordered rest after the resolved prefix).  Up to OV_INLINE_MAX of them (24 KB of LDS per
+// strip in dg_raster_strips_ov; real columns hold 0-6) travel with dg_raster_strips_ov as per-column records and are applied
+// in the same pass; longer lists go through dg_overlay_strips.  Returns how many spans the strip kernel applies (0 or all).
+constexpr uint32_t OV_INLINE_MAX = 12;
+DG_HD uint32_t overlay_inline_count(uint32_t n_overlay) { return n_overlay <= OV_INLINE_MAX ? n_overlay : 0u; }
+// The record of one inline overlay span: its DevSeg (row-major offsets, prepared reciprocal), except that word 0 keeps the
+// span's own row-range word (ctop | imm << 15 | cbot << 16) with the SEGMENT kind in bits 30-31 (SEG_NONE: draws nothing).
+DG_HD DevSeg overlay_record(const DevRSpan &sp, const DevScene &sc) {
+    DevSeg o = seg_from_span(sp, 0, sc);
+    o.w[0] = (sp.w[0] & 0x3fffffffu) | (o.w[0] & 0xc0000000u);
+    return o;
+}
 struct ResolveResult {
     uint32_t n_segs;      // segments written (0xffffffff: more than `cap`, nothing usable was written)
     uint32_t n_base;      // spans [0, n_base) were resolved; spans [n_base, n) are the overlay, still in draw order
@@ -84,6 +92,8 @@ DG_HD ResolveResult resolve_column(W0At w0_at, const DevRSpan *spans, uint32_t n
     }
     uint32_t nseg = 0;
     int32_t row = 0, pend_owner = -2, pend_start = 0;
+    DevRSpan pend_span = {};                          // the pending owner's words, requested when it becomes the owner: by the time
+                                                      // its segment is flushed (a boundary scan later) the load has landed
     // One elementary interval per iteration: [row, next boundary).  Its owner is the last span covering `row`; adjacent
     // intervals with the same owner merge.  At most 2 * nb + 1 iterations of nb steps each; nb is 2-8 in real scenes.
     for (;;) {
@@ -100,11 +110,12 @@ DG_HD ResolveResult resolve_column(W0At w0_at, const DevRSpan *spans, uint32_t n
         if (owner != pend_owner || row >= H) {
             if (pend_owner != -2) {                                       // flush [pend_start, row - 1]
                 if (nseg >= cap) { res.n_segs = 0xffffffffu; return res; }
-                seg_out[(size_t)nseg * seg_stride] = pend_owner < 0 ? seg_none(row - 1) : seg_from_span(spans[pend_owner], row - 1, sc);
+                seg_out[(size_t)nseg * seg_stride] = pend_owner < 0 ? seg_none(row - 1) : seg_from_span(pend_span, row - 1, sc);
                 for (int32_t b = (pend_start + band_rows - 1) / band_rows; b * band_rows < row; b++) band_out[(size_t)b * band_stride] = (uint8_t)nseg;
                 nseg++;
             }
             pend_owner = owner; pend_start = row;
+            if (owner >= 0) pend_span = spans[owner];
         }
         if (row >= H) break;
         row = next;
@@ -139,6 +150,20 @@ DG_HD uint32_t seg_flat_offset(const DevFrame &f, uint32_t w1, uint32_t w2, uint
     // two, so the product is exact and the fused form rounds exactly like the reference's separate multiply and subtract.
     factor = __builtin_fmaf(-(float)f32_as_i16(wx), 1.0f / (16.0f * 256.0f), bits_f32(w5));
     return w2 + (uint32_t)(ty * 64 + tx);
+}
+
+// Offset into the u16 texel plane (index | opaque << 8) and light factor of one overlay pixel; false: nothing is drawn.
+// vy = CFY - y, r_vy = prepare_rcp(vy), srow = sky texture row of y (or -1).
+DG_HD bool overlay_texel(const DevScene &sc, const DevFrame &f, const uint32_t *a, const uint32_t *b, int32_t y, float vy, float r_vy, int32_t srow,
+                         uint32_t &off16, float &fac) {
+    const uint32_t kind = seg_kind(a[0]);
+    if (kind == SPAN_WALL) { off16 = seg_wall_offset(a[1], a[2], b[0], b[1], b[2], b[3], y); fac = bits_f32(a[3]); return true; }
+    if (kind == SPAN_FLAT) {
+        off16 = sc.pool_tx16_flats + (seg_flat_offset(f, a[1], a[2], b[0], b[1], b[2], vy, r_vy, fac) - sc.pool_flats);
+        return true;
+    }
+    if (kind == SPAN_SKY && srow >= 0) { off16 = a[2] + (uint32_t)srow * (uint32_t)sc.sky_w; fac = 1.0f; return true; }
+    return false;
 }
 
 }  // namespace dg

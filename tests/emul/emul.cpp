@@ -61,7 +61,7 @@ static void raster_spans(const DevScene &ds, const DevConsts &k, const DevFrame 
 static bool raster_strips_check(const Scene &sc, DevScene ds, const DevConsts &k, const DevFrame &hdr, const uint32_t *pal, const uint32_t *col_off,
                                 const DevRSpan *rs, int W, int H, const uint8_t *expect) {
     std::vector<uint8_t> pool;
-    ds.pool_flats = sc.build_strip_pool(pool, ds.pool_opq);
+    ds.pool_flats = sc.build_strip_pool(pool, ds.pool_opq, ds.pool_tx16, ds.pool_tx16_flats);
     ds.pool = pool.data();
     int band_rows = std::max(1, (H + 8 * ((H + 511) / 512) - 1) / (8 * ((H + 511) / 512)));   // = strip_band_rows(H), kernels.hip
     const int n_bands = (H + band_rows - 1) / band_rows;
@@ -98,23 +98,27 @@ static bool raster_strips_check(const Scene &sc, DevScene ds, const DevConsts &k
             }
             start = end + 1;
         }
+        const uint32_t k_inl = overlay_inline_count(n - r.n_base);
         {
             const uint32_t k = n - r.n_base;
-            const bool inl = overlay_is_inline(k, k ? sp[r.n_base].w[0] : 0u);
-            g_ov_stats[k == 0 ? 0 : k == 1 ? (inl ? 1 : 2) : k == 2 ? 3 : 4]++;
+            g_ov_stats[k == 0 ? 0 : k_inl ? 1 : 2]++;
             g_ov_hist[k < 15 ? k : 15]++;
             for (uint32_t i = r.n_base; i < n; i++) g_ov_px[k < 15 ? k : 15] += (uint64_t)(w0_cbot(sp[i].w[0]) - w0_ctop(sp[i].w[0]) + 1);
-            if (k >= 2) for (uint32_t i = r.n_base; i < n; i++) g_ov_stats[5] += (uint64_t)(w0_cbot(sp[i].w[0]) - w0_ctop(sp[i].w[0]) + 1);
         }
-        if (overlay_is_inline(n - r.n_base, n > r.n_base ? sp[r.n_base].w[0] : 0u)) {   // dg_raster_strips: the single overlay span, as a segment
-            DevSeg ov = seg_from_span(sp[r.n_base], 0, ds);
-            const uint32_t w0 = sp[r.n_base].w[0];
-            for (int y = w0_ctop(w0); y <= w0_cbot(w0); y++) {
-                const uint32_t o = seg_wall_offset(ov.w[1], ov.w[2], ov.w[4], ov.w[5], ov.w[6], ov.w[7], y);
-                if (w0_immediate(w0) && !pool[ds.pool_opq + o]) continue;
-                const uint32_t c = shade(pal[pool[o]], bits_f32(ov.w[3]));
-                uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
-                p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
+        if (k_inl) {                                                  // dg_raster_strips_ov: the overlay spans as records, in draw order
+            for (uint32_t i = r.n_base; i < n; i++) {
+                const DevSeg ov = overlay_record(sp[i], ds);
+                for (int y = w0_ctop(ov.w[0]); y <= w0_cbot(ov.w[0]); y++) {
+                    uint32_t o;
+                    float fac;
+                    const float vy = k.CFY - (float)y;
+                    if (!overlay_texel(ds, hdr, ov.w, ov.w + 4, y, vy, prepare_rcp(vy), sky_row(ds, k, y), o, fac)) continue;
+                    const uint32_t t16 = (uint32_t)pool[ds.pool_tx16 + 2 * o] | ((uint32_t)pool[ds.pool_tx16 + 2 * o + 1] << 8);
+                    if (w0_immediate(ov.w[0]) && !(t16 >> 8)) continue;
+                    const uint32_t c = shade(pal[t16 & 255u], fac);
+                    uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
+                    p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
+                }
             }
         } else
         for (uint32_t i = r.n_base; i < n; i++) {                    // dg_overlay_strips: the spans from the first possibly-transparent one on
