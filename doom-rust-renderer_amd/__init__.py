@@ -44,7 +44,7 @@ class DgTiming(ctypes.Structure):
                 ("host_ms", ctypes.c_float),
                 ("n_spans", ctypes.c_uint64), ("n_frames", ctypes.c_uint64), ("covered_pixels", ctypes.c_uint64),
                 ("n_walls", ctypes.c_uint64), ("n_planes", ctypes.c_uint64), ("list_bytes", ctypes.c_uint64),
-                ("front_end", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("front_end", ctypes.c_int32), ("strips_ms", ctypes.c_float)]
 
 
 class DgBitmapColumn(ctypes.Structure):
@@ -109,6 +109,8 @@ _SIGNATURES = {
     "dg_wait": (ctypes.c_int, [_P, ctypes.c_int]),
     "dg_slot_framebuffer": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(_P)]),
     "dg_readback": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "dg_readback_async": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    "dg_ctx_fallbacks": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "dg_frame_checksums": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     "dg_alloc_host": (_P, [ctypes.c_size_t]),
     "dg_free_host": (None, [_P]),
@@ -246,6 +248,15 @@ class Context:
         out = np.zeros(count, dtype=np.uint64)
         _check(lib().dg_frame_checksums(self._h, slot, first, count, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
         return out
+
+    def readback_async(self, slot: int, first: int, count: int, host_ptr: int):
+        """Queue the D2H copy behind the slot's kernels (own copy stream); complete after wait(slot)."""
+        _check(lib().dg_readback_async(self._h, slot, first, count, _P(host_ptr)))
+
+    def fallbacks(self) -> dict:
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(lib().dg_ctx_fallbacks(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return {"front_end": a.value, "segments": b.value}
 
     def readback_into(self, slot: int, first: int, count: int, host_ptr: int):
         _check(lib().dg_readback(self._h, slot, first, count, _P(host_ptr)))

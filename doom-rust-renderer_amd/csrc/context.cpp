@@ -106,7 +106,11 @@ private:
 
 struct Slot {
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_raster = nullptr, ev_rstart = nullptr;
+    hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_raster = nullptr, ev_rstart = nullptr, ev_resolved = nullptr;
+    hipStream_t copy_stream = nullptr;   // dg_readback_async: D2H of this slot's frames while another slot's kernels run
+    uint8_t *copy_out = nullptr;         // pending asynchronous readback (re-issued if the batch has to be redone)
+    int copy_first = 0, copy_count = 0;
+    bool copy_pending = false;
     uint8_t *h_lists = nullptr;   // pinned staging
     uint8_t *d_lists = nullptr;
     DevRSpan *d_rspans = nullptr;
@@ -115,10 +119,8 @@ struct Slot {
     // strip path (dg_resolve_columns -> dg_raster_strips): segments [F][seg_cap][W], band index, overlay index, flags
     DevSeg *d_segs = nullptr;
     uint8_t *d_band_first = nullptr;
-    uint16_t *d_ov_first = nullptr;
-    DevSeg *d_ov_inline = nullptr;   // [F][OV_INLINE_MAX][W]
-    uint8_t *d_ov_cnt = nullptr;     // [F][W]
-    uint32_t *d_frame_flags = nullptr, *h_frame_flags = nullptr;   // device: [F] flags followed by the band overlay bytes [F][n_bands][strips]
+    uint32_t *d_tile_list = nullptr;                               // [F][n_bands][strips] at most
+    uint32_t *d_frame_flags = nullptr, *h_frame_flags = nullptr;   // device: [F] flags, 2 tile counters, band overlay bytes [F][n_bands][strips]
     // last submission
     RasterParams P{};
     uint32_t max_spans = 0;
@@ -161,6 +163,7 @@ struct dg_ctx {
     uint8_t *d_pool = nullptr;          // row-major texel plane + flats, the strip rasteriser's texel source
     bool strips = true;                 // dg_resolve_columns + dg_raster_strips + overlay (DOOMGPU_STRIPS=0: dg_raster_tiles alone)
     int seg_cap = 32, band_rows = 1, n_bands = 1;
+    int tile_workgroups = 1024;         // persistent workgroups of dg_raster_tile_list (4 per CU)
     uint4 *d_row_tab = nullptr;         // per-row constants of the flat / sky mappers (dg_row_table), rebuilt per scene upload
     DevScene dscene{};
     std::vector<Slot> slots;
@@ -198,9 +201,7 @@ void free_ctx(dg_ctx *c) {
         if (s.d_fb) (void)hipFree(s.d_fb);
         if (s.d_segs) (void)hipFree(s.d_segs);
         if (s.d_band_first) (void)hipFree(s.d_band_first);
-        if (s.d_ov_first) (void)hipFree(s.d_ov_first);
-        if (s.d_ov_inline) (void)hipFree(s.d_ov_inline);
-        if (s.d_ov_cnt) (void)hipFree(s.d_ov_cnt);
+        if (s.d_tile_list) (void)hipFree(s.d_tile_list);
         if (s.d_frame_flags) (void)hipFree(s.d_frame_flags);
         if (s.h_frame_flags) (void)hipHostFree(s.h_frame_flags);
         if (s.h_fe) (void)hipHostFree(s.h_fe);
@@ -212,6 +213,8 @@ void free_ctx(dg_ctx *c) {
         if (s.ev_setup) (void)hipEventDestroy(s.ev_setup);
         if (s.ev_raster) (void)hipEventDestroy(s.ev_raster);
         if (s.ev_rstart) (void)hipEventDestroy(s.ev_rstart);
+        if (s.ev_resolved) (void)hipEventDestroy(s.ev_resolved);
+        if (s.copy_stream) { (void)hipStreamSynchronize(s.copy_stream); (void)hipStreamDestroy(s.copy_stream); }
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     if (c->d_palette) (void)hipFree(c->d_palette);
@@ -227,9 +230,11 @@ void free_ctx(dg_ctx *c) {
 }
 
 void fill_strip_params(const dg_ctx *c, const Slot &s, RasterParams &P) {
-    P.segs = s.d_segs; P.band_first = s.d_band_first; P.ov_first = s.d_ov_first; P.ov_inline = s.d_ov_inline; P.ov_cnt = s.d_ov_cnt; P.frame_flags = s.d_frame_flags;
-    P.band_ovl = reinterpret_cast<uint8_t *>(s.d_frame_flags + c->cfg.max_batch);
-    P.band_inl = P.band_ovl + (size_t)c->cfg.max_batch * (size_t)c->n_bands * (size_t)((c->cfg.width + 63) / 64);
+    P.segs = s.d_segs; P.band_first = s.d_band_first; P.frame_flags = s.d_frame_flags;
+    P.tile_counters = s.d_frame_flags + c->cfg.max_batch;
+    P.band_ovl = reinterpret_cast<uint8_t *>(P.tile_counters + 2);
+    P.tile_list = s.d_tile_list;
+    P.tile_workgroups = c->tile_workgroups;
     P.seg_cap = c->seg_cap; P.band_rows = c->band_rows; P.n_bands = c->n_bands; P.strips = c->strips ? 1 : 0;
 }
 
@@ -445,7 +450,7 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
         HIP_TRY(hipEventRecord(s.ev_setup, s.stream));
     }
     HIP_TRY(hipEventRecord(s.ev_rstart, s.stream));
-    HIP_TRY(launch_raster(s.P, s.stream));
+    HIP_TRY(launch_raster(s.P, s.stream, s.ev_resolved));
     HIP_TRY(hipEventRecord(s.ev_raster, s.stream));
     c->last_raster = s.ev_raster;
     if (s.fe_mode) {
@@ -492,10 +497,37 @@ int settle_slot(dg_ctx *c, Slot &s) {
         if (overflow) {
             c->fallbacks_seg++;
             s.P.strips = 0;
-            hipError_t e = launch_raster(s.P, s.stream);
+            hipError_t e = launch_raster(s.P, s.stream, s.ev_resolved);
             if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
             if (e != hipSuccess) return set_err(DG_ERR_HIP, std::string("strip fallback: ") + hipGetErrorString(e));
         }
+    }
+    return DG_OK;
+}
+
+int enqueue_copy(dg_ctx *c, Slot &s) {
+    const size_t fsz = (size_t)3 * (size_t)c->cfg.width * (size_t)c->cfg.height;
+    HIP_TRY(hipStreamWaitEvent(s.copy_stream, s.ev_raster, 0));
+    HIP_TRY(hipMemcpyAsync(s.copy_out, s.d_fb + (size_t)s.copy_first * fsz, (size_t)s.copy_count * fsz, hipMemcpyDeviceToHost, s.copy_stream));
+    return DG_OK;
+}
+
+// Everything queued for the slot has finished: kernels, capacity checks (a batch that overflowed is redone here) and a
+// pending asynchronous readback (re-issued after a redo: its first copy took frames of the overflowed run).
+int finish_slot(dg_ctx *c, Slot &s) {
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    s.busy = false;
+    const uint64_t redone = c->fallbacks_fe + c->fallbacks_seg;
+    int rc = settle_slot(c, s);
+    if (rc) return rc;
+    if (s.copy_pending) {
+        HIP_TRY(hipStreamSynchronize(s.copy_stream));
+        if (c->fallbacks_fe + c->fallbacks_seg != redone) {
+            rc = enqueue_copy(c, s);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(s.copy_stream));
+        }
+        s.copy_pending = false;
     }
     return DG_OK;
 }
@@ -592,6 +624,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     HIP_TRY(hipSetDevice(cfg->device));
 
     dg_ctx *c = new dg_ctx();
+    c->tile_workgroups = std::max(1, prop.multiProcessorCount * 4);
     c->cfg = *cfg;
     c->fk = make_consts(cfg->width, cfg->height);
     c->dk = DevConsts{c->fk.ARC, c->fk.GCFX, c->fk.CFX, c->fk.CFY, cfg->width, cfg->height};
@@ -662,6 +695,8 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         CTX_TRY(hipEventCreate(&s.ev_setup));
         CTX_TRY(hipEventCreate(&s.ev_raster));
         CTX_TRY(hipEventCreate(&s.ev_rstart));
+        CTX_TRY(hipEventCreate(&s.ev_resolved));
+        CTX_TRY(hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking));
         CTX_TRY(hipHostMalloc((void **)&s.h_lists, lists_cap, hipHostMallocDefault));
         CTX_TRY(hipMalloc((void **)&s.d_lists, lists_cap));
         CTX_TRY(hipMalloc((void **)&s.d_rspans, c->span_cap_per_batch * sizeof(DevRSpan)));
@@ -669,10 +704,8 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         if (c->strips) {
             CTX_TRY(hipMalloc((void **)&s.d_segs, F * (size_t)c->seg_cap * W * sizeof(DevSeg)));
             CTX_TRY(hipMalloc((void **)&s.d_band_first, F * (size_t)c->n_bands * W));
-            CTX_TRY(hipMalloc((void **)&s.d_ov_first, F * W * 2));
-            CTX_TRY(hipMalloc((void **)&s.d_ov_inline, F * W * OV_INLINE_MAX * sizeof(DevSeg)));
-            CTX_TRY(hipMalloc((void **)&s.d_ov_cnt, F * W));
-            CTX_TRY(hipMalloc((void **)&s.d_frame_flags, F * 4 + 2 * F * (size_t)c->n_bands * ((W + 63) / 64)));
+            CTX_TRY(hipMalloc((void **)&s.d_tile_list, F * (size_t)c->n_bands * ((W + 63) / 64) * 4));
+            CTX_TRY(hipMalloc((void **)&s.d_frame_flags, F * 4 + 8 + F * (size_t)c->n_bands * ((W + 63) / 64)));
             CTX_TRY(hipHostMalloc((void **)&s.h_frame_flags, F * 4, hipHostMallocDefault));
         }
         if (c->fe_enabled) {
@@ -718,12 +751,11 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     }
     if (!sc.flat_pool.empty()) HIP_TRY(hipMemcpy(c->d_flats, sc.flat_pool.data(), sc.flat_pool.size(), hipMemcpyHostToDevice));
     std::vector<uint8_t> pool;
-    uint32_t pool_opq = 0, pool_tx16 = 0, pool_tx16_flats = 0;
-    const uint32_t pool_flats = sc.build_strip_pool(pool, pool_opq, pool_tx16, pool_tx16_flats);
+    const uint32_t pool_flats = sc.build_strip_pool(pool);
     HIP_TRY(hipMalloc((void **)&c->d_pool, std::max<size_t>(pool.size(), 16)));
     if (!pool.empty()) HIP_TRY(hipMemcpy(c->d_pool, pool.data(), pool.size(), hipMemcpyHostToDevice));
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
-    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, c->d_pool, pool_flats, pool_opq, pool_tx16, pool_tx16_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
+    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, c->d_pool, pool_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
     if (!c->d_row_tab) HIP_TRY(hipMalloc((void **)&c->d_row_tab, (size_t)c->cfg.height * sizeof(uint4)));
     HIP_TRY(launch_row_table(c->dscene, c->dk, c->d_row_tab, nullptr));
     HIP_TRY(hipDeviceSynchronize());
@@ -739,8 +771,8 @@ int dg_submit_views(dg_ctx *c, int slot, const dg_view *views, int n) {
     if (!views) return set_err(DG_ERR_INVALID, "null views");
     HIP_TRY(hipSetDevice(c->cfg.device));
     Slot &s = c->slots[(size_t)slot];
-    if (s.busy) { HIP_TRY(hipStreamSynchronize(s.stream)); s.busy = false; }
-    s.fe_check = false;
+    if (s.busy || s.copy_pending) { rc = finish_slot(c, s); if (rc) return rc; }
+    s.fe_check = false; s.seg_check = false;
     rc = build_batch(c, s, views, nullptr, n);
     if (rc) return rc;
     return enqueue_kernels(c, s);
@@ -750,10 +782,28 @@ int dg_wait(dg_ctx *c, int slot) {
     int rc = check_slot(c, slot);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->cfg.device));
+    return finish_slot(c, c->slots[(size_t)slot]);
+}
+
+int dg_readback_async(dg_ctx *c, int slot, int first, int count, uint8_t *out) {
+    int rc = check_slot(c, slot);
+    if (rc) return rc;
     Slot &s = c->slots[(size_t)slot];
-    HIP_TRY(hipStreamSynchronize(s.stream));
-    s.busy = false;
-    return settle_slot(c, s);
+    if (!out || first < 0 || count < 0 || first + count > s.n_frames) return set_err(DG_ERR_INVALID, "bad readback range");
+    if (s.copy_pending) return set_err(DG_ERR_INVALID, "the slot already has a readback in flight (dg_wait it first)");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    s.copy_out = out; s.copy_first = first; s.copy_count = count;
+    rc = enqueue_copy(c, s);
+    if (rc) return rc;
+    s.copy_pending = true;
+    return DG_OK;
+}
+
+int dg_ctx_fallbacks(const dg_ctx *c, uint64_t *front_end, uint64_t *segments) {
+    if (!c) return set_err(DG_ERR_INVALID, "null ctx");
+    if (front_end) *front_end = c->fallbacks_fe;
+    if (segments) *segments = c->fallbacks_seg;
+    return DG_OK;
 }
 
 int dg_slot_framebuffer(dg_ctx *c, int slot, void **p) {
@@ -894,6 +944,8 @@ int dg_slot_timing(dg_ctx *c, int slot, dg_timing *out) {
     out->host_ms = s.host_ms; out->list_bytes = s.list_bytes;
     out->n_walls = s.n_walls; out->n_planes = s.n_planes;
     out->front_end = s.fe_mode ? DG_FE_DEVICE : DG_FE_HOST;
+    out->strips_ms = 0.0f;
+    if (s.P.strips) HIP_TRY(hipEventElapsedTime(&out->strips_ms, s.ev_resolved, s.ev_raster));
     return DG_OK;
 }
 

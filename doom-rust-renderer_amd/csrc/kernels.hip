@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) { return (uint32
 
 // Per-pixel evaluation with per-lane span words (the lanes of one wave may own pixels of different spans).
 __device__ __forceinline__ uint32_t eval_wall(const RasterParams &P, const uint32_t *pal, const uint4 a, const uint4 b, int y, bool &opaque) {
-    const uint32_t o = wall_texel_offset(a.y, a.z, b.x, b.y, b.z, b.w, y);
+    const uint32_t o = wall_texel_offset_staged(a.y, a.z, b.x, b.y, b.z, b.w, y);
     opaque = w0_immediate(a.x) ? P.scene.texel_opq[o] != 0 : true;
     return shade(pal[P.scene.texel_idx[o]], bits_f32(a.w));
 }
@@ -150,17 +150,18 @@ __device__ __forceinline__ uint32_t raster_column_small(const RasterParams &P, c
     return shade_winner(P, fr, pal, lsp, winner, color, y, vy, r_vy, srow);
 }
 
-__global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[TILE_H * TILE_STRIDE];
-    __shared__ __attribute__((aligned(16))) uint4 lspans[SPAN_CAP * 2];
-    __shared__ uint32_t lw0[SPAN_CAP];
-    __shared__ uint32_t pal[256];
-    __shared__ uint32_t lcoff[TILE_W + 1];
+struct TileLds {
+    uint32_t tile[TILE_H * TILE_STRIDE];
+    uint4 lspans[SPAN_CAP * 2];
+    uint32_t lw0[SPAN_CAP];
+    uint32_t pal[256];
+    uint32_t lcoff[TILE_W + 1];
+};
 
-    const int f = blockIdx.z;
+// One 64 x 64 tile of frame f: columns x0 .., rows y0 ..
+__device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int f, int x0, int y0) {
     const DevFrame fr = P.frames[f];
     const int W = P.k.W, H = P.k.H;
-    const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int y = y0 + lane;
@@ -175,26 +176,29 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
     const uint32_t coff_v = coff[xc < W ? xc : W];
     const float r_vy = bits_f32(rt.x);
     const int srow = (int)rt.y;
-    if (threadIdx.x < 256) pal[threadIdx.x] = pal_v;
-    if (threadIdx.x <= TILE_W) lcoff[threadIdx.x] = coff_v;
+    if (threadIdx.x < 256) L.pal[threadIdx.x] = pal_v;
+    if (threadIdx.x <= TILE_W) L.lcoff[threadIdx.x] = coff_v;
     __syncthreads();
 
     // The spans of adjacent columns are one contiguous range of the column-major span array.  Stage as many whole columns
     // as fit in LDS (normally the whole tile) with one coalesced burst — every load of the workgroup in flight at once, so
     // the dependent chain col_off -> spans is paid once per tile — then rasterise those columns; repeat if needed.
+    // Wall spans are put into their per-pixel form on the way (stage_wall_span: texture column start, prepared 1/d).
     int c_lo = 0;
     while (c_lo < TILE_W) {
-        const uint32_t t0 = lcoff[c_lo];
+        const uint32_t t0 = L.lcoff[c_lo];
         int c_hi = TILE_W;
-        if (lcoff[TILE_W] - t0 > SPAN_CAP) {
+        if (L.lcoff[TILE_W] - t0 > SPAN_CAP) {
             c_hi = c_lo + 1;                  // a single column always fits: the binner caps a column at SPAN_CAP spans
-            while (c_hi < TILE_W && lcoff[c_hi + 1] - t0 <= SPAN_CAP) c_hi++;
+            while (c_hi < TILE_W && L.lcoff[c_hi + 1] - t0 <= SPAN_CAP) c_hi++;
         }
-        const uint32_t n_stage = lcoff[c_hi] - t0;
-        for (uint32_t i = threadIdx.x; i < 2 * n_stage; i += THREADS) {
-            const uint4 v = gspans[2 * (size_t)t0 + i];
-            lspans[i] = v;
-            if ((i & 1u) == 0) lw0[i >> 1] = v.x;
+        const uint32_t n_stage = L.lcoff[c_hi] - t0;
+        for (uint32_t i = threadIdx.x; i < n_stage; i += THREADS) {
+            uint4 a = gspans[2 * ((size_t)t0 + i)], b = gspans[2 * ((size_t)t0 + i) + 1];
+            if (w0_kind(a.x) == SPAN_WALL) stage_wall_span(a.y, a.z, b.z, b.w);
+            L.lspans[2 * i] = a;
+            L.lspans[2 * i + 1] = b;
+            L.lw0[i] = a.x;
         }
         __syncthreads();
         // Wave-level pre-filter: this wave owns columns c_lo + wave + 8k (k = 0..7).  Lane (k, slot) = (lane >> 3, lane & 7)
@@ -205,10 +209,10 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
         uint32_t f_n0 = 0, f_n = 0, f_w0 = 0;
         bool f_hit = false;
         if (fcol < c_hi) {
-            f_n0 = lcoff[fcol] - t0;
-            f_n = lcoff[fcol + 1] - lcoff[fcol];
+            f_n0 = L.lcoff[fcol] - t0;
+            f_n = L.lcoff[fcol + 1] - L.lcoff[fcol];
             if ((uint32_t)fslot < f_n && f_n <= 8u) {
-                f_w0 = lw0[f_n0 + (uint32_t)fslot];
+                f_w0 = L.lw0[f_n0 + (uint32_t)fslot];
                 f_hit = w0_cbot(f_w0) >= y0 && w0_ctop(f_w0) <= y0 + (TILE_H - 1);
             }
         }
@@ -217,9 +221,9 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
         for (int c = c_lo + wave; c < c_hi; c += WAVES, k8 += 8) {
             const uint32_t n0 = bcast(f_n0, k8), n = bcast(f_n, k8);
             uint32_t px;
-            if (n > 8u) px = raster_column(P, fr, pal, lw0 + n0, lspans + 2 * n0, n, lane, y, y0, vy, r_vy, srow);
-            else px = raster_column_small(P, fr, pal, (uint32_t)(hitm >> k8) & 0xffu, f_w0, k8, lspans + 2 * n0, y, vy, r_vy, srow);
-            tile[lane * TILE_STRIDE + c] = px;
+            if (n > 8u) px = raster_column(P, fr, L.pal, L.lw0 + n0, L.lspans + 2 * n0, n, lane, y, y0, vy, r_vy, srow);
+            else px = raster_column_small(P, fr, L.pal, (uint32_t)(hitm >> k8) & 0xffu, f_w0, k8, L.lspans + 2 * n0, y, vy, r_vy, srow);
+            L.tile[lane * TILE_STRIDE + c] = px;
         }
 
         c_lo = c_hi;
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
         const int row = g >> 4, gc = g & 15;
         const int yy = y0 + row, xx = x0 + 4 * gc;
         if (yy < H && xx < W) {   // W % 4 == 0 (checked at dg_create), so a group never straddles the right edge
-            const uint4 p = *reinterpret_cast<const uint4 *>(&tile[row * TILE_STRIDE + 4 * gc]);
+            const uint4 p = *reinterpret_cast<const uint4 *>(&L.tile[row * TILE_STRIDE + 4 * gc]);
             const uint32_t o0 = (p.x & 0xffffffu) | (p.y << 24);
             const uint32_t o1 = ((p.y >> 8) & 0xffffu) | (p.z << 16);
             const uint32_t o2 = ((p.z >> 16) & 0xffu) | (p.w << 8);
@@ -246,23 +250,32 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
     }
 }
 
+// Every tile of every frame (the strip path is off, or a batch is redone because a column exceeded the segment slots).
+__global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
+    __shared__ __attribute__((aligned(16))) TileLds L;
+    tile_body(P, L, (int)blockIdx.z, (int)blockIdx.x * TILE_W, (int)blockIdx.y * TILE_H);
+}
+
+// The tiles dg_resolve_columns listed: those that a possibly-transparent span (masked wall, sprite) touches, where the
+// winner of a pixel depends on texels and dg_raster_strips therefore does not go.  A fixed number of workgroups strides over
+// the list, so the launch costs the same whether the list holds 50 tiles or 50 000.
+__global__ __launch_bounds__(THREADS) void dg_raster_tile_list(RasterParams P) {
+    __shared__ __attribute__((aligned(16))) TileLds L;
+    const uint32_t count = P.tile_counters[0];
+    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {   // tiles cost about the same: a static stride balances well enough
+        if (item != blockIdx.x) __syncthreads();                           // the previous tile's read-out is done with L
+        const uint32_t t = P.tile_list[item];
+        tile_body(P, L, (int)(t >> 16), (int)(t & 0xffu) * TILE_W, (int)((t >> 8) & 0xffu) * TILE_H);
+    }
+}
+
 // ---- strip path ---------------------------------------------------------------------------------------------------------
 
 constexpr int RES_STAGE = 24;     // row-range words of a column staged in LDS by dg_resolve_columns (longer columns read HBM)
 
-// One lane per (frame, screen column): strip_core.h resolve_column.  The row-range words (w0) of the column's spans are
-// staged in LDS first (independent loads, all in flight at once), then the scan over boundaries x spans runs out of LDS.
-// Real columns hold 2-8 spans.  Negligible next to the raster kernels (320 000 columns per launch against 256 M pixels).
-__global__ __launch_bounds__(256) void dg_resolve_columns(RasterParams P) {
-    __shared__ uint32_t lw0_all[4][RES_STAGE * 64];
-    const int f = blockIdx.y;
+__device__ __forceinline__ void resolve_lane(const RasterParams &P, int f, int x, int lane, uint32_t *lw0, uint32_t (*lbands)[8]) {
     const int W = P.k.W, H = P.k.H;
-    const int lane = threadIdx.x & 63;
-    const uint32_t strip = blockIdx.x * 4 + (threadIdx.x >> 6), n_strips = (uint32_t)(W + 63) / 64;
-    uint32_t *lw0 = lw0_all[threadIdx.x >> 6];
-    const int x = (int)strip * 64 + lane;
     const DevFrame fr = P.frames[f];
-    if (x >= W) return;                               // no barrier below: the staging area is private to a lane
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
     const uint32_t o = coff[x], n = coff[x + 1] - o;
     const DevRSpan *spans = P.rspans + fr.span_base + o;
@@ -279,21 +292,50 @@ __global__ __launch_bounds__(256) void dg_resolve_columns(RasterParams P) {
                                            P.segs + (size_t)f * (size_t)P.seg_cap * (size_t)W + (size_t)x, (size_t)W,
                                            P.band_first + (size_t)f * (size_t)P.n_bands * (size_t)W + (size_t)x, (size_t)W);
     if (r.n_segs == 0xffffffffu) atomicOr(&P.frame_flags[f], 1u);
-    P.ov_first[(size_t)f * (size_t)W + (size_t)x] = (uint16_t)r.n_base;
-    // Overlay spans (strip_core.h overlay_inline_count): up to OV_INLINE_MAX of them go to dg_raster_strips_ov as
-    // per-column records; anything else to dg_overlay_strips.  Either way the bands they touch are flagged (same value from
-    // every writer).
-    const uint32_t k_inl = overlay_inline_count(n - r.n_base);
-    P.ov_cnt[(size_t)f * (size_t)W + (size_t)x] = (uint8_t)k_inl;
-    uint8_t *bflag = (k_inl ? P.band_inl : P.band_ovl) + (size_t)f * (size_t)P.n_bands * (size_t)n_strips + strip;
+    // Overlay spans: the bands (= 64-row tiles of this strip) they touch are rendered by dg_raster_tile_list from the draw-ordered
+    // spans instead.  Every wave collects its strip's bands in LDS; lane 0 then flags them and appends them to the tile list.
     for (uint32_t j = r.n_base; j < n; j++) {
         const uint32_t w0 = w0_at(j);
-        for (int b = w0_ctop(w0) / P.band_rows; b <= w0_cbot(w0) / P.band_rows; b++) bflag[(size_t)b * (size_t)n_strips] = 1;
-        if (k_inl) {
-            const DevSeg ov = overlay_record(spans[j], P.scene);
-            uint4 *od = reinterpret_cast<uint4 *>(P.ov_inline + ((size_t)f * OV_INLINE_MAX + (j - r.n_base)) * (size_t)W + (size_t)x);
-            od[0] = make_uint4(ov.w[0], ov.w[1], ov.w[2], ov.w[3]);
-            od[1] = make_uint4(ov.w[4], ov.w[5], ov.w[6], ov.w[7]);
+        for (int b = w0_ctop(w0) / P.band_rows; b <= w0_cbot(w0) / P.band_rows; b++) atomicOr(&lbands[threadIdx.x >> 6][b >> 5], 1u << (b & 31));
+    }
+}
+
+// One lane per (frame, screen column): strip_core.h resolve_column.  The row-range words (w0) of the column's spans are
+// staged in LDS first (independent loads, all in flight at once), then the scan over boundaries x spans runs out of LDS.
+// Real columns hold 2-8 spans.  Negligible next to the raster kernels (320 000 columns per launch against 256 M pixels).
+__global__ __launch_bounds__(256) void dg_resolve_columns(RasterParams P) {
+    __shared__ uint32_t lw0_all[4][RES_STAGE * 64];
+    __shared__ uint32_t lbands[4][8];                 // per wave: bands (up to 256) touched by overlay spans of its strip
+    if (threadIdx.x < 32) lbands[threadIdx.x >> 3][threadIdx.x & 7] = 0;
+    __syncthreads();
+    const int f = blockIdx.y;
+    const int W = P.k.W;
+    const int lane = threadIdx.x & 63;
+    const uint32_t strip = blockIdx.x * 4 + (threadIdx.x >> 6), n_strips = (uint32_t)(W + 63) / 64;
+    uint32_t *lw0 = lw0_all[threadIdx.x >> 6];
+    const int x = (int)strip * 64 + lane;
+    if (x < W) resolve_lane(P, f, x, lane, lw0, lbands);
+    __syncthreads();
+    // the wave's bands -> flags + tile list: one atomic for the wave, then lane l appends band l (64, 128, 192 + l) at its rank
+    if (strip < n_strips) {
+        const uint32_t *mw = lbands[threadIdx.x >> 6];
+        uint32_t total = 0;
+        for (uint32_t g = 0; g < 8; g++) total += (uint32_t)__builtin_popcount(mw[g]);
+        if (total) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&P.tile_counters[0], total);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            uint32_t before = 0;                      // bands below this 64-band group
+            for (uint32_t g2 = 0; g2 < 4; g2++) {
+                const unsigned long long m64 = (unsigned long long)mw[2 * g2] | ((unsigned long long)mw[2 * g2 + 1] << 32);
+                if ((m64 >> lane) & 1ull) {
+                    const uint32_t b = g2 * 64 + (uint32_t)lane;
+                    const uint32_t rank = before + (uint32_t)__builtin_popcountll(m64 & ((1ull << lane) - 1ull));
+                    P.band_ovl[((size_t)f * (size_t)P.n_bands + b) * (size_t)n_strips + strip] = 1;
+                    P.tile_list[base + rank] = ((uint32_t)f << 16) | (b << 8) | strip;
+                }
+                before += (uint32_t)__builtin_popcountll(m64);
+            }
         }
     }
 }
@@ -337,13 +379,9 @@ typedef const u32x4 __attribute__((address_space(4))) *RowTabPtr;   // "constant
 // Finished rows are packed to RGB24 by quads of lanes (one DPP move, one byte permute), parked in LDS and leave four at a
 // time, 16 contiguous bytes per lane.  Texels are row-major here (pool), so the 64 adjacent columns of a wall row read a
 // handful of cache lines.
-//
-// OV = this (strip, band) has columns with an inline overlay span (a masked wall or sprite column, strip_core.h): the second
-// instantiation carries that span per lane and applies it in the same pass.  Each (strip, band) is rendered by exactly one
-// of the two kernels (band_inl), so the common one keeps 8 wavefronts per SIMD.
-// band: the band this wavefront renders; ov_tab / ov_w0: the strip's inline overlay records in LDS ([layer][lane], OV only).
-template <bool OV>
-__device__ __forceinline__ void strips_body(const RasterParams &P, int band, const float4 *palf, uint32_t *rowbuf, const uint4 *ov_tab, uint32_t ov_n) {
+// Bands (= 64-row tiles of the strip) that a possibly-transparent span touches are not rendered here but by
+// dg_raster_tile_list, from the draw-ordered spans (band_ovl).
+__device__ __forceinline__ void strips_body(const RasterParams &P, int band, const float4 *palf, uint32_t *rowbuf) {
     const int f = blockIdx.z;
     const int lane = threadIdx.x & 63;
     const int W = P.k.W, H = P.k.H;
@@ -381,18 +419,6 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, int band, con
     const uint32_t st_off = (uint32_t)st_row * (uint32_t)W * 3u + (uint32_t)st_chunk * 16u;
     uint8_t *rowp = P.fb + (((size_t)f * (size_t)H + (size_t)y_lo) * (size_t)W + (size_t)x0) * 3;
     int parked = 0;                                   // rows in rowbuf
-
-    // Inline overlay spans of this column (ov_n layers at most in this strip): rows of the band on which some column of the
-    // strip has an overlay pixel, wave-uniform.
-    int ov_lo = 0x7fff, ov_hi = -1;
-    if constexpr (OV) {
-        for (uint32_t j = 0; j < ov_n; j++) {
-            const uint32_t w0 = ov_tab[(j * 64 + (uint32_t)lane) * 2].x;      // first row > last row in unused slots
-            ov_lo = min(ov_lo, max(w0_ctop(w0), y_lo)); ov_hi = max(ov_hi, min(w0_cbot(w0), y_hi));
-        }
-        for (int o = 32; o > 0; o >>= 1) { ov_lo = min(ov_lo, __shfl_xor(ov_lo, o)); ov_hi = max(ov_hi, __shfl_xor(ov_hi, o)); }
-        ov_lo = __builtin_amdgcn_readfirstlane(ov_lo); ov_hi = __builtin_amdgcn_readfirstlane(ov_hi);
-    }
 
     // Which mapper the next rows run (wave-uniform; recomputed only on rows where a column changes segment).
     enum { MODE_GENERIC = 0, MODE_FLAT = 1, MODE_WALL = 2, MODE_MIXED = 3 };
@@ -482,41 +508,10 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, int band, con
     // among themselves (a store may complete before an older load), so the only operation that may stay in flight is the one
     // load known to be younger than this row's: the next row's texel.  Anything else issued in between — segment prefetches,
     // overlay texels, the row buffer's store — only makes the wait stricter.
-    auto row_b = [&](Row &R, int y, bool keep) {
+    auto row_b = [&](Row &R, bool keep) {
         asm volatile("s_waitcnt vmcnt(1)" : "+v"(R.tex) : : "memory");
         uint32_t tex = R.tex;
         float fac = R.fac;
-        if constexpr (OV) {
-            // The column's masked-wall / sprite pixels of this row, in draw order (bitmap_render.rs:256-265): an opaque texel
-            // replaces what is there.  All layers' texels are requested before the first is looked at.
-            if (y >= ov_lo && y <= ov_hi) {           // wave-uniform
-                const u32x4 rc = rows[y];             // floors / ceilings and sky among the overlay spans need the row constants
-                const uint16_t *tx16 = reinterpret_cast<const uint16_t *>(pool + P.scene.pool_tx16);
-                for (uint32_t g = 0; g < ov_n; g += 4) {          // four layers at a time: their texels are requested together
-                    uint32_t o_off[4], o_t16[4], o_w0[4];
-                    float o_fac[4];
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; q++) {
-                        const uint32_t j = g + q;
-                        o_off[q] = 0; o_fac[q] = 0.0f; o_w0[q] = 0x3fffu;          // first row > last row: not here
-                        if (j < ov_n) {               // wave-uniform
-                            const uint4 a = ov_tab[(j * 64 + (uint32_t)lane) * 2];
-                            if (y >= w0_ctop(a.x) && y <= w0_cbot(a.x)) {
-                                const uint4 b = ov_tab[(j * 64 + (uint32_t)lane) * 2 + 1];
-                                const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
-                                if (overlay_texel(P.scene, fr, aw, bw, y, bits_f32(rc.z), bits_f32(rc.x), (int32_t)rc.y, o_off[q], o_fac[q])) o_w0[q] = a.x;
-                                else o_off[q] = 0;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; q++) o_t16[q] = g + q < ov_n ? (uint32_t)tx16[o_off[q]] : 0u;
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; q++)
-                        if (g + q < ov_n && w0_ctop(o_w0[q]) <= w0_cbot(o_w0[q]) && ((o_t16[q] >> 8) != 0u || !w0_immediate(o_w0[q]))) { tex = o_t16[q] & 255u; fac = o_fac[q]; }
-                }
-            }
-        }
         const float4 c = palf[tex];
         uint32_t px;
         {
@@ -539,9 +534,9 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, int band, con
     row_a(y_lo, A);
     for (int y = y_lo; y <= y_hi; y += 2) {           // two rows per trip so that the in-flight texel needs no register move
         row_a(min(y + 1, y_hi), B);
-        row_b(A, y, true);
+        row_b(A, true);
         row_a(min(y + 2, y_hi), A);
-        row_b(B, y + 1, y + 1 <= y_hi);
+        row_b(B, y + 1 <= y_hi);
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(A.tex) : : "memory");   // the last, unused look-ahead
     if (parked) flush_rows(parked);
@@ -555,9 +550,7 @@ __device__ __forceinline__ void stage_palette(const RasterParams &P, float4 *pal
     }
 }
 
-// Bands without inline overlay spans.  Four wavefronts = four consecutive bands of one strip per workgroup: the wavefronts
-// are independent, but the workgroup dispatcher launches only ~0.3 workgroups per ns, so 80 000 one-wave workgroups would
-// cost more than the rendering itself.
+// Four wavefronts = four consecutive bands of one strip per workgroup (they are independent and only share the palette).
 __global__ __launch_bounds__(256) void dg_raster_strips(RasterParams P) {
     __shared__ float4 palf[256];                      // palette as f32 triples: shading needs no v_cvt_f32_ubyte
     __shared__ __attribute__((aligned(16))) uint32_t rowbuf[4][4 * 48];   // per wave: four finished rows of the strip (RGB24, 192 B each)
@@ -567,127 +560,8 @@ __global__ __launch_bounds__(256) void dg_raster_strips(RasterParams P) {
     stage_palette(P, palf, threadIdx.x, 256);
     __syncthreads();
     const int band = (int)blockIdx.y * 4 + wave;
-    if (band >= P.n_bands || P.band_inl[((size_t)f * (size_t)P.n_bands + (size_t)band) * (size_t)gridDim.x + blockIdx.x] != 0) return;   // dg_raster_strips_ov
-    strips_body<false>(P, band, palf, rowbuf[wave], nullptr, 0u);
-}
-
-// Bands with inline overlay spans: four wavefronts = four consecutive bands of one strip per workgroup, which share the
-// strip's overlay records (OV_INLINE_MAX x 64 columns x 32 bytes) and the palette in LDS.
-__global__ __launch_bounds__(256) void dg_raster_strips_ov(RasterParams P) {
-    __shared__ float4 palf[256];
-    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[4][4 * 48];
-    __shared__ __attribute__((aligned(16))) uint4 ov_tab[OV_INLINE_MAX * 64 * 2];
-    const int f = blockIdx.z;
-    if (P.frame_flags[f] != 0u) return;
-    const int W = P.k.W;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int band0 = (int)blockIdx.y * 4;
-    const uint8_t *binl = P.band_inl + (size_t)f * (size_t)P.n_bands * (size_t)gridDim.x + blockIdx.x;
-    bool any = false;
-    for (int b = band0; b < min(band0 + 4, P.n_bands); b++) any |= binl[(size_t)b * (size_t)gridDim.x] != 0;
-    if (!any) return;                                 // workgroup-uniform
-    stage_palette(P, palf, threadIdx.x, 256);
-    // layer `wave` of the strip's 64 columns (slots beyond a column's count read as "first row > last row")
-    const int x = (int)blockIdx.x * 64 + lane;
-    const uint32_t cnt = x < W ? P.ov_cnt[(size_t)f * (size_t)W + (size_t)x] : 0u;
-    uint32_t n_layers = cnt;
-    for (int o = 32; o > 0; o >>= 1) n_layers = max(n_layers, (uint32_t)__shfl_xor((int)n_layers, o));
-    for (uint32_t j = (uint32_t)wave; j < OV_INLINE_MAX; j += 4) {
-        uint4 a = make_uint4(0x3fffu, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
-        if (j < cnt) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(P.ov_inline + ((size_t)f * OV_INLINE_MAX + j) * (size_t)W + (size_t)x);
-            a = src[0]; b = src[1];
-        }
-        if (j < n_layers) {
-            ov_tab[(j * 64 + (uint32_t)lane) * 2] = a;
-            ov_tab[(j * 64 + (uint32_t)lane) * 2 + 1] = b;
-        }
-    }
-    __syncthreads();
-    const int band = band0 + wave;
-    if (band >= P.n_bands || binl[(size_t)band * (size_t)gridDim.x] == 0) return;     // that band belongs to dg_raster_strips
-    strips_body<true>(P, band, palf, rowbuf[wave], ov_tab, __builtin_amdgcn_readfirstlane(n_layers));
-}
-
-// The spans dg_resolve_columns left in draw order (from a column's first possibly-transparent span on: masked walls and
-// sprites, whose texels decide whether they write: bitmap_render.rs:265) on top of what dg_raster_strips stored.  One
-// wavefront per (frame, 64-column strip, band) that such a span touches, lane = column.  Layer j = the j-th overlay span of
-// every column; layers run in order, a layer's rows run top to bottom with the row wave-uniform, and a lane stores its 3
-// bytes only where the texel is opaque — so "later draw call wins" is simply the order of this wave's stores, and nothing
-// has to be read back.
-__global__ __launch_bounds__(256) void dg_overlay_strips(RasterParams P) {
-    __shared__ uint32_t pal[256];
-    const int f = blockIdx.y;
-    if (P.frame_flags[f] != 0u) return;
-    const uint8_t *bovl = P.band_ovl + (size_t)f * (size_t)P.n_bands * (size_t)gridDim.x + blockIdx.x;
-    bool any = false;
-    for (int b = 0; b < P.n_bands; b++) any |= bovl[(size_t)b * (size_t)gridDim.x] != 0;
-    if (!any) return;                                 // workgroup-uniform: the usual case (real columns have few overlay spans)
-    const int lane = threadIdx.x & 63;
-    const int W = P.k.W, H = P.k.H;
-    const int x = (int)blockIdx.x * 64 + lane;
-    pal[threadIdx.x] = P.scene.palette[threadIdx.x];
-    __syncthreads();
-    for (int band = (int)(threadIdx.x >> 6); band < P.n_bands; band += 4) {
-    if (!bovl[(size_t)band * (size_t)gridDim.x]) continue;
-    const int y_lo = band * P.band_rows;
-    const int y_hi = min(H, y_lo + P.band_rows) - 1;
-    const DevFrame fr = P.frames[f];
-    uint32_t k_spans = 0;
-    const DevRSpan *spans = P.rspans;
-    if (x < W) {
-        const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
-        const uint32_t first = P.ov_first[(size_t)f * (size_t)W + (size_t)x];
-        const uint32_t o = coff[x], n = coff[x + 1] - o;
-        k_spans = n - first;
-        spans = P.rspans + fr.span_base + o + first;
-        if (P.ov_cnt[(size_t)f * (size_t)W + (size_t)x] != 0) k_spans = 0;        // dg_raster_strips_ov applied them
-    }
-    const uint8_t *pool = P.scene.pool;
-    uint8_t *fbx = P.fb + ((size_t)f * (size_t)H * (size_t)W + (size_t)(x < W ? x : 0)) * 3;
-    for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(j < k_spans) != 0ull; j++) {
-        uint4 a = make_uint4(0, 0, 0, 0), b = a;
-        int t = 0x7fff, bt = -1;
-        if (j < k_spans) {
-            const uint4 *q = reinterpret_cast<const uint4 *>(spans + j);
-            a = q[0]; b = q[1];
-            t = max(w0_ctop(a.x), y_lo); bt = min(w0_cbot(a.x), y_hi);
-        }
-        int lo = t, hi = bt;
-        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-        const uint32_t kind = w0_kind(a.x);
-        const bool holes = w0_immediate(a.x);
-        const float r_d = prepare_rcp(bits_f32(a.y));
-        for (int y = lo; y <= hi; y++) {
-            if (y < t || y > bt) continue;
-            uint32_t color = 0;
-            bool opaque = false;
-            if (kind == SPAN_WALL) {
-                const int32_t h = (int32_t)(b.z & 0xffffu), w = (int32_t)(b.z >> 16);
-                const uint32_t o = a.z + b.w + (uint32_t)(wall_texel_row(bits_f32(a.y), r_d, bits_f32(b.x), b.y, h, y) * w);
-                opaque = holes ? pool[P.scene.pool_opq + o] != 0 : true;
-                color = shade(pal[pool[o]], bits_f32(a.w));
-            } else if (kind == SPAN_FLAT) {
-                const float vy = P.k.CFY - (float)y;
-                float factor;
-                const uint32_t o = flat_texel_offset(fr, a.y, a.z, b.x, b.y, b.z, vy, bits_f32(P.row_tab[y].x), factor);
-                color = shade(pal[pool[P.scene.pool_flats + o]], factor);
-                opaque = true;
-            } else {
-                const int srow = (int)P.row_tab[y].y;
-                if (b.w != 0xffffffffu && srow >= 0) {
-                    const uint32_t o = P.scene.sky_texel_off + (uint32_t)srow * (uint32_t)P.scene.sky_w + b.w;
-                    opaque = holes ? pool[P.scene.pool_opq + o] != 0 : true;
-                    color = pal[pool[o]];
-                }
-            }
-            if (opaque) {
-                uint8_t *p = fbx + (size_t)y * (size_t)W * 3;
-                p[0] = (uint8_t)color; p[1] = (uint8_t)(color >> 8); p[2] = (uint8_t)(color >> 16);
-            }
-        }
-    }
-    }
+    if (band >= P.n_bands || P.band_ovl[((size_t)f * (size_t)P.n_bands + (size_t)band) * (size_t)gridDim.x + blockIdx.x] != 0) return;   // dg_raster_tile_list
+    strips_body(P, band, palf, rowbuf[wave]);
 }
 
 // Per-row constants of the flat and sky mappers for one frame size: the prepared reciprocal of vy = CFY - y (visplanes.rs:109)
@@ -733,29 +607,25 @@ hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hip
     return hipGetLastError();
 }
 
-int strip_band_rows(int H) {
-    // 8 bands per 512 rows: 50 rows at H = 800 (16 bands), 25 at 200, 48 at 768, 50 at 1600
-    const int groups = (H + 511) / 512;
-    return std::max(1, (H + 8 * groups - 1) / (8 * groups));
-}
-
-hipError_t launch_raster(const RasterParams &P, hipStream_t stream) {
+hipError_t launch_raster(const RasterParams &P, hipStream_t stream, hipEvent_t after_resolve) {
     if (P.n_frames <= 0) return hipSuccess;
     const unsigned strips = (unsigned)((P.k.W + TILE_W - 1) / TILE_W);
     if (P.strips) {
-        // frame_flags [max_batch] is followed by band_ovl and band_inl, [F][n_bands][strips] each: one fill clears all three
-        hipError_t e = hipMemsetAsync(P.frame_flags, 0, (size_t)(reinterpret_cast<uint8_t *>(P.band_inl) - reinterpret_cast<uint8_t *>(P.frame_flags)) +
+        // frame_flags [max_batch], the two tile counters and band_ovl [F][n_bands][strips] are one allocation: one fill clears all
+        hipError_t e = hipMemsetAsync(P.frame_flags, 0, (size_t)(P.band_ovl - reinterpret_cast<uint8_t *>(P.frame_flags)) +
                                                            (size_t)P.n_frames * (size_t)P.n_bands * strips, stream);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(dg_resolve_columns, dim3((strips + 3) / 4, (unsigned)P.n_frames), dim3(256), 0, stream, P);
+        if (after_resolve) { e = hipEventRecord(after_resolve, stream); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(dg_raster_strips, dim3(strips, (unsigned)((P.n_bands + 3) / 4), (unsigned)P.n_frames), dim3(256), 0, stream, P);
-        hipLaunchKernelGGL(dg_raster_strips_ov, dim3(strips, (unsigned)((P.n_bands + 3) / 4), (unsigned)P.n_frames), dim3(256), 0, stream, P);
-        hipLaunchKernelGGL(dg_overlay_strips, dim3(strips, (unsigned)P.n_frames), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL(dg_raster_tile_list, dim3((unsigned)P.tile_workgroups), dim3(THREADS), 0, stream, P);
         return hipGetLastError();
     }
     dim3 grid(strips, (unsigned)((P.k.H + TILE_H - 1) / TILE_H), (unsigned)P.n_frames);
     hipLaunchKernelGGL(dg_raster_tiles, grid, dim3(THREADS), 0, stream, P);
     return hipGetLastError();
 }
+
+int strip_band_rows(int H) { (void)H; return TILE_H; }   // a band of dg_raster_strips = one tile row of dg_raster_tile_list
 
 }  // namespace dg

@@ -99,11 +99,8 @@ struct DevScene {             // immutable, uploaded once per map
     const uint8_t *texel_idx; // column-major per bitmap (off + x*h + y): dg_raster_tiles, lane = row
     const uint8_t *texel_opq;
     const uint8_t *flats;
-    const uint8_t *pool;      // strip kernels (lane = column): [row-major texel index plane (off + y*w + x) | flats | row-major opacity plane]
+    const uint8_t *pool;      // dg_raster_strips (lane = column): [row-major texel index plane (off + y*w + x) | flats]
     uint32_t pool_flats;      // byte offset of the flats inside pool
-    uint32_t pool_opq;        // byte offset of the opacity plane inside pool
-    uint32_t pool_tx16;       // byte offset (even) of the u16 plane index | opaque << 8 (bitmaps row-major, then the flats): one load per overlay texel
-    uint32_t pool_tx16_flats; // ELEMENT offset of the flats inside that plane
     uint32_t sky_texel_off;   // sky bitmap (256 x 128 expected)
     int32_t sky_w, sky_h;
     uint32_t sky_has_holes;   // any transparent texel in the sky bitmap (then sky spans are evaluated in draw order)

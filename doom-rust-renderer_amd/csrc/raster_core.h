@@ -212,7 +212,17 @@ DG_HD int32_t wall_texel_row(float d, float r_d, float uy1, uint32_t w5, int32_t
     const int32_t mask = (h & (h - 1)) == 0 ? h - 1 : 0;
     return floor_mod_fast(ty, h, mask, mask ? 0.0f : approx_rcp((float)h));
 }
-// Texel offset of one wall pixel in the column-major planes (DevRSpan words, dg_raster_tiles).
+// dg_raster_tiles keeps a wall span in LDS in its per-pixel form: w2 = start of the texture column in the column-major planes,
+// w7 = prepared reciprocal of d (in HBM those words hold the bitmap's offset and tx, so that dg_resolve_columns can also
+// address the row-major pool).
+DG_HD void stage_wall_span(uint32_t w1, uint32_t &w2, uint32_t w6, uint32_t &w7) {
+    w2 += w7 * (w6 & 0xffffu);
+    w7 = f32_bits(prepare_rcp(bits_f32(w1)));
+}
+DG_HD uint32_t wall_texel_offset_staged(uint32_t w1, uint32_t w2, uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7, int32_t y) {
+    return w2 + (uint32_t)wall_texel_row(bits_f32(w1), bits_f32(w7), bits_f32(w4), w5, (int32_t)(w6 & 0xffffu), y);
+}
+// Texel offset of one wall pixel in the column-major planes from the DevRSpan words as they are in HBM.
 DG_HD uint32_t wall_texel_offset(uint32_t w1, uint32_t w2, uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7, int32_t y) {
     const int32_t h = (int32_t)(w6 & 0xffffu);
     return w2 + w7 * (uint32_t)h + (uint32_t)wall_texel_row(bits_f32(w1), prepare_rcp(bits_f32(w1)), bits_f32(w4), w5, h, y);

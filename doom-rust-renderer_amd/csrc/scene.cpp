@@ -291,26 +291,14 @@ static inline bool left_of_partition(const NodeRec &n, float px, float py) {
     return ax * by - ay * bx <= 0.0f;
 }
 
-uint32_t Scene::build_strip_pool(std::vector<uint8_t> &pool, uint32_t &opq_at_out, uint32_t &tx16_at_out, uint32_t &tx16_flats_out) const {
+uint32_t Scene::build_strip_pool(std::vector<uint8_t> &pool) const {
     const size_t flats_at = (texel_idx.size() + 255) / 256 * 256;
-    const size_t opq_at = (flats_at + flat_pool.size() + 255) / 256 * 256;
-    const size_t tx16_at = (opq_at + texel_opq.size() + 255) / 256 * 256;
-    const size_t tx16_flats = (texel_idx.size() + 255) / 256 * 256;             // element offset of the flats in the u16 plane
-    pool.assign(tx16_at + 2 * (tx16_flats + flat_pool.size()), 0);
-    for (size_t i = 0; i < flat_pool.size(); i++) { pool[tx16_at + 2 * (tx16_flats + i)] = flat_pool[i]; pool[tx16_at + 2 * (tx16_flats + i) + 1] = 1; }
+    pool.assign(flats_at + flat_pool.size(), 0);
     for (const BitmapInfo &b : bitmaps)
         for (int x = 0; x < b.w; x++)
-            for (int y = 0; y < b.h; y++) {
-                const size_t cm = (size_t)b.texel_off + (size_t)x * (size_t)b.h + (size_t)y, rm = (size_t)b.texel_off + (size_t)y * (size_t)b.w + (size_t)x;
-                pool[rm] = texel_idx[cm];
-                pool[opq_at + rm] = texel_opq[cm];
-                pool[tx16_at + 2 * rm] = texel_idx[cm];
-                pool[tx16_at + 2 * rm + 1] = texel_opq[cm];
-            }
+            for (int y = 0; y < b.h; y++)
+                pool[(size_t)b.texel_off + (size_t)y * (size_t)b.w + (size_t)x] = texel_idx[(size_t)b.texel_off + (size_t)x * (size_t)b.h + (size_t)y];
     std::copy(flat_pool.begin(), flat_pool.end(), pool.begin() + (long)flats_at);
-    opq_at_out = (uint32_t)opq_at;
-    tx16_at_out = (uint32_t)tx16_at;
-    tx16_flats_out = (uint32_t)tx16_flats;
     return (uint32_t)flats_at;
 }
 

@@ -90,10 +90,8 @@ struct Scene {
     int sector_from_vertex(float x, float y) const;                              // renderer/bsp.rs:9-44
     int find_or_add_sprite_frame(const std::string &sprite, uint8_t frame, std::string &err);
     // Texel source of the strip rasteriser (lane = column): every bitmap's index plane row-major (texel_off + y*w + x: the 64
-    // adjacent columns of a wall row then read a few cache lines), the flats, and the opacity plane row-major (same offsets as the
-    // index plane, + opq_at), and both interleaved as u16 (index | opaque << 8) at tx16_at + 2 * offset.  Returns the offset of the flats.
-    // The flats follow in the u16 plane (always opaque) at element offset tx16_flats.
-    uint32_t build_strip_pool(std::vector<uint8_t> &pool, uint32_t &opq_at, uint32_t &tx16_at, uint32_t &tx16_flats) const;
+    // adjacent columns of a wall row then read a few cache lines), followed by the flats.  Returns the offset of the flats.
+    uint32_t build_strip_pool(std::vector<uint8_t> &pool) const;
 };
 
 // Returns nullptr and fills err on any condition where the reference's loaders panic.

@@ -1,4 +1,4 @@
-// strip_core.h — bodies of the strip rasteriser (dg_resolve_columns, dg_raster_strips, dg_overlay_strips: kernels.hip) as host/device inline
+// strip_core.h — bodies of the strip rasteriser (dg_resolve_columns, dg_raster_strips: kernels.hip) as host/device inline
 // functions, so that tests/emul can run the same code on the CPU.
 //
 // The reference's final pixel is "the last Pixels::set wins" over draw calls whose row ranges overlap by design (inclusive
@@ -8,8 +8,9 @@
 // 0 .. H-1, each carrying the texture-mapping constants of its winning span (uncovered rows: SEG_NONE = the zeroed buffer of
 // Pixels::new, pixels.rs:10-14).  dg_raster_strips then walks a column top to bottom with the current segment in registers
 // and evaluates every pixel exactly once, with no per-pixel ownership test.  The spans from the first possibly-transparent
-// one on (masked walls, sprites: whether they write depends on the texel, bitmap_render.rs:265) stay in draw order and are
-// applied on top by dg_overlay_strips.
+// one on (masked walls, sprites: whether they write depends on the texel, bitmap_render.rs:265) cannot be resolved like that:
+// the 64 x 64 tiles they touch are rendered by dg_raster_tile_list, which replays all spans of its columns in draw order with
+// an ownership walk per pixel.  Real frames are mostly made of tiles without such spans.
 #pragma once
 #include "raster_core.h"
 
@@ -55,18 +56,6 @@ DG_HD DevSeg seg_none(int32_t end) {
     return o;
 }
 
-// Overlay spans of a column (the draw-ordered rest after the resolved prefix).  Up to OV_INLINE_MAX of them (24 KB of LDS per
-// strip in dg_raster_strips_ov; real columns hold 0-6) travel with dg_raster_strips_ov as per-column records and are applied
-// in the same pass; longer lists go through dg_overlay_strips.  Returns how many spans the strip kernel applies (0 or all).
-constexpr uint32_t OV_INLINE_MAX = 12;
-DG_HD uint32_t overlay_inline_count(uint32_t n_overlay) { return n_overlay <= OV_INLINE_MAX ? n_overlay : 0u; }
-// The record of one inline overlay span: its DevSeg (row-major offsets, prepared reciprocal), except that word 0 keeps the
-// span's own row-range word (ctop | imm << 15 | cbot << 16) with the SEGMENT kind in bits 30-31 (SEG_NONE: draws nothing).
-DG_HD DevSeg overlay_record(const DevRSpan &sp, const DevScene &sc) {
-    DevSeg o = seg_from_span(sp, 0, sc);
-    o.w[0] = (sp.w[0] & 0x3fffffffu) | (o.w[0] & 0xc0000000u);
-    return o;
-}
 struct ResolveResult {
     uint32_t n_segs;      // segments written (0xffffffff: more than `cap`, nothing usable was written)
     uint32_t n_base;      // spans [0, n_base) were resolved; spans [n_base, n) are the overlay, still in draw order
@@ -150,20 +139,6 @@ DG_HD uint32_t seg_flat_offset(const DevFrame &f, uint32_t w1, uint32_t w2, uint
     // two, so the product is exact and the fused form rounds exactly like the reference's separate multiply and subtract.
     factor = __builtin_fmaf(-(float)f32_as_i16(wx), 1.0f / (16.0f * 256.0f), bits_f32(w5));
     return w2 + (uint32_t)(ty * 64 + tx);
-}
-
-// Offset into the u16 texel plane (index | opaque << 8) and light factor of one overlay pixel; false: nothing is drawn.
-// vy = CFY - y, r_vy = prepare_rcp(vy), srow = sky texture row of y (or -1).
-DG_HD bool overlay_texel(const DevScene &sc, const DevFrame &f, const uint32_t *a, const uint32_t *b, int32_t y, float vy, float r_vy, int32_t srow,
-                         uint32_t &off16, float &fac) {
-    const uint32_t kind = seg_kind(a[0]);
-    if (kind == SPAN_WALL) { off16 = seg_wall_offset(a[1], a[2], b[0], b[1], b[2], b[3], y); fac = bits_f32(a[3]); return true; }
-    if (kind == SPAN_FLAT) {
-        off16 = sc.pool_tx16_flats + (seg_flat_offset(f, a[1], a[2], b[0], b[1], b[2], vy, r_vy, fac) - sc.pool_flats);
-        return true;
-    }
-    if (kind == SPAN_SKY && srow >= 0) { off16 = a[2] + (uint32_t)srow * (uint32_t)sc.sky_w; fac = 1.0f; return true; }
-    return false;
 }
 
 }  // namespace dg

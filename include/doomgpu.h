@@ -96,6 +96,10 @@ int dg_create(const dg_config *cfg, dg_ctx **out);
 void dg_destroy(dg_ctx *ctx);
 /* Number of host threads the ctx uses for list generation (after the default / cap has been applied). */
 int dg_ctx_host_threads(const dg_ctx *ctx);
+/* Batches that had to be rendered a second time because a device-side capacity was exceeded: the column scratch of the device
+ * column walk (redone through DG_FE_HOST) / the segment slots of the strip rasteriser (redone by the tile rasteriser).  Same
+ * pixels either way; a workload that keeps hitting them should raise DOOMGPU_FE_COLUMN_SLOTS / DOOMGPU_SEG_SLOTS. */
+int dg_ctx_fallbacks(const dg_ctx *ctx, uint64_t *front_end, uint64_t *segments);
 /* Copy palette, texel planes, flats to HBM (immutable per map). The scene must outlive the ctx's use of it. */
 int dg_upload_scene(dg_ctx *ctx, const dg_scene *scene);
 
@@ -112,6 +116,11 @@ void *dg_alloc_host(size_t bytes);
 void dg_free_host(void *p);
 /* D2H copy of frames [first, first+count) of a completed slot. */
 int dg_readback(dg_ctx *ctx, int slot, int first, int count, uint8_t *rgb24_out);
+/* The same without waiting: the copy is queued behind the slot's kernels on the slot's own copy stream, so it overlaps the
+ * kernels of the NEXT submission on another slot (the reference's caller consumes `pixels.pixels` on the host every frame,
+ * src/game.rs:521-525).  rgb24_out should be page-locked (dg_alloc_host) and is complete after dg_wait(slot); submitting to the
+ * slot again waits for it.  One readback in flight per slot. */
+int dg_readback_async(dg_ctx *ctx, int slot, int first, int count, uint8_t *rgb24_out);
 /* Frame sink without the PCIe copy: one 64-bit checksum per frame of a finished slot, computed on the GPU over the frame's
  * RGB24 bytes taken as little-endian dwords d[0 .. 3*W*H/4):
  *     sum over i of  m ^ (m >> 32),   m = (d[i] ^ (i * 0x9E3779B97F4A7C15)) * 0xBF58476D1CE4E5B9    (all mod 2^64)
@@ -189,9 +198,9 @@ typedef struct dg_timing {
     uint64_t n_spans, n_frames, covered_pixels;
     uint64_t n_walls, n_planes, list_bytes; /* drawn records / visplanes, bytes of lists copied to HBM */
     int32_t front_end;        /* DG_FE_HOST or DG_FE_DEVICE: what that submission actually used; with DG_FE_DEVICE setup_ms is
-                                 the column walk (dg_fe_columns + dg_fe_finalize), n_walls = wall records, n_planes = sprites,
-                                 covered_pixels is not tracked (0) */
-    int32_t reserved;
+                                 the column walk (dg_fe_columns, dg_fe_gaps, dg_fe_scan, dg_fe_scatter), n_walls = wall records,
+                                 n_planes = sprites, covered_pixels is not tracked (0) */
+    float strips_ms;          /* of raster_ms (= dg_resolve_columns + dg_raster_strips + dg_raster_tile_list): the two pixel kernels */
 } dg_timing;
 int dg_slot_timing(dg_ctx *ctx, int slot, dg_timing *out);
 

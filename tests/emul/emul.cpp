@@ -21,7 +21,6 @@ using namespace dg;
 
 static std::string g_err;
 static uint64_t g_ov_stats[6];
-static uint64_t g_ov_hist[16], g_ov_px[16];   // columns by overlay span count: 0, 1 inline, 1 not inline, 2, 3+; [5] = overlay pixels of k >= 2 columns
 
 // What dg_raster_tiles does for every column: spans in order, every row of the span (lane = row), later span overwrites.
 static void raster_spans(const DevScene &ds, const DevConsts &k, const DevFrame &hdr, const uint32_t *pal, const uint32_t *col_off,
@@ -55,102 +54,99 @@ static void raster_spans(const DevScene &ds, const DevConsts &k, const DevFrame 
     }
 }
 
-// The strip path (dg_resolve_columns + dg_raster_strips + dg_raster_tiles in overlay mode) on the same span lists:
-// resolve every column's opaque prefix into segments, walk them top to bottom (lane = column), then apply the overlay
-// spans in draw order.  Returns false (and says why) when the result differs from raster_spans' or when a band index is off.
+// The strip path on the same span lists: resolve every column's opaque prefix into segments (dg_resolve_columns); 64-row
+// bands of 64-column strips that no overlay span touches are then walked segment by segment (dg_raster_strips, lane =
+// column), the other tiles are replayed from the draw-ordered spans (dg_raster_tile_list = raster_spans restricted to the
+// tile).  Returns false (and says why) when the result differs from raster_spans' or when a band index is off.
 static bool raster_strips_check(const Scene &sc, DevScene ds, const DevConsts &k, const DevFrame &hdr, const uint32_t *pal, const uint32_t *col_off,
                                 const DevRSpan *rs, int W, int H, const uint8_t *expect) {
     std::vector<uint8_t> pool;
-    ds.pool_flats = sc.build_strip_pool(pool, ds.pool_opq, ds.pool_tx16, ds.pool_tx16_flats);
+    ds.pool_flats = sc.build_strip_pool(pool);
     ds.pool = pool.data();
-    int band_rows = std::max(1, (H + 8 * ((H + 511) / 512) - 1) / (8 * ((H + 511) / 512)));   // = strip_band_rows(H), kernels.hip
-    const int n_bands = (H + band_rows - 1) / band_rows;
+    const int band_rows = 64;                                          // = strip_band_rows(H), kernels.hip
+    const int n_bands = (H + band_rows - 1) / band_rows, n_strips = (W + 63) / 64;
     const uint32_t cap = 255;
-    std::vector<DevSeg> segs((size_t)cap);
-    std::vector<uint8_t> bands((size_t)n_bands), rgb((size_t)3 * W * H, 0);
-    for (int x = 0; x < W; x++) {
+    std::vector<std::vector<DevSeg>> segs((size_t)W);
+    std::vector<uint8_t> bands((size_t)n_bands), rgb((size_t)3 * W * H, 0), ovl((size_t)n_bands * n_strips, 0);
+    std::vector<DevSeg> tmp((size_t)cap);
+    for (int x = 0; x < W; x++) {                                      // dg_resolve_columns
         const uint32_t n = col_off[x + 1] - col_off[x];
         const DevRSpan *sp = rs + col_off[x];
-        const ResolveResult r = resolve_column([&](uint32_t j) { return sp[j].w[0]; }, sp, n, ds, H, band_rows, cap, segs.data(), 1, bands.data(), 1);
+        const ResolveResult r = resolve_column([&](uint32_t j) { return sp[j].w[0]; }, sp, n, ds, H, band_rows, cap, tmp.data(), 1, bands.data(), 1);
         if (r.n_segs == 0xffffffffu) { g_err = "strip path: more than 255 segments in a column"; return false; }
-        if (r.n_segs == 0 || seg_end(segs[r.n_segs - 1].w[0]) != H - 1) { g_err = "strip path: segments do not end at H - 1"; return false; }
+        if (r.n_segs == 0 || seg_end(tmp[r.n_segs - 1].w[0]) != H - 1) { g_err = "strip path: segments do not end at H - 1"; return false; }
+        segs[(size_t)x].assign(tmp.begin(), tmp.begin() + r.n_segs);
         int start = 0;
-        for (uint32_t s = 0; s < r.n_segs; s++) {                    // dg_raster_strips: one lane, all rows
-            const uint32_t *w = segs[s].w;
-            const int end = seg_end(w[0]);
+        for (uint32_t s = 0; s < r.n_segs; s++) {
+            const int end = seg_end(tmp[s].w[0]);
             if (end < start) { g_err = "strip path: empty or unsorted segment"; return false; }
             for (int b = 0; b < n_bands; b++)
                 if (b * band_rows >= start && b * band_rows <= end && bands[(size_t)b] != s) { g_err = "strip path: band_first is wrong"; return false; }
-            for (int y = start; y <= end; y++) {
-                const uint32_t kind = seg_kind(w[0]);
-                uint32_t off = w[2];
-                float fac = bits_f32(w[3]);
-                const float vy = k.CFY - (float)y;
-                if (kind == SPAN_FLAT) off = seg_flat_offset(hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), fac);
-                else if (kind == SPAN_WALL) off = seg_wall_offset(w[1], w[2], w[4], w[5], w[6], w[7], y);
-                else if (kind == SPAN_SKY) {
-                    const int srow = sky_row(ds, k, y);
-                    if (srow >= 0) off = w[2] + (uint32_t)srow * (uint32_t)ds.sky_w; else { off = 0; fac = 0.0f; }
-                }
-                const uint32_t c = shade(pal[pool[off]], fac);
-                uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
-                p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
-            }
             start = end + 1;
         }
-        const uint32_t k_inl = overlay_inline_count(n - r.n_base);
-        {
-            const uint32_t k = n - r.n_base;
-            g_ov_stats[k == 0 ? 0 : k_inl ? 1 : 2]++;
-            g_ov_hist[k < 15 ? k : 15]++;
-            for (uint32_t i = r.n_base; i < n; i++) g_ov_px[k < 15 ? k : 15] += (uint64_t)(w0_cbot(sp[i].w[0]) - w0_ctop(sp[i].w[0]) + 1);
-        }
-        if (k_inl) {                                                  // dg_raster_strips_ov: the overlay spans as records, in draw order
-            for (uint32_t i = r.n_base; i < n; i++) {
-                const DevSeg ov = overlay_record(sp[i], ds);
-                for (int y = w0_ctop(ov.w[0]); y <= w0_cbot(ov.w[0]); y++) {
-                    uint32_t o;
-                    float fac;
-                    const float vy = k.CFY - (float)y;
-                    if (!overlay_texel(ds, hdr, ov.w, ov.w + 4, y, vy, prepare_rcp(vy), sky_row(ds, k, y), o, fac)) continue;
-                    const uint32_t t16 = (uint32_t)pool[ds.pool_tx16 + 2 * o] | ((uint32_t)pool[ds.pool_tx16 + 2 * o + 1] << 8);
-                    if (w0_immediate(ov.w[0]) && !(t16 >> 8)) continue;
-                    const uint32_t c = shade(pal[t16 & 255u], fac);
-                    uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
-                    p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
-                }
-            }
-        } else
-        for (uint32_t i = r.n_base; i < n; i++) {                    // dg_overlay_strips: the spans from the first possibly-transparent one on
-            const uint32_t *w = sp[i].w;
-            if (w0_ctop(w[0]) < r.ov_lo || w0_cbot(w[0]) > r.ov_hi) { g_err = "strip path: overlay rows outside the reported range"; return false; }
-            for (int y = w0_ctop(w[0]); y <= w0_cbot(w[0]); y++) {
-                uint32_t c = 0;
-                bool wr = false;
-                const uint32_t kind = w0_kind(w[0]);
-                if (kind == SPAN_WALL) {                                  // dg_overlay_strips: row-major planes of the pool
-                    const int32_t h = (int32_t)(w[6] & 0xffffu), bw = (int32_t)(w[6] >> 16);
-                    const uint32_t o = w[2] + w[7] + (uint32_t)(wall_texel_row(bits_f32(w[1]), prepare_rcp(bits_f32(w[1])), bits_f32(w[4]), w[5], h, y) * bw);
-                    if (!w0_immediate(w[0]) || pool[ds.pool_opq + o]) { c = shade(pal[pool[o]], bits_f32(w[3])); wr = true; }
-                } else if (kind == SPAN_FLAT) {
-                    float factor;
-                    const float vy = k.CFY - (float)y;
-                    uint32_t o = flat_texel_offset(hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), factor);
-                    c = shade(pal[pool[ds.pool_flats + o]], factor); wr = true;
-                } else {
-                    const int srow = sky_row(ds, k, y);
-                    if (w[7] != 0xffffffffu && srow >= 0) {
-                        const uint32_t o = ds.sky_texel_off + (uint32_t)srow * (uint32_t)ds.sky_w + w[7];
-                        if (!w0_immediate(w[0]) || pool[ds.pool_opq + o]) { c = pal[pool[o]]; wr = true; }
-                    }
-                }
-                if (wr) {
-                    uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
-                    p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
-                }
-            }
+        g_ov_stats[n - r.n_base ? 1 : 0]++;
+        for (uint32_t j = r.n_base; j < n; j++) {
+            if (w0_ctop(sp[j].w[0]) < r.ov_lo || w0_cbot(sp[j].w[0]) > r.ov_hi) { g_err = "strip path: overlay rows outside the reported range"; return false; }
+            for (int b = w0_ctop(sp[j].w[0]) / band_rows; b <= w0_cbot(sp[j].w[0]) / band_rows; b++) ovl[(size_t)b * n_strips + (size_t)(x / 64)] = 1;
         }
     }
+    for (int b = 0; b < n_bands; b++)
+        for (int st = 0; st < n_strips; st++) {
+            const int y_lo = b * band_rows, y_hi = std::min(H, y_lo + band_rows) - 1;
+            g_ov_stats[ovl[(size_t)b * n_strips + (size_t)st] ? 3 : 2]++;
+            for (int x = st * 64; x < std::min(W, st * 64 + 64); x++) {
+                if (!ovl[(size_t)b * n_strips + (size_t)st]) {         // dg_raster_strips: one lane, the band's rows
+                    int start = 0;
+                    for (const DevSeg &sg : segs[(size_t)x]) {
+                        const uint32_t *w = sg.w;
+                        const int end = seg_end(w[0]);
+                        for (int y = std::max(start, y_lo); y <= std::min(end, y_hi); y++) {
+                            const uint32_t kind = seg_kind(w[0]);
+                            uint32_t off = w[2];
+                            float fac = bits_f32(w[3]);
+                            const float vy = k.CFY - (float)y;
+                            if (kind == SPAN_FLAT) off = seg_flat_offset(hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), fac);
+                            else if (kind == SPAN_WALL) off = seg_wall_offset(w[1], w[2], w[4], w[5], w[6], w[7], y);
+                            else if (kind == SPAN_SKY) {
+                                const int srow = sky_row(ds, k, y);
+                                if (srow >= 0) off = w[2] + (uint32_t)srow * (uint32_t)ds.sky_w; else { off = 0; fac = 0.0f; }
+                            }
+                            const uint32_t c = shade(pal[pool[off]], fac);
+                            uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
+                            p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
+                        }
+                        start = end + 1;
+                    }
+                } else {                                               // dg_raster_tile_list: all spans of the column in draw order, the tile's rows
+                    for (uint32_t i = col_off[x]; i < col_off[x + 1]; i++) {
+                        uint32_t w[8];
+                        std::memcpy(w, rs[i].w, sizeof w);
+                        const uint32_t kind = w0_kind(w[0]);
+                        if (kind == SPAN_WALL) stage_wall_span(w[1], w[2], w[6], w[7]);
+                        for (int y = std::max(w0_ctop(w[0]), y_lo); y <= std::min(w0_cbot(w[0]), y_hi); y++) {
+                            uint32_t c = 0;
+                            bool wr = false;
+                            if (kind == SPAN_WALL) {
+                                const uint32_t o = wall_texel_offset_staged(w[1], w[2], w[4], w[5], w[6], w[7], y);
+                                if (!w0_immediate(w[0]) || ds.texel_opq[o]) { c = shade(pal[ds.texel_idx[o]], bits_f32(w[3])); wr = true; }
+                            } else if (kind == SPAN_FLAT) {
+                                float factor;
+                                const float vy = k.CFY - (float)y;
+                                const uint32_t o = flat_texel_offset(hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), factor);
+                                c = shade(pal[ds.flats[o]], factor); wr = true;
+                            } else {
+                                const uint32_t o = sky_texel_offset(w[2], sky_row(ds, k, y));
+                                if (o != 0xffffffffu && ds.texel_opq[o]) { c = pal[ds.texel_idx[o]]; wr = true; }
+                            }
+                            if (wr) {
+                                uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
+                                p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
+                            }
+                        }
+                    }
+                }
+            }
+        }
     if (std::memcmp(rgb.data(), expect, rgb.size()) != 0) {
         size_t i = 0;
         while (rgb[i] == expect[i]) i++;
@@ -163,7 +159,6 @@ static bool raster_strips_check(const Scene &sc, DevScene ds, const DevConsts &k
 extern "C" {
 
 const char *emul_last_error() { return g_err.c_str(); }
-void emul_overlay_hist(uint64_t *cols, uint64_t *px) { for (int i = 0; i < 16; i++) { cols[i] = g_ov_hist[i]; px[i] = g_ov_px[i]; g_ov_hist[i] = g_ov_px[i] = 0; } }
 void emul_overlay_stats(uint64_t *out, int reset) { for (int i = 0; i < 6; i++) { out[i] = g_ov_stats[i]; if (reset) g_ov_stats[i] = 0; } }
 
 void *emul_load(const uint8_t *wad, size_t len, const char *map_name) {

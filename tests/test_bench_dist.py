@@ -1,4 +1,5 @@
-"""N > 1 path of bench.py on CPU: world-size-2 gloo, the sharding helper and the MAX-over-ranks timing reduction."""
+"""N > 1 path of bench.py on CPU: bench.run end to end under world-size-2 gloo with a stub context (rank plan, CPU binding,
+barriers, timed steps, MAX over ranks, per-rank report), and the path / map sharding helpers."""
 import os
 import socket
 import sys
@@ -18,43 +19,121 @@ def _free_port():
     return p
 
 
+class _StubCtx:
+    """Stands in for dg.Context: every call bench.run makes, with sleeps instead of GPU work (rank 1 is the slow one)."""
+
+    def __init__(self, rank, n_slots, batch):
+        self.rank, self.n_slots, self.batch = rank, n_slots, batch
+        self.host_threads = 3
+        self.submits = self.replays = self.prepares = 0
+        self.frame_bytes = 12
+
+    def submit(self, slot, views):
+        import time
+        time.sleep(0.002 * (1 + self.rank))
+        self.submits += 1
+
+    def wait(self, slot):
+        pass
+
+    def prepare(self, slot, views):
+        self.prepares += 1
+
+    def replay(self, slot):
+        self.replays += 1
+
+    def timing(self, slot):
+        return {"raster_ms": 0.5, "strips_ms": 0.3, "setup_ms": 0.1, "host_ms": 0.25 * (1 + self.rank), "n_frames": self.batch, "n_spans": 1000 * self.batch,
+                "list_bytes": 4096 * self.batch, "front_end": 2}
+
+    def fallbacks(self):
+        return {"front_end": 0, "segments": 0}
+
+    def close(self):
+        pass
+
+
+class _StubBackend:
+    def __init__(self, args, device):
+        self.args = args
+
+    def load(self, map_seed, path_seed):
+        import bench
+        self.map_seed, self.path_seed = map_seed, path_seed
+        B = self.args.batch
+        self.n_slots = max(1, min(self.args.slots, (bench.PATH_FRAMES + B - 1) // B))
+        self.views = [object()] * self.n_slots
+        self.batch_first = [s * B for s in range(self.n_slots)]
+        self.ctx = _StubCtx(int(os.environ["RANK"]), self.n_slots, B)
+        return self.ctx
+
+
 def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      LOCAL_WORLD_SIZE=str(world))
     import torch.distributed as dist
     import bench
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     dist.barrier()
     slow = bench.dist_max(0.5 + rank, dist)            # rank 1 is the slow one
-    route = bench.rank_route([(i, 2 * i) for i in range(10)], rank, world)
-    q.put((rank, slow, route[0], bench.aggregate_fps(1000, world, slow)))
+    # bench.run end to end (rank plan, CPU binding, barriers, timed steps, MAX over ranks, report gather) on a stub context
+    args = bench.parse_args(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    holder = {}
+
+    def factory(a, device):
+        holder["be"] = _StubBackend(a, device)
+        return holder["be"]
+    line = bench.run(args, factory)
+    be = holder["be"]
+    q.put((rank, slow, line, be.map_seed, be.path_seed, be.ctx.submits, len(os.sched_getaffinity(0))))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_timing_and_sharding():
+def test_two_rank_gloo_bench_run():
     import torch.multiprocessing as mp
+    import bench
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
+    ncpu = len(os.sched_getaffinity(0))
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][1] == res[1][1] == 1.5                # MAX over ranks
-    assert res[0][3] == res[1][3] == pytest.approx(2000 / 1.5)   # whole-job frames / max time
-    assert res[0][2] == (0, 0) and res[1][2] == (4, 8)  # rank 1: rotated by n/2 = 5 -> [5..9,0..4], reversed -> starts at 4
+    line = res[0][2]
+    assert res[1][2] is None and line is not None       # only rank 0 reports
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 3
+    # 3 timed + 1 warmup steps of 4 batches each on every rank
+    assert res[0][5] == res[1][5] == 4 * 4
+    # value = frames of all ranks / the SLOWER rank's time (rank 1 sleeps 4 ms per batch: 12 batches >= 48 ms)
+    assert line["value"] <= 2 * 3 * 1000 / 0.048
+    assert line["value"] == pytest.approx(2 * 3 * 1000 / (line["ms_per_step"] * 3 / 1e3))
+    per = line["per_rank"]
+    assert [p["rank"] for p in per] == [0, 1]
+    assert [(p["map_seed"], p["path_seed"]) for p in per] == [(1993, 1993), (1994, 1994)] == [(r[3], r[4]) for r in res]
+    assert per[0]["frames_per_s"] > per[1]["frames_per_s"]                  # rank 0 really was faster; the headline is not its rate
+    assert per[1]["host_ms_per_batch"] == pytest.approx(0.5)
+    if ncpu >= 2:                                                            # each rank pinned itself to its half before starting
+        assert res[0][6] + res[1][6] <= ncpu and res[0][6] >= 1
 
 
-def test_rank_routes_are_permutations_of_the_same_loop():
+def test_seeded_routes_are_permutations_of_the_same_loop():
     import bench
     route = [(i, i * i) for i in range(37)]
-    for world in (1, 2, 4, 8):
-        for r in range(world):
-            rr = bench.rank_route(route, r, world)
-            assert sorted(rr) == sorted(route) and len(rr) == len(route)
+    assert bench.seeded_route(route, 1993) == route
+    starts = set()
+    for seed in range(1993, 2001):
+        rr = bench.seeded_route(route, seed)
+        assert sorted(rr) == sorted(route) and len(rr) == len(route)
+        starts.add(rr[0])
+    assert len(starts) >= 5                             # eight paths, (almost) all entering the loop somewhere else
+    assert [bench.rank_plan(r, 8) for r in range(4)] == [(1993, 1993), (1994, 1994), (1993, 1995), (1994, 1996)]
+    assert bench.rank_plan(0, 1) == (1993, 1993)
 
 
 def test_route_from_wad_gives_a_closed_walk(synth, campath_mod):

@@ -169,7 +169,7 @@ def test_checker_does_not_count_stores_as_younger_loads():
     assert len(check(parse(body))) == 1
 
 
-@pytest.mark.parametrize("mangled", ["_ZN2dg16dg_raster_stripsENS_12RasterParamsE", "_ZN2dg19dg_raster_strips_ovENS_12RasterParamsE"])
+@pytest.mark.parametrize("mangled", ["_ZN2dg16dg_raster_stripsENS_12RasterParamsE"])
 def test_raster_strips_never_touches_a_texel_in_flight(kernels_asm, mangled):
     blocks = parse(kernel_body(kernels_asm, mangled))
     assert sum(1 for b in blocks for (m, _) in b["insts"] if m == "global_load_ubyte") >= 2, "the asm texel loads are gone?"
