@@ -415,7 +415,9 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, int band, con
     const uint32_t park_at = (uint32_t)(lane - (lane >> 2));
     const bool park_on = (lane & 3) != 3;
     const int st_row = lane / 12, st_chunk = lane % 12;
-    const bool st_lane = lane < 48 && x0 + st_chunk * 16 / 3 < W;      // W % 4 == 0: a 16-byte chunk (5 1/3 pixels) lies inside the frame iff its first pixel does
+    const uint32_t row_bytes = (uint32_t)min(64, W - x0) * 3u;         // of this strip (a multiple of 12: W % 4 == 0)
+    const bool st_lane = lane < 48 && (uint32_t)st_chunk * 16u + 16u <= row_bytes;          // the whole 16-byte chunk lies inside the row
+    const bool st_part = lane < 48 && !st_lane && (uint32_t)st_chunk * 16u < row_bytes;     // the row ends inside it (last strip of a frame whose width is not a multiple of 64)
     const uint32_t st_off = (uint32_t)st_row * (uint32_t)W * 3u + (uint32_t)st_chunk * 16u;
     uint8_t *rowp = P.fb + (((size_t)f * (size_t)H + (size_t)y_lo) * (size_t)W + (size_t)x0) * 3;
     int parked = 0;                                   // rows in rowbuf
@@ -499,6 +501,10 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, int band, con
         if (st_lane && st_row < n) {
             const u32x4 v = *reinterpret_cast<const u32x4 *>(&rowbuf[st_row * 48 + st_chunk * 4]);
             asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(st_off), "v"(v), "s"(rowp) : "memory");
+        }
+        if (st_part && st_row < n) {
+            for (uint32_t i = 0; i < 4 && (uint32_t)st_chunk * 16u + 4u * i < row_bytes; i++)
+                *reinterpret_cast<uint32_t *>(rowp + st_off + 4u * i) = rowbuf[st_row * 48 + st_chunk * 4 + (int)i];
         }
         rowp += (size_t)n * (size_t)W * 3;
         parked = 0;

@@ -449,3 +449,127 @@ def test_every_frame_of_both_paths_at_1280x800_against_the_oracle_checksums(dg, 
             bad = [b0 + k for k in range(B) if got[k] != gold[b0 + k]]
             assert not bad, f"front end {fe}: frames {bad[:10]} differ from the oracle"
         ctx.close()
+
+
+# ---- round 2: the strip rasteriser and its fallbacks, overlapped submission, the remaining C-ABI entry points -------------
+
+def test_segment_capacity_falls_back_to_the_tile_rasteriser(dg, scene1994, oracle_scene1994, path1994, monkeypatch):
+    """dg_resolve_columns flags a frame whose column needs more segment slots than the ctx has; dg_wait then redoes the batch
+    with dg_raster_tiles (same pixels), and dg_ctx_fallbacks counts it.  With two slots per column every frame overflows."""
+    W, H = 320, 200
+    idx = list(range(0, 1000, 100))
+    monkeypatch.setenv("DOOMGPU_SEG_SLOTS", "2")
+    ctx = make_ctx(dg, scene1994, W, H, len(idx), slots=2)
+    monkeypatch.delenv("DOOMGPU_SEG_SLOTS")
+    views = dg.make_views(path1994[idx])
+    out = ctx.render(views)
+    assert ctx.fallbacks()["segments"] == 1
+    for k, i in enumerate(idx):
+        assert np.array_equal(out[k], np.frombuffer(oracle_scene1994.render(W, H, path1994[i]), dtype=np.uint8).reshape(H, W, 3)), f"frame {i}"
+    # a prepared slot replays through the same route, and so does an asynchronous readback queued before the redo
+    ctx.prepare(1, views)
+    ctx.replay(1)
+    host = np.empty_like(out)
+    ctx.readback_async(1, 0, len(idx), host.ctypes.data)
+    ctx.wait(1)
+    assert np.array_equal(host, out) and ctx.fallbacks()["segments"] >= 3
+    ctx.close()
+
+
+def test_tile_rasteriser_alone_is_bit_exact(dg, scene1993, oracle_scene1993, path1993, monkeypatch):
+    """DOOMGPU_STRIPS=0: every tile through dg_raster_tiles (the path the segment fallback takes)."""
+    monkeypatch.setenv("DOOMGPU_STRIPS", "0")
+    idx = list(range(0, 1000, 125))
+    for (W, H) in ((320, 200), (1280, 800)):
+        ctx = make_ctx(dg, scene1993, W, H, len(idx))
+        out = ctx.render(dg.make_views(path1993[idx]))
+        assert ctx.timing(0)["strips_ms"] == 0.0
+        for k, i in enumerate(idx):
+            assert np.array_equal(out[k], np.frombuffer(oracle_scene1993.render(W, H, path1993[i]), dtype=np.uint8).reshape(H, W, 3)), f"frame {i}"
+        ctx.close()
+
+
+def test_overlapped_slots_device_front_end(dg, scene1993, path1993):
+    """Four slots submitted back to back with no waits (the column scratch is shared between slots and ordered only by the
+    event chain in enqueue_kernels), replayed in rotated order, then waited: every slot's frames must equal a quiet render."""
+    W, H, B, S = 320, 200, 40, 4
+    batches = [path1993[s * 250:s * 250 + B] for s in range(S)]
+    quiet = dg.Context(W, H, max_batch=B, slots=1, front_end=dg.DG_FE_DEVICE)
+    quiet.upload_scene(scene1993)
+    want = []
+    for b in batches:
+        quiet.render(dg.make_views(b))
+        want.append(quiet.frame_checksums(0, 0, B))
+    quiet.close()
+    ctx = dg.Context(W, H, max_batch=B, slots=S, front_end=dg.DG_FE_DEVICE)
+    ctx.upload_scene(scene1993)
+    views = [dg.make_views(b) for b in batches]
+    for rounds in range(3):
+        for s in range(S):
+            ctx.submit(s, views[s])
+    for s in range(S):
+        ctx.wait(s)
+    for s in range(S):
+        assert np.array_equal(ctx.frame_checksums(s, 0, B), want[s]), f"slot {s} after pipelined submits"
+    for s in range(S):
+        ctx.prepare(s, views[(s + 1) % S])
+    for k in range(3 * S):
+        ctx.replay((k * 3 + 1) % S)                      # rotated order, several launches per slot in flight
+    for s in range(S):
+        ctx.wait(s)
+    for s in range(S):
+        assert np.array_equal(ctx.frame_checksums(s, 0, B), want[(s + 1) % S]), f"slot {s} after rotated replays"
+    ctx.close()
+
+
+def test_upload_scene_invalidates_prepared_slots(dg, scene1993, scene1994, path1993):
+    """dg_upload_scene frees the device scene the slots' prepared records point into: a replay must be refused, not run."""
+    ctx = make_ctx(dg, scene1993, 320, 200, 4, slots=2)
+    ctx.prepare(0, dg.make_views(path1993[:4]))
+    ctx.replay(0)
+    ctx.wait(0)
+    ctx.upload_scene(scene1994)
+    with pytest.raises(dg.DoomGpuError) as e:
+        ctx.replay(0)
+    assert e.value.code == dg.DG_ERR_INVALID
+    ctx.prepare(0, dg.make_views(path1993[:4]))          # preparing again makes the slot usable
+    ctx.replay(0)
+    ctx.wait(0)
+    ctx.close()
+
+
+def test_player_start_viewpoint_bit_exact(dg, campath_mod, scene1993, oracle_scene1993):
+    """BASELINE config 1: the single Player-1-start viewpoint (src/game.rs:151-156) at 320x200 and at the reference's native size."""
+    x, y, a = scene1993.player_start()
+    rec = campath_mod.view_record(x, y, a, scene1993.floor_height_at(x, y, 0.0))
+    for (W, H) in ((320, 200), (1024, 768)):
+        ctx = make_ctx(dg, scene1993, W, H, 1, slots=1)
+        out = ctx.render(dg.make_views(rec[None, :]))
+        ref = np.frombuffer(oracle_scene1993.render(W, H, rec), dtype=np.uint8).reshape(H, W, 3)
+        assert np.array_equal(out[0], ref)
+        assert out[0].any()                               # the spawn view is not an empty frame
+        ctx.close()
+
+
+def test_async_readback_overlaps_and_matches(dg, scene1993, path1993):
+    """dg_readback_async: the copy of slot s is queued behind its kernels while slot s + 1 renders; contents as dg_readback."""
+    W, H, B, S = 320, 200, 50, 3
+    ctx = dg.Context(W, H, max_batch=B, slots=S)
+    ctx.upload_scene(scene1993)
+    views = [dg.make_views(path1993[s * 100:s * 100 + B]) for s in range(S)]
+    bufs = [dg.lib().dg_alloc_host(B * ctx.frame_bytes) for _ in range(S)]
+    assert all(bufs)
+    for rounds in range(2):
+        for s in range(S):
+            ctx.submit(s, views[s])                       # the second round waits for the first round's copy of that slot
+            ctx.readback_async(s, 0, B, bufs[s])
+    with pytest.raises(dg.DoomGpuError):
+        ctx.readback_async(0, 0, B, bufs[0])              # one readback in flight per slot
+    for s in range(S):
+        ctx.wait(s)
+    for s in range(S):
+        got = np.ctypeslib.as_array(ctypes.cast(bufs[s], ctypes.POINTER(ctypes.c_uint8)), shape=(B, H, W, 3))
+        assert np.array_equal(got, ctx.readback(s, 0, B)), f"slot {s}"
+    for b in bufs:
+        dg.lib().dg_free_host(b)
+    ctx.close()
