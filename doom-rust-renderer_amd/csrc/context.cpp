@@ -107,6 +107,8 @@ private:
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_raster = nullptr, ev_rstart = nullptr, ev_resolved = nullptr;
+    hipStream_t tile_stream = nullptr;   // dg_raster_tile_list beside dg_raster_strips
+    hipEvent_t ev_tiles = nullptr;
     hipStream_t copy_stream = nullptr;   // dg_readback_async: D2H of this slot's frames while another slot's kernels run
     uint8_t *copy_out = nullptr;         // pending asynchronous readback (re-issued if the batch has to be redone)
     int copy_first = 0, copy_count = 0;
@@ -161,9 +163,12 @@ struct dg_ctx {
     uint32_t *d_palette = nullptr;
     uint8_t *d_texel_idx = nullptr, *d_texel_opq = nullptr, *d_flats = nullptr;
     uint8_t *d_pool = nullptr;          // row-major texel plane + flats, the strip rasteriser's texel source
-    bool strips = true;                 // dg_resolve_columns + dg_raster_strips + overlay (DOOMGPU_STRIPS=0: dg_raster_tiles alone)
+    bool strips = false;                // DOOMGPU_STRIPS=1: dg_resolve_columns + dg_raster_strips + dg_raster_tile_list instead of dg_raster_tiles alone.
+                                        // Measured on the benchmark scene (a third of its tiles hold masked walls / sprites) the two are
+                                        // equal at 1280x800 and the tile rasteriser alone is faster at 320x200 (profiles/r02_strip_rasteriser.md).
     int seg_cap = 32, band_rows = 1, n_bands = 1;
-    int tile_workgroups = 1024;         // persistent workgroups of dg_raster_tile_list (4 per CU)
+    int tile_workgroups = 512;          // persistent workgroups of dg_raster_tile_list
+    bool side_tiles = true;             // ... on their own stream beside dg_raster_strips (DOOMGPU_SIDE_TILES=0: behind it)
     uint4 *d_row_tab = nullptr;         // per-row constants of the flat / sky mappers (dg_row_table), rebuilt per scene upload
     DevScene dscene{};
     std::vector<Slot> slots;
@@ -215,6 +220,8 @@ void free_ctx(dg_ctx *c) {
         if (s.ev_rstart) (void)hipEventDestroy(s.ev_rstart);
         if (s.ev_resolved) (void)hipEventDestroy(s.ev_resolved);
         if (s.copy_stream) { (void)hipStreamSynchronize(s.copy_stream); (void)hipStreamDestroy(s.copy_stream); }
+        if (s.tile_stream) { (void)hipStreamSynchronize(s.tile_stream); (void)hipStreamDestroy(s.tile_stream); }
+        if (s.ev_tiles) (void)hipEventDestroy(s.ev_tiles);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     if (c->d_palette) (void)hipFree(c->d_palette);
@@ -450,7 +457,7 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
         HIP_TRY(hipEventRecord(s.ev_setup, s.stream));
     }
     HIP_TRY(hipEventRecord(s.ev_rstart, s.stream));
-    HIP_TRY(launch_raster(s.P, s.stream, s.ev_resolved));
+    HIP_TRY(launch_raster(s.P, s.stream, s.ev_resolved, c->side_tiles ? s.tile_stream : nullptr, s.ev_tiles));
     HIP_TRY(hipEventRecord(s.ev_raster, s.stream));
     c->last_raster = s.ev_raster;
     if (s.fe_mode) {
@@ -497,7 +504,7 @@ int settle_slot(dg_ctx *c, Slot &s) {
         if (overflow) {
             c->fallbacks_seg++;
             s.P.strips = 0;
-            hipError_t e = launch_raster(s.P, s.stream, s.ev_resolved);
+            hipError_t e = launch_raster(s.P, s.stream, s.ev_resolved, nullptr, nullptr);
             if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
             if (e != hipSuccess) return set_err(DG_ERR_HIP, std::string("strip fallback: ") + hipGetErrorString(e));
         }
@@ -625,6 +632,9 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
 
     dg_ctx *c = new dg_ctx();
     c->tile_workgroups = std::max(1, prop.multiProcessorCount * 4);
+    c->side_tiles = false;
+    if (const char *e = std::getenv("DOOMGPU_SIDE_TILES")) c->side_tiles = std::strtol(e, nullptr, 10) != 0;
+    if (const char *e = std::getenv("DOOMGPU_TILE_WGS_PER_CU")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 8) c->tile_workgroups = prop.multiProcessorCount * (int)v; }
     c->cfg = *cfg;
     c->fk = make_consts(cfg->width, cfg->height);
     c->dk = DevConsts{c->fk.ARC, c->fk.GCFX, c->fk.CFX, c->fk.CFY, cfg->width, cfg->height};
@@ -697,6 +707,8 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         CTX_TRY(hipEventCreate(&s.ev_rstart));
         CTX_TRY(hipEventCreate(&s.ev_resolved));
         CTX_TRY(hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking));
+        CTX_TRY(hipStreamCreateWithFlags(&s.tile_stream, hipStreamNonBlocking));
+        CTX_TRY(hipEventCreate(&s.ev_tiles));
         CTX_TRY(hipHostMalloc((void **)&s.h_lists, lists_cap, hipHostMallocDefault));
         CTX_TRY(hipMalloc((void **)&s.d_lists, lists_cap));
         CTX_TRY(hipMalloc((void **)&s.d_rspans, c->span_cap_per_batch * sizeof(DevRSpan)));

@@ -257,20 +257,30 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
 }
 
 // The tiles dg_resolve_columns listed: those that a possibly-transparent span (masked wall, sprite) touches, where the
-// winner of a pixel depends on texels and dg_raster_strips therefore does not go.  A fixed number of workgroups strides over
-// the list, so the launch costs the same whether the list holds 50 tiles or 50 000.
+// winner of a pixel depends on texels and dg_raster_strips therefore does not go.  A fixed number of persistent workgroups
+// pulls tiles off the list, so the launch costs the same whether the list holds 50 tiles or 50 000.  It runs on its own
+// stream beside dg_raster_strips: the two kernels stress different parts of a CU (LDS / barriers / ownership walk here,
+// VALU there) and fill each other's gaps.
 __global__ __launch_bounds__(THREADS) void dg_raster_tile_list(RasterParams P) {
     __shared__ __attribute__((aligned(16))) TileLds L;
+    __shared__ uint32_t next_item;
     const uint32_t count = P.tile_counters[0];
-    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {   // tiles cost about the same: a static stride balances well enough
-        if (item != blockIdx.x) __syncthreads();                           // the previous tile's read-out is done with L
+    uint32_t item = blockIdx.x;                       // the first tile is free; further ones come off a shared counter that starts at gridDim.x
+    while (item < count) {
         const uint32_t t = P.tile_list[item];
+        if (threadIdx.x == 0) next_item = gridDim.x + atomicAdd(&P.tile_counters[1], 1u);   // requested now, read after the tile: the round trip is hidden
         tile_body(P, L, (int)(t >> 16), (int)(t & 0xffu) * TILE_W, (int)((t >> 8) & 0xffu) * TILE_H);
+        __syncthreads();                              // the tile's read-out is done with L; next_item is visible
+        item = next_item;
+        __syncthreads();
     }
 }
 
 // ---- strip path ---------------------------------------------------------------------------------------------------------
 
+#ifndef DG_STRIPS_MIN_WAVES
+#define DG_STRIPS_MIN_WAVES 1
+#endif
 constexpr int RES_STAGE = 24;     // row-range words of a column staged in LDS by dg_resolve_columns (longer columns read HBM)
 
 __device__ __forceinline__ void resolve_lane(const RasterParams &P, int f, int x, int lane, uint32_t *lw0, uint32_t (*lbands)[8]) {
@@ -412,8 +422,8 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, int band, con
     // Rows leave four at a time: lane 4q + j (j < 3) parks dword 3q + j of its row in LDS; then lane L < 48 stores 16
     // contiguous bytes (chunk L % 12 of row L / 12) — one vector-memory instruction per four rows instead of four, which
     // matters because the texture/store address unit takes ~16 clocks per wave instruction whatever its width.
-    const uint32_t park_at = (uint32_t)(lane - (lane >> 2));
-    const bool park_on = (lane & 3) != 3;
+    const uint32_t park_at = (lane & 3) != 3 ? (uint32_t)(lane - (lane >> 2)) : 4u * 48u;   // lanes 4q + 3 have no dword of their own: they write
+    const uint32_t park_mul = (lane & 3) != 3 ? 48u : 0u;                                    // one dump slot behind the four rows (never read)
     const int st_row = lane / 12, st_chunk = lane % 12;
     const uint32_t row_bytes = (uint32_t)min(64, W - x0) * 3u;         // of this strip (a multiple of 12: W % 4 == 0)
     const bool st_lane = lane < 48 && (uint32_t)st_chunk * 16u + 16u <= row_bytes;          // the whole 16-byte chunk lies inside the row
@@ -431,10 +441,10 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, int band, con
     };
     int mode = classify();
 
-    // What one row has in flight between its two halves.  The loads are issued with inline assembly and waited for with an
-    // explicit s_waitcnt in row_b: hipcc's own wait insertion would also wait for the row buffer's STORE before it lets the
-    // texel be used, which serialises the rows.
-    struct Row { uint32_t tex; float fac; };
+    // What two rows have in flight between their two halves.  The loads are issued with inline assembly and waited for with
+    // an explicit s_waitcnt in pair_b: hipcc's own wait insertion would also wait for the row buffer's STORE before it lets
+    // the texels be used, which serialises the rows.
+    struct Pair { uint32_t tex0, tex1; float fac0, fac1; };
 
     // visplanes.rs:108-126 for a floor / ceiling pixel within the divide shortcut's verified domain
     auto flat_px = [&](float vy, float r_vy, float &fac) {
@@ -452,12 +462,9 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, int band, con
         const int32_t ty = (f32_as_i16(S.hf + ay * S.q1) + S.off_y) & S.hmask;
         return S.base + (uint32_t)ty * S.wst;
     };
-
-    // Row y, first half: columns whose segment ended on the previous row move to their next one; then the texture mapper
-    // -> pool offset of the texel and the light factor; the texel load is issued and NOT waited for.
-    auto row_a = [&](int y, Row &R) {
-        const u32x4 rc = rows[y];                     // scalar load: prepared 1/vy, sky row, vy (dg_row_table)
-        if (__builtin_amdgcn_ballot_w64(y > S.end) != 0ull) {      // wave-uniform: rows without a segment change skip all of this
+    // columns whose segment ended before row y move to their next one (wave-uniform test: most rows skip all of this)
+    auto advance = [&](int y) {
+        if (__builtin_amdgcn_ballot_w64(y > S.end) != 0ull) {
             if (y > S.end) {
                 seg_unpack(na, nb, S);
                 if (S.end < H - 1) {
@@ -467,38 +474,70 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, int band, con
             }
             mode = classify();
         }
-        const float r_vy = bits_f32(rc.x), vy = bits_f32(rc.z);   // visplanes.rs:109
-        uint32_t off;
-        if (mode == MODE_FLAT) {
-            off = flat_px(vy, r_vy, R.fac);
-        } else if (mode == MODE_WALL) {
-            R.fac = S.fac;
-            off = wall_px(y);
+    };
+    // the texture mapper of row y for lanes of any class -> pool offset of the texel, light factor
+    auto mixed_px = [&](int y, const u32x4 rc, float &fac) {
+        const float r_vy = bits_f32(rc.x), vy = bits_f32(rc.z);
+        uint32_t off = S.base;                        // CLS_NONE: offset 0, factor 0 -> black
+        fac = S.fac;
+        if (mode == MODE_MIXED) {                     // floors / ceilings, power-of-two walls, sky, nothing: one masked pass each
+            if (S.cls == CLS_FLAT) off = flat_px(vy, r_vy, fac);
+            if (S.cls == CLS_WALL) off = wall_px(y);
         } else {
-            off = S.base;                             // CLS_NONE: offset 0, factor 0 -> black
-            R.fac = S.fac;
-            if (mode == MODE_MIXED) {                 // floors / ceilings, power-of-two walls, sky, nothing: one masked pass each
-                if (S.cls == CLS_FLAT) off = flat_px(vy, r_vy, R.fac);
-                if (S.cls == CLS_WALL) off = wall_px(y);
-            } else {
-                if (S.cls == CLS_FLAT || S.cls == CLS_FLAT_SLOW)
-                    off = seg_flat_offset(fr, f32_bits(S.q0), S.base, f32_bits(S.q1), f32_bits(S.q2), S.cls == CLS_FLAT ? 1u : 0u, vy, r_vy, R.fac);
-                else if (S.cls == CLS_WALL || S.cls == CLS_WALL_MOD) {
-                    const int32_t h = (int32_t)S.hf;
-                    off = S.base + (uint32_t)wall_texel_row(S.q0, S.q2, S.q1, (uint32_t)(uint16_t)S.top_y | ((uint32_t)(uint16_t)S.off_y << 16), h, y) * S.wst;
-                }
-            }
-            if (S.cls == CLS_SKY) {
-                const int srow = (int)rc.y;
-                if (srow >= 0) off = S.base + (uint32_t)srow * sky_w;
-                else { off = 0; R.fac = 0.0f; }       // row outside the sky bitmap: nothing is drawn
+            if (S.cls == CLS_FLAT || S.cls == CLS_FLAT_SLOW)
+                off = seg_flat_offset(fr, f32_bits(S.q0), S.base, f32_bits(S.q1), f32_bits(S.q2), S.cls == CLS_FLAT ? 1u : 0u, vy, r_vy, fac);
+            else if (S.cls == CLS_WALL || S.cls == CLS_WALL_MOD) {
+                const int32_t h = (int32_t)S.hf;
+                off = S.base + (uint32_t)wall_texel_row(S.q0, S.q2, S.q1, (uint32_t)(uint16_t)S.top_y | ((uint32_t)(uint16_t)S.off_y << 16), h, y) * S.wst;
             }
         }
-        asm volatile("global_load_ubyte %0, %1, %2" : "=v"(R.tex) : "v"(off), "s"(pool) : "memory");
+        if (S.cls == CLS_SKY) {
+            const int srow = (int)rc.y;
+            if (srow >= 0) off = S.base + (uint32_t)srow * sky_w;
+            else { off = 0; fac = 0.0f; }             // row outside the sky bitmap: nothing is drawn
+        }
+        return off;
+    };
+
+    // Rows y0 and y0 + 1, first half: segment changes, then the texture mappers -> the two texel loads are issued and NOT
+    // waited for.  When no column changes segment between the two rows (the usual case) both rows run one straight-line
+    // mapper on the same per-lane constants, which gives the scheduler two independent dependency chains to interleave.
+    auto pair_a = [&](int y0, Pair &R) {
+        const int y1 = min(y0 + 1, y_hi);
+        const u32x4 rc0 = rows[y0], rc1 = rows[y1];   // scalar loads: prepared 1/vy, sky row, vy (dg_row_table)
+        advance(y0);
+        uint32_t off0, off1;
+        if (__builtin_amdgcn_ballot_w64(y1 > S.end) == 0ull) {
+            if (mode == MODE_FLAT) {
+                off0 = flat_px(bits_f32(rc0.z), bits_f32(rc0.x), R.fac0);
+                off1 = flat_px(bits_f32(rc1.z), bits_f32(rc1.x), R.fac1);
+            } else if (mode == MODE_WALL) {
+                R.fac0 = R.fac1 = S.fac;
+                off0 = wall_px(y0);
+                off1 = wall_px(y1);
+            } else {
+                off0 = mixed_px(y0, rc0, R.fac0);
+                off1 = mixed_px(y1, rc1, R.fac1);
+            }
+        } else {                                      // a segment ends on row y0: the second row runs on the next segment's constants
+            off0 = mixed_px(y0, rc0, R.fac0);
+            advance(y1);
+            off1 = mixed_px(y1, rc1, R.fac1);
+        }
+#ifdef DG_EXP_NOLOAD
+        R.tex0 = off0 & 255u; R.tex1 = off1 & 255u;
+#else
+        asm volatile("global_load_ubyte %0, %1, %2" : "=v"(R.tex0) : "v"(off0), "s"(pool) : "memory");
+        asm volatile("global_load_ubyte %0, %1, %2" : "=v"(R.tex1) : "v"(off1), "s"(pool) : "memory");
+#endif
     };
     // `n` parked rows (192 bytes each) -> HBM.
     auto flush_rows = [&](int n) {
+#ifdef DG_EXP_NOSTORE
+        if (st_lane && st_row < n && rowbuf[0] == 0x12345678u) {
+#else
         if (st_lane && st_row < n) {
+#endif
             const u32x4 v = *reinterpret_cast<const u32x4 *>(&rowbuf[st_row * 48 + st_chunk * 4]);
             asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(st_off), "v"(v), "s"(rowp) : "memory");
         }
@@ -509,42 +548,48 @@ __device__ __forceinline__ void strips_body(const RasterParams &P, int band, con
         rowp += (size_t)n * (size_t)W * 3;
         parked = 0;
     };
-    // Row y, second half: palette, lighting (bitmap_render.rs:202-207), RGB24 packing, park.
-    // The texel of this row must have arrived.  vmcnt counts loads and stores together, but only loads return in issue order
-    // among themselves (a store may complete before an older load), so the only operation that may stay in flight is the one
-    // load known to be younger than this row's: the next row's texel.  Anything else issued in between — segment prefetches,
-    // overlay texels, the row buffer's store — only makes the wait stricter.
-    auto row_b = [&](Row &R, bool keep) {
-        asm volatile("s_waitcnt vmcnt(1)" : "+v"(R.tex) : : "memory");
-        uint32_t tex = R.tex;
-        float fac = R.fac;
+    // palette, lighting (bitmap_render.rs:202-207), RGB24 packing of one pixel per lane -> this lane's dword of the packed row
+    auto shade_pack = [&](uint32_t tex, float fac) {
+#ifdef DG_EXP_NOPAL
+        const float4 c = make_float4((float)tex, (float)(tex >> 1), (float)(tex >> 2), 0.0f);
+#else
         const float4 c = palf[tex];
+#endif
         uint32_t px;
-        {
-            const float r = __builtin_truncf(c.x * fac), g = __builtin_truncf(c.y * fac), b = __builtin_truncf(c.z * fac);
-            asm("v_cvt_pk_u8_f32 %0, %1, 0, 0" : "=v"(px) : "v"(r));
-            asm("v_cvt_pk_u8_f32 %0, %1, 1, %2" : "=v"(px) : "v"(g), "v"(px));
-            asm("v_cvt_pk_u8_f32 %0, %1, 2, %2" : "=v"(px) : "v"(b), "v"(px));
-        }
+        const float r = __builtin_truncf(c.x * fac), g = __builtin_truncf(c.y * fac), b = __builtin_truncf(c.z * fac);
+        asm("v_cvt_pk_u8_f32 %0, %1, 0, 0" : "=v"(px) : "v"(r));
+        asm("v_cvt_pk_u8_f32 %0, %1, 1, %2" : "=v"(px) : "v"(g), "v"(px));
+        asm("v_cvt_pk_u8_f32 %0, %1, 2, %2" : "=v"(px) : "v"(b), "v"(px));
         const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)px, (int)px, 0xF9, 0xf, 0xf, false);   // quad_perm [1,2,3,3]
-        const uint32_t out = __builtin_amdgcn_perm(nx, px, perm_sel);
-        if (!keep) return;                            // wave-uniform: the look-ahead past the band's last row
-        if (park_on) rowbuf[parked * 48 + park_at] = out;
-        if (++parked == 4) flush_rows(4);
+        return __builtin_amdgcn_perm(nx, px, perm_sel);
     };
-    // Order of the vector-memory operations:  L(y+1)  [wait L(y)]  (S)  L(y+2)  [wait L(y+1)]  (S) ...
-    // The loop has ONE shape for every trip — an odd last row is loaded twice rather than handled by a peeled tail — so that
-    // a texel in flight always sits in the register its load was issued into: a register copy inserted on a loop-exit edge
-    // would read the register before the load has landed (tests/test_isa_checks.py looks for such reads in the built ISA).
-    Row A, B;
-    row_a(y_lo, A);
-    for (int y = y_lo; y <= y_hi; y += 2) {           // two rows per trip so that the in-flight texel needs no register move
-        row_a(min(y + 1, y_hi), B);
-        row_b(A, true);
-        row_a(min(y + 2, y_hi), A);
-        row_b(B, y + 1 <= y_hi);
+    // The pair's second half; `keep` of its rows are real (the look-ahead past the band's last row is computed and dropped).
+    // The pair's texels must have arrived.  vmcnt counts loads and stores together, but only loads return in issue order
+    // among themselves (a store may complete before an older load), so the only operations that may stay in flight are the two
+    // loads known to be younger: the next pair's texels.  Anything else issued in between — segment prefetches, the row
+    // buffer's store — only makes the wait stricter.
+    auto pair_b = [&](Pair &R, int keep) {
+        asm volatile("s_waitcnt vmcnt(2)" : "+v"(R.tex0), "+v"(R.tex1) : : "memory");
+        const uint32_t out0 = shade_pack(R.tex0, R.fac0), out1 = shade_pack(R.tex1, R.fac1);
+        if (keep <= 0) return;                        // wave-uniform
+        rowbuf[(uint32_t)parked * park_mul + park_at] = out0;
+        if (keep > 1) rowbuf[(uint32_t)(parked + 1) * park_mul + park_at] = out1;
+        parked += keep;
+        if (parked >= 4) flush_rows(4);
+    };
+    // Order of the vector-memory operations:  L(p+1) x2  [wait L(p)]  (S)  L(p+2) x2  [wait L(p+1)]  (S) ...
+    // The loop has ONE shape for every trip — rows past the band's end are loaded again rather than handled by a peeled tail —
+    // so that a texel in flight always sits in the register its load was issued into: a register copy inserted on a loop-exit
+    // edge would read the register before the load has landed (tests/test_isa_checks.py looks for such reads in the built ISA).
+    Pair A, B;
+    pair_a(y_lo, A);
+    for (int y = y_lo; y <= y_hi; y += 4) {           // two pairs per trip so that the in-flight texels need no register move
+        pair_a(min(y + 2, y_hi), B);
+        pair_b(A, min(2, y_hi - y + 1));
+        pair_a(min(y + 4, y_hi), A);
+        pair_b(B, min(2, y_hi - (y + 2) + 1));
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(A.tex) : : "memory");   // the last, unused look-ahead
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(A.tex0), "+v"(A.tex1) : : "memory");   // the last, unused look-ahead
     if (parked) flush_rows(parked);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -557,9 +602,9 @@ __device__ __forceinline__ void stage_palette(const RasterParams &P, float4 *pal
 }
 
 // Four wavefronts = four consecutive bands of one strip per workgroup (they are independent and only share the palette).
-__global__ __launch_bounds__(256) void dg_raster_strips(RasterParams P) {
+__global__ __launch_bounds__(256, DG_STRIPS_MIN_WAVES) void dg_raster_strips(RasterParams P) {
     __shared__ float4 palf[256];                      // palette as f32 triples: shading needs no v_cvt_f32_ubyte
-    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[4][4 * 48];   // per wave: four finished rows of the strip (RGB24, 192 B each)
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[4][4 * 48 + 16];   // per wave: four finished rows of the strip (RGB24, 192 B each) + a dump slot
     const int f = blockIdx.z;
     if (P.frame_flags[f] != 0u) return;               // segment slots exceeded: the batch is redone by dg_raster_tiles
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -613,7 +658,7 @@ hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hip
     return hipGetLastError();
 }
 
-hipError_t launch_raster(const RasterParams &P, hipStream_t stream, hipEvent_t after_resolve) {
+hipError_t launch_raster(const RasterParams &P, hipStream_t stream, hipEvent_t after_resolve, hipStream_t aux, hipEvent_t aux_done) {
     if (P.n_frames <= 0) return hipSuccess;
     const unsigned strips = (unsigned)((P.k.W + TILE_W - 1) / TILE_W);
     if (P.strips) {
@@ -623,8 +668,15 @@ hipError_t launch_raster(const RasterParams &P, hipStream_t stream, hipEvent_t a
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(dg_resolve_columns, dim3((strips + 3) / 4, (unsigned)P.n_frames), dim3(256), 0, stream, P);
         if (after_resolve) { e = hipEventRecord(after_resolve, stream); if (e != hipSuccess) return e; }
+        const bool side = aux && aux_done && after_resolve;
+        if (side) {                                   // the tile list beside the strips
+            if ((e = hipStreamWaitEvent(aux, after_resolve, 0)) != hipSuccess) return e;
+            hipLaunchKernelGGL(dg_raster_tile_list, dim3((unsigned)P.tile_workgroups), dim3(THREADS), 0, aux, P);
+            if ((e = hipEventRecord(aux_done, aux)) != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(dg_raster_strips, dim3(strips, (unsigned)((P.n_bands + 3) / 4), (unsigned)P.n_frames), dim3(256), 0, stream, P);
-        hipLaunchKernelGGL(dg_raster_tile_list, dim3((unsigned)P.tile_workgroups), dim3(THREADS), 0, stream, P);
+        if (side) { if ((e = hipStreamWaitEvent(stream, aux_done, 0)) != hipSuccess) return e; }
+        else hipLaunchKernelGGL(dg_raster_tile_list, dim3((unsigned)P.tile_workgroups), dim3(THREADS), 0, stream, P);
         return hipGetLastError();
     }
     dim3 grid(strips, (unsigned)((P.k.H + TILE_H - 1) / TILE_H), (unsigned)P.n_frames);

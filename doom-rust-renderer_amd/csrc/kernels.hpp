@@ -23,7 +23,7 @@ struct RasterParams {
     DevSeg *segs;                // [n_frames][seg_cap][W]
     uint8_t *band_first;         // [n_frames][n_bands][W] slot of the segment that contains the first row of a band
     uint32_t *frame_flags;       // [max_batch] != 0: a column needed more than seg_cap segments; the batch is redone with strips = 0
-    uint32_t *tile_counters;     // [0] tiles on the list ([1] unused)
+    uint32_t *tile_counters;     // [0] tiles on the list, [1] tiles taken beyond each workgroup's first (dg_raster_tile_list)
     uint8_t *band_ovl;           // [n_frames][n_bands][ceil(W / 64)] != 0: an overlay span (strip_core.h) touches that band of that 64-column
                                  // strip -> rendered by dg_raster_tile_list (these three directly follow each other: one fill clears them)
     uint32_t *tile_list;         // frame << 16 | band << 8 | strip
@@ -35,7 +35,8 @@ struct RasterParams {
 hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hipStream_t stream);
 // dg_resolve_columns + dg_raster_strips + dg_raster_tile_list when P.strips, else dg_raster_tiles.
 // after_resolve (optional) is recorded between dg_resolve_columns and the pixel kernels.
-hipError_t launch_raster(const RasterParams &P, hipStream_t stream, hipEvent_t after_resolve = nullptr);
+// With aux / aux_done (a second stream and an event), dg_raster_tile_list runs on aux beside dg_raster_strips; `stream` waits for it.
+hipError_t launch_raster(const RasterParams &P, hipStream_t stream, hipEvent_t after_resolve = nullptr, hipStream_t aux = nullptr, hipEvent_t aux_done = nullptr);
 // Rows per band of dg_raster_strips for a frame height (one wavefront renders 64 columns x band_rows rows).
 int strip_band_rows(int H);
 // out[k] = checksum (include/doomgpu.h: dg_frame_checksums) of frame k of `count` consecutive frames of `frame_bytes` bytes at fb; out must be zeroed.

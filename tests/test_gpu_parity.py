@@ -458,6 +458,7 @@ def test_segment_capacity_falls_back_to_the_tile_rasteriser(dg, scene1994, oracl
     with dg_raster_tiles (same pixels), and dg_ctx_fallbacks counts it.  With two slots per column every frame overflows."""
     W, H = 320, 200
     idx = list(range(0, 1000, 100))
+    monkeypatch.setenv("DOOMGPU_STRIPS", "1")
     monkeypatch.setenv("DOOMGPU_SEG_SLOTS", "2")
     ctx = make_ctx(dg, scene1994, W, H, len(idx), slots=2)
     monkeypatch.delenv("DOOMGPU_SEG_SLOTS")
@@ -476,22 +477,29 @@ def test_segment_capacity_falls_back_to_the_tile_rasteriser(dg, scene1994, oracl
     ctx.close()
 
 
-def test_tile_rasteriser_alone_is_bit_exact(dg, scene1993, oracle_scene1993, path1993, monkeypatch):
-    """DOOMGPU_STRIPS=0: every tile through dg_raster_tiles (the path the segment fallback takes)."""
-    monkeypatch.setenv("DOOMGPU_STRIPS", "0")
-    idx = list(range(0, 1000, 125))
-    for (W, H) in ((320, 200), (1280, 800)):
-        ctx = make_ctx(dg, scene1993, W, H, len(idx))
-        out = ctx.render(dg.make_views(path1993[idx]))
-        assert ctx.timing(0)["strips_ms"] == 0.0
-        for k, i in enumerate(idx):
-            assert np.array_equal(out[k], np.frombuffer(oracle_scene1993.render(W, H, path1993[i]), dtype=np.uint8).reshape(H, W, 3)), f"frame {i}"
-        ctx.close()
+@pytest.mark.parametrize("side", ["0", "1"], ids=["tile-list-behind", "tile-list-beside"])
+def test_strip_rasteriser_is_bit_exact(dg, scene1993, scene1994, oracle_scene1993, oracle_scene1994, path1993, path1994, monkeypatch, side):
+    """DOOMGPU_STRIPS=1: dg_resolve_columns + dg_raster_strips (tiles made of opaque spans only) + dg_raster_tile_list (tiles a
+    masked wall / sprite touches), against the oracle at sizes with full and partial strips and bands, both maps."""
+    monkeypatch.setenv("DOOMGPU_STRIPS", "1")
+    monkeypatch.setenv("DOOMGPU_SIDE_TILES", side)
+    for (scene, osc, path, sizes) in ((scene1993, oracle_scene1993, path1993, ((320, 200), (1280, 800), (132, 67), (64, 48), (1024, 768))),
+                                      (scene1994, oracle_scene1994, path1994, ((320, 200), (2560, 1600)))):
+        for (W, H) in sizes:
+            idx = list(range(0, 1000, 125 if W * H > 70000 else 40))
+            ctx = make_ctx(dg, scene, W, H, len(idx))
+            out = ctx.render(dg.make_views(path[idx]))
+            assert ctx.timing(0)["strips_ms"] > 0.0 and ctx.fallbacks()["segments"] == 0
+            for k, i in enumerate(idx):
+                assert np.array_equal(out[k], np.frombuffer(osc.render(W, H, path[i]), dtype=np.uint8).reshape(H, W, 3)), f"frame {i} at {W}x{H}"
+            ctx.close()
 
 
-def test_overlapped_slots_device_front_end(dg, scene1993, path1993):
+@pytest.mark.parametrize("strips", ["0", "1"], ids=["tiles", "strips"])
+def test_overlapped_slots_device_front_end(dg, scene1993, path1993, monkeypatch, strips):
     """Four slots submitted back to back with no waits (the column scratch is shared between slots and ordered only by the
     event chain in enqueue_kernels), replayed in rotated order, then waited: every slot's frames must equal a quiet render."""
+    monkeypatch.setenv("DOOMGPU_STRIPS", strips)
     W, H, B, S = 320, 200, 40, 4
     batches = [path1993[s * 250:s * 250 + B] for s in range(S)]
     quiet = dg.Context(W, H, max_batch=B, slots=1, front_end=dg.DG_FE_DEVICE)
