@@ -35,6 +35,19 @@ class DgView(ctypes.Structure):
                [("trig_valid", ctypes.c_int32)]
 
 
+class DgSectorLight(ctypes.Structure):
+    _fields_ = [("sector", ctypes.c_int32), ("light_level", ctypes.c_int32)]
+
+
+class DgMobjState(ctypes.Structure):
+    _fields_ = [("mobj", ctypes.c_int32), ("sprite_frame", ctypes.c_int32), ("full_bright", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class DgViewState(ctypes.Structure):
+    _fields_ = [("lights", ctypes.POINTER(DgSectorLight)), ("n_lights", ctypes.c_uint32),
+                ("mobjs", ctypes.POINTER(DgMobjState)), ("n_mobjs", ctypes.c_uint32)]
+
+
 class DgConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in "device width height max_batch slots host_threads front_end".split()]
 
@@ -106,6 +119,9 @@ _SIGNATURES = {
     "dg_upload_scene": (ctypes.c_int, [_P, _P]),
     "dg_render_views": (ctypes.c_int, [_P, ctypes.POINTER(DgView), ctypes.c_int, _P]),
     "dg_submit_views": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(DgView), ctypes.c_int]),
+    "dg_submit_views_state": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(DgView), ctypes.POINTER(DgViewState), ctypes.c_int]),
+    "dg_render_views_state": (ctypes.c_int, [_P, ctypes.POINTER(DgView), ctypes.POINTER(DgViewState), ctypes.c_int, _P]),
+    "dg_scene_sprite_frame": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_uint8]),
     "dg_wait": (ctypes.c_int, [_P, ctypes.c_int]),
     "dg_slot_framebuffer": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(_P)]),
     "dg_readback": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
@@ -149,6 +165,19 @@ def _check(rc: int):
     return rc
 
 
+def make_view_states(states):
+    """states: one (lights, mobjs) pair per view; lights = [(sector, light_level), ...], mobjs = [(mobj, sprite_frame or -1, full_bright), ...].
+    Returns (ctypes array of dg_view_state, keep-alive list)."""
+    arr = (DgViewState * len(states))()
+    keep = []
+    for i, (lights, mobjs) in enumerate(states):
+        la = (DgSectorLight * max(1, len(lights)))(*[DgSectorLight(int(s), int(l)) for s, l in lights])
+        ma = (DgMobjState * max(1, len(mobjs)))(*[DgMobjState(int(m), int(sf), int(fb), 0) for m, sf, fb in mobjs])
+        keep += [la, ma]
+        arr[i] = DgViewState(la, len(lights), ma, len(mobjs))
+    return arr, keep
+
+
 def make_views(records, timestamp: float = 0.0):
     """camera_path records (n, 8) f32 [x, y, angle, cos, sin, cos(-a), sin(-a), floor] -> ctypes array of dg_view."""
     recs = np.asarray(records, dtype=np.float32).reshape(-1, 8)
@@ -185,6 +214,10 @@ class Scene:
 
     def mobj_count(self) -> int:
         return lib().dg_scene_mobj_count(self._h)
+
+    def sprite_frame(self, sprite: str, frame: int = 0) -> int:
+        """Handle for dg_mobj_state.sprite_frame (may decode bitmaps: call before Context.upload_scene)."""
+        return _check(lib().dg_scene_sprite_frame(self._h, sprite.encode(), frame))
 
     def set_mobj_state(self, mobj: int, sprite, frame: int = 0, full_bright: bool = False):
         _check(lib().dg_scene_set_mobj_state(self._h, mobj, sprite.encode() if sprite else None, frame, int(full_bright)))
@@ -226,8 +259,18 @@ class Context:
         _check(lib().dg_render_views(self._h, views, n, out.ctypes.data_as(_P)))
         return out
 
-    def submit(self, slot: int, views, n=None):
-        _check(lib().dg_submit_views(self._h, slot, views, len(views) if n is None else n))
+    def submit(self, slot: int, views, n=None, states=None):
+        if states is None:
+            _check(lib().dg_submit_views(self._h, slot, views, len(views) if n is None else n))
+        else:
+            _check(lib().dg_submit_views_state(self._h, slot, views, states, len(views) if n is None else n))
+
+    def render_state(self, views, states) -> np.ndarray:
+        """render() with one game-state snapshot per view (make_view_states)."""
+        n = len(views)
+        out = np.empty((n, self.height, self.width, 3), dtype=np.uint8)
+        _check(lib().dg_render_views_state(self._h, views, states, n, out.ctypes.data_as(_P)))
+        return out
 
     def wait(self, slot: int):
         _check(lib().dg_wait(self._h, slot))

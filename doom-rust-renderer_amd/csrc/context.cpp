@@ -140,6 +140,20 @@ struct Slot {
     bool fe_mode = false;         // the last submission went through the device column walk
     bool fe_check = false;        // ... and its overflow flags have not been looked at yet
     std::vector<dg_view> views;   // the views of that submission (to redo it on the host if a capacity overflowed)
+    // ... and a private copy of their game-state snapshots (the caller's arrays need not outlive the call)
+    std::vector<dg_view_state> states;
+    std::vector<dg_sector_light> state_lights;
+    std::vector<dg_mobj_state> state_mobjs;
+    void keep_states(const dg_view_state *st, int n) {
+        states.clear(); state_lights.clear(); state_mobjs.clear();
+        if (!st) return;
+        for (int i = 0; i < n; i++) { state_lights.insert(state_lights.end(), st[i].lights, st[i].lights + st[i].n_lights); state_mobjs.insert(state_mobjs.end(), st[i].mobjs, st[i].mobjs + st[i].n_mobjs); }
+        size_t lo = 0, mo = 0;
+        for (int i = 0; i < n; i++) {
+            states.push_back(dg_view_state{state_lights.data() + lo, st[i].n_lights, state_mobjs.data() + mo, st[i].n_mobjs});
+            lo += st[i].n_lights; mo += st[i].n_mobjs;
+        }
+    }
 };
 
 struct FeFrameOut {               // parts-mode output of one frame, owned per batch index
@@ -169,6 +183,7 @@ struct dg_ctx {
     int seg_cap = 32, band_rows = 1, n_bands = 1;
     int tile_workgroups = 512;          // persistent workgroups of dg_raster_tile_list
     bool side_tiles = true;             // ... on their own stream beside dg_raster_strips (DOOMGPU_SIDE_TILES=0: behind it)
+    unsigned long long *d_checksums = nullptr;   // dg_frame_checksums scratch, max_batch entries
     uint4 *d_row_tab = nullptr;         // per-row constants of the flat / sky mappers (dg_row_table), rebuilt per scene upload
     DevScene dscene{};
     std::vector<Slot> slots;
@@ -230,6 +245,7 @@ void free_ctx(dg_ctx *c) {
     if (c->d_flats) (void)hipFree(c->d_flats);
     if (c->d_pool) (void)hipFree(c->d_pool);
     if (c->d_row_tab) (void)hipFree(c->d_row_tab);
+    if (c->d_checksums) (void)hipFree(c->d_checksums);
     if (c->d_fe_cnt) (void)hipFree(c->d_fe_cnt);
     if (c->d_fe_cspans) (void)hipFree(c->d_fe_cspans);
     if (c->d_fe_recs) (void)hipFree(c->d_fe_recs);
@@ -246,7 +262,7 @@ void fill_strip_params(const dg_ctx *c, const Slot &s, RasterParams &P) {
 }
 
 // Build + bin the lists of n views in parallel, pack them into the slot's pinned slab, fill slot.P.
-int build_batch_host(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *given, int n) {
+int build_batch_host(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *given, int n, const dg_view_state *states = nullptr) {
     const auto t0 = std::chrono::steady_clock::now();
     if (!c->scene) return set_err(DG_ERR_INVALID, "no scene uploaded (dg_upload_scene)");
     if (n <= 0 || n > c->cfg.max_batch) return set_err(DG_ERR_CAPACITY, "batch size outside [1, max_batch]");
@@ -265,7 +281,7 @@ int build_batch_host(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_li
             dg_view v = views[i];
             fill_view_trig(v);
             dg_frame_lists fl;
-            rc[(size_t)i] = build_frame_lists(sc, W, H, v, *c->arenas[(size_t)wid], fl, errs[(size_t)i]);
+            rc[(size_t)i] = build_frame_lists(sc, W, H, v, *c->arenas[(size_t)wid], fl, errs[(size_t)i], states ? &states[i] : nullptr);
             if (!rc[(size_t)i]) rc[(size_t)i] = bin_frame(sc, c->fk, fl, bf, errs[(size_t)i]);
         }
     });
@@ -321,7 +337,7 @@ int build_batch_host(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_li
 
 // DG_FE_DEVICE: build the per-seg / per-sprite records of n views in parallel, pack them into the slot's record slab,
 // fill slot.FP / slot.P.  Returns kPartsUnsupported when the batch has to go through build_batch_host instead.
-int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
+int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_view_state *states) {
     const auto t0 = std::chrono::steady_clock::now();
     if (!c->scene) return set_err(DG_ERR_INVALID, "no scene uploaded (dg_upload_scene)");
     if (n <= 0 || n > c->cfg.max_batch) return set_err(DG_ERR_CAPACITY, "batch size outside [1, max_batch]");
@@ -335,7 +351,7 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
         FeFrameOut &o = c->fe_out[(size_t)i];
         dg_view v = views[i];
         fill_view_trig(v);
-        rc[(size_t)i] = build_frame_parts(sc, W, H, v, A, errs[(size_t)i]);
+        rc[(size_t)i] = build_frame_parts(sc, W, H, v, A, errs[(size_t)i], states ? &states[i] : nullptr);
         if (rc[(size_t)i]) return;
         o.parts.swap(A.parts); o.sprites.swap(A.sprites); o.behind.swap(A.behind); o.sky_parts.swap(A.sky_parts);
         o.bin_off.swap(A.bin_off); o.bin_parts.swap(A.bin_parts); o.sbin_off.swap(A.sbin_off); o.sbin_sprites.swap(A.sbin_sprites);
@@ -423,17 +439,18 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     s.list_bytes = total;
     s.fe_mode = true; s.fe_check = false; s.seg_check = false;
     s.views.assign(views, views + n);
+    s.keep_states(states, n);
     s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIP_TRY(hipMemcpyAsync(s.d_fe, s.h_fe, total, hipMemcpyHostToDevice, s.stream));
     return DG_OK;
 }
 
-int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *given, int n) {
+int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *given, int n, const dg_view_state *states = nullptr) {
     if (!given && c->fe_enabled && c->fe_scene_ok) {
-        const int rc = build_batch_fe(c, s, views, n);
+        const int rc = build_batch_fe(c, s, views, n, states);
         if (rc != kPartsUnsupported) return rc;
     }
-    return build_batch_host(c, s, views, given, n);
+    return build_batch_host(c, s, views, given, n, states);
 }
 
 int enqueue_kernels(dg_ctx *c, Slot &s) {
@@ -488,7 +505,7 @@ int settle_slot(dg_ctx *c, Slot &s) {
             c->fallbacks_fe++;
             s.seg_check = false;
             const std::vector<dg_view> views = s.views;
-            int rc = build_batch_host(c, s, views.data(), nullptr, (int)views.size());
+            int rc = build_batch_host(c, s, views.data(), nullptr, (int)views.size(), s.states.empty() ? nullptr : s.states.data());
             if (rc) return rc;
             rc = enqueue_kernels(c, s);
             if (rc) return rc;
@@ -694,6 +711,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     c->slots.resize((size_t)cfg->slots);
     hipError_t e;
 #define CTX_TRY(expr) if ((e = (expr)) != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(e); free_ctx(c); return set_err(DG_ERR_HIP, m); }
+    CTX_TRY(hipMalloc((void **)&c->d_checksums, F * 8));
     if (c->fe_enabled) {
         CTX_TRY(hipMalloc((void **)&c->d_fe_cspans, F * c->fe_col_slots * W * sizeof(FeU4)));
         CTX_TRY(hipMalloc((void **)&c->d_fe_recs, F * c->fe_col_slots * W * sizeof(FeColRec)));
@@ -777,15 +795,34 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     return DG_OK;
 }
 
-int dg_submit_views(dg_ctx *c, int slot, const dg_view *views, int n) {
+int dg_submit_views(dg_ctx *c, int slot, const dg_view *views, int n) { return dg_submit_views_state(c, slot, views, nullptr, n); }
+
+int dg_scene_sprite_frame(dg_scene *s, const char *sprite, uint8_t frame) {
+    if (!s || !sprite) return set_err(DG_ERR_INVALID, "null argument");
+    std::string err;
+    const int sf = s->sc->find_or_add_sprite_frame(sprite, frame, err);
+    return sf < 0 ? set_err(DG_ERR_WAD, err) : sf;
+}
+
+int dg_render_views_state(dg_ctx *c, const dg_view *views, const dg_view_state *states, int n, uint8_t *out) {
+    int rc = dg_submit_views_state(c, 0, views, states, n);
+    if (rc) return rc;
+    if (out) return dg_readback(c, 0, 0, n, out);
+    return dg_wait(c, 0);
+}
+
+int dg_submit_views_state(dg_ctx *c, int slot, const dg_view *views, const dg_view_state *states, int n) {
     int rc = check_slot(c, slot);
     if (rc) return rc;
     if (!views) return set_err(DG_ERR_INVALID, "null views");
+    if (states)
+        for (int i = 0; i < n; i++)
+            if ((states[i].n_lights && !states[i].lights) || (states[i].n_mobjs && !states[i].mobjs)) return set_err(DG_ERR_INVALID, "view state with a null array");
     HIP_TRY(hipSetDevice(c->cfg.device));
     Slot &s = c->slots[(size_t)slot];
     if (s.busy || s.copy_pending) { rc = finish_slot(c, s); if (rc) return rc; }
     s.fe_check = false; s.seg_check = false;
-    rc = build_batch(c, s, views, nullptr, n);
+    rc = build_batch(c, s, views, nullptr, n, states);
     if (rc) return rc;
     return enqueue_kernels(c, s);
 }
@@ -857,13 +894,11 @@ int dg_frame_checksums(dg_ctx *c, int slot, int first, int count, uint64_t *out)
         if (rc) return rc;
     }
     const size_t fsz = (size_t)3 * (size_t)c->cfg.width * (size_t)c->cfg.height;
-    unsigned long long *d_sum = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_sum, (size_t)count * 8));
+    unsigned long long *d_sum = c->d_checksums;      // max_batch entries, allocated at dg_create
     hipError_t e = hipMemsetAsync(d_sum, 0, (size_t)count * 8, s.stream);
     if (e == hipSuccess) e = launch_checksums(s.d_fb + (size_t)first * fsz, fsz, count, d_sum, s.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_sum, (size_t)count * 8, hipMemcpyDeviceToHost, s.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
-    (void)hipFree(d_sum);
     if (e != hipSuccess) return set_err(DG_ERR_HIP, std::string("dg_frame_checksums: ") + hipGetErrorString(e));
     s.busy = false;
     return DG_OK;

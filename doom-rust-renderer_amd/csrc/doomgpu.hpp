@@ -1,5 +1,5 @@
 // doomgpu.hpp — host-side mirror of the reference's draw API for this path, in C++ because the reference is compiled
-// code and no Rust toolchain exists in this image (the Rust binding is given as source in INTEGRATION.md).
+// code and no Rust toolchain exists in this image (the Rust binding is shipped as source under rust/).
 //
 //   reference (src/renderer/pixels.rs:5-47, src/renderer/mod.rs:27-58,118-136, src/game.rs:40-45,505-525)      here
 //   Pixels::new() / .pixels / clear / set / draw_vertical_line                                          doom::Pixels
@@ -10,6 +10,8 @@
 // Same names, argument meaning and ownership: the caller owns Pixels and World, the Renderer borrows them for one
 // frame.  Where the reference panics these wrappers throw doom::Error carrying the dg_status code.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -92,7 +94,10 @@ public:
     Renderer(Pixels &pixels, const World &world, const Player &player, float timestamp, Device &dev)
         : pixels_(pixels), dev_(dev) {
         (void)world;   // the device already holds the uploaded world; kept in the signature to mirror Renderer::new
-        view_ = dg_view{player.position.x, player.position.y, player.angle, player.floor_height, 0, 0, 0, 0, timestamp, 0};
+        // Vertex::rotate (src/map/vertexes.rs:20-25) evaluates f32::cos / f32::sin of +-angle: the same libm calls, made here,
+        // so that the library consumes the caller's bits (trig_valid = 1) instead of evaluating its own
+        const float a = player.angle;
+        view_ = dg_view{player.position.x, player.position.y, a, player.floor_height, std::cos(a), std::sin(a), std::cos(-a), std::sin(-a), timestamp, 1};
     }
     void render() { check(dg_render_views(dev_.handle(), &view_, 1, pixels_.pixels.data())); }
 private:

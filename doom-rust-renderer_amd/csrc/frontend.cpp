@@ -199,10 +199,54 @@ struct Walker {
     // visplanes carry a pool tag in the top bit of first_entry until finalisation
     static constexpr uint32_t kCeilPool = 0x80000000u;
 
-    Walker(const Scene &s, int W, int H, const dg_view &v, FrameArena &a, std::string &e)
+    const dg_view_state *state = nullptr;   // this view's game-state snapshot (light levels, mobj states) on top of the scene's
+
+    Walker(const Scene &s, int W, int H, const dg_view &v, FrameArena &a, std::string &e, const dg_view_state *st = nullptr)
         : sc(s), k(make_consts(W, H)), view(v), A(a), recs(*a.recs), err(e) {
         ppos = V2{v.x, v.y};
         player_height = v.floor_height + kEye;
+        apply_state(st);
+    }
+    ~Walker() {                                                      // the arena's overlay tables go back to "no override"
+        if (!state) return;
+        for (uint32_t i = 0; i < state->n_lights; i++)
+            if ((size_t)state->lights[i].sector < A.light_ov.size()) A.light_ov[(size_t)state->lights[i].sector] = kNoOverride;
+        for (uint32_t i = 0; i < state->n_mobjs; i++)
+            if ((size_t)state->mobjs[i].mobj < A.mobj_ov.size()) A.mobj_ov[(size_t)state->mobjs[i].mobj] = kNoOverride;
+    }
+    static constexpr int32_t kNoOverride = INT32_MIN;
+
+    // sector.light_level / map object state as the reference's thinkers would have left them before this frame
+    // (src/lights.rs:47-259, src/map_objects.rs:63-121): the view's snapshot entry if there is one, else the scene's value.
+    void apply_state(const dg_view_state *st) {
+        if (!st || (st->n_lights == 0 && st->n_mobjs == 0)) return;
+        if (A.light_ov.size() != sc.sectors.size()) A.light_ov.assign(sc.sectors.size(), kNoOverride);
+        if (A.mobj_ov.size() != sc.mobjs.size()) A.mobj_ov.assign(sc.mobjs.size(), kNoOverride);
+        for (uint32_t i = 0; i < st->n_lights; i++) {
+            const dg_sector_light &l = st->lights[i];
+            if (l.sector < 0 || (size_t)l.sector >= sc.sectors.size()) { status = DG_ERR_INVALID; err = "view state: sector index out of range"; continue; }
+            A.light_ov[(size_t)l.sector] = (int32_t)l.light_level;
+        }
+        for (uint32_t i = 0; i < st->n_mobjs; i++) {
+            const dg_mobj_state &m = st->mobjs[i];
+            if (m.mobj < 0 || (size_t)m.mobj >= sc.mobjs.size() || m.sprite_frame >= (int32_t)sc.sprite_frames.size()) {
+                status = DG_ERR_INVALID; err = "view state: map object or sprite frame index out of range"; continue;
+            }
+            A.mobj_ov[(size_t)m.mobj] = (m.sprite_frame < 0 ? -1 : m.sprite_frame) * 2 + (m.full_bright ? 1 : 0);   // -2 / -1: S_NULL
+        }
+        state = st;
+    }
+    int16_t sector_light(int sector) const {
+        if (state && A.light_ov[(size_t)sector] != kNoOverride) return (int16_t)A.light_ov[(size_t)sector];
+        return sc.sectors[(size_t)sector].light;
+    }
+    void mobj_state(size_t i, int32_t &sprite_frame, int32_t &full_bright) const {
+        const MapObjectRec &m = sc.mobjs[i];
+        sprite_frame = m.sprite_frame; full_bright = m.full_bright;
+        if (state && A.mobj_ov[i] != kNoOverride) {
+            const int32_t v = A.mobj_ov[i];
+            sprite_frame = v < 0 ? -1 : v >> 1; full_bright = v < 0 ? 0 : v & 1;
+        }
     }
 
     int fail(const std::string &m) {
@@ -432,7 +476,7 @@ struct Walker {
             ceiling_height = std::fmin((float)bs->ceil_h, ceiling_height);
             draw_ceiling = false;
         }
-        Side s{&cl, &front, sg.offset, fs.floor_h, fs.ceil_h, fs.light, floor_flat, ceil_flat};
+        Side s{&cl, &front, sg.offset, fs.floor_h, fs.ceil_h, sector_light(front.sector), floor_flat, ceil_flat};
 
         if (!two_sided) {
             int32_t oy = bottom_unpegged ? f32_as_i32(floor_height - ceiling_height) : 0;
@@ -523,8 +567,11 @@ struct Walker {
         const size_t n_wall_recs = recs.size();
         if (parts_mode) A.behind_words = (uint32_t)((n_wall_recs + 31) / 32);
         std::vector<uint32_t> mo;   // indices of map-object records in recs
-        for (const MapObjectRec &m : sc.mobjs) {
-            if (m.sprite_frame < 0) continue;                         // S_NULL
+        for (size_t mi = 0; mi < sc.mobjs.size(); mi++) {
+            const MapObjectRec &m = sc.mobjs[mi];
+            int32_t m_sprite_frame, m_full_bright;
+            mobj_state(mi, m_sprite_frame, m_full_bright);
+            if (m_sprite_frame < 0) continue;                         // S_NULL
             float angle = view.angle - m.angle - kPi;
             angle += kPi / 16.0f;
             angle = std::fmod(angle, 2.0f * kPi);
@@ -532,7 +579,7 @@ struct Walker {
             angle = std::fmod(angle, 2.0f * kPi);
             int rotation = f32_as_u8(angle * 8.0f / (2.0f * kPi));
             if (rotation > 7) { fail("Invalid rotation (sprites.rs:106-108)"); return; }
-            const SpriteFrameRec &sf = sc.sprite_frames[(size_t)m.sprite_frame];
+            const SpriteFrameRec &sf = sc.sprite_frames[(size_t)m_sprite_frame];
             int bitmap = sf.rotate ? sf.bitmap[rotation] : sf.bitmap[0];
             const BitmapInfo &bi = sc.bitmaps[(size_t)bitmap];
 
@@ -545,7 +592,7 @@ struct Walker {
             if (cl.line.a.x < -0.01f) { fail("Clipped line x < -0.01 (map_objects.rs:92-97)"); return; }
             if (m.sector < 0) continue;                               // "Thing is outside map"
             const SectorRec &sec = sc.sectors[(size_t)m.sector];
-            int16_t light = m.full_bright ? (int16_t)255 : sec.light;
+            int16_t light = m_full_bright ? (int16_t)255 : sector_light(m.sector);
 
             int16_t bh = (int16_t)bi.h;
             float bottom_height = (float)sec.floor_h - player_height;
@@ -679,7 +726,7 @@ struct Walker {
 
 }  // namespace
 
-int build_frame_lists(const Scene &sc, int W, int H, const dg_view &view, FrameArena &A, dg_frame_lists &out, std::string &err) {
+int build_frame_lists(const Scene &sc, int W, int H, const dg_view &view, FrameArena &A, dg_frame_lists &out, std::string &err, const dg_view_state *state) {
     if (W <= 0 || H <= 0 || W > 16384 || H > 16384) { err = "bad frame size"; return DG_ERR_INVALID; }
     A.renders.clear(); A.columns.clear(); A.visplanes.clear(); A.plane_tb.clear(); A.order.clear();
     A.recs->clear(); A.floor_tb.clear(); A.ceil_tb.clear();
@@ -689,7 +736,8 @@ int build_frame_lists(const Scene &sc, int W, int H, const dg_view &view, FrameA
     A.top_clip.resize((size_t)W);
     A.bottom_clip.resize((size_t)W);
 
-    Walker wk(sc, W, H, view, A, err);
+    Walker wk(sc, W, H, view, A, err, state);
+    if (wk.status) return wk.status;
     wk.walk_bsp();
     if (wk.status) return wk.status;
     // visplanes are drawn after all inline walls, in push order (mod.rs:122)
@@ -736,11 +784,12 @@ void bin_by_columns(const std::vector<T> &recs, int W, Range range, std::vector<
 }
 }  // namespace
 
-int build_frame_parts(const Scene &sc, int W, int H, const dg_view &view, FrameArena &A, std::string &err) {
+int build_frame_parts(const Scene &sc, int W, int H, const dg_view &view, FrameArena &A, std::string &err, const dg_view_state *state) {
     if (W <= 0 || H <= 0 || W > 16384 || H > 16384) { err = "bad frame size"; return DG_ERR_INVALID; }
     A.parts.clear(); A.sprites.clear(); A.behind.clear(); A.sky_parts.clear(); A.behind_words = 0; A.n_sky_slots = 0;
     A.recs->clear();
-    Walker wk(sc, W, H, view, A, err);
+    Walker wk(sc, W, H, view, A, err, state);
+    if (wk.status) return wk.status;
     wk.parts_mode = true;
     wk.walk_bsp();
     if (wk.status) return wk.status;

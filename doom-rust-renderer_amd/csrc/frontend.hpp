@@ -45,6 +45,7 @@ struct FrameArena {
     std::vector<int16_t> floor_tb, ceil_tb;
     std::vector<uint8_t> hor_ocl;
     std::vector<int16_t> floor_ocl, ceil_ocl, top_clip, bottom_clip;
+    std::vector<int32_t> light_ov, mobj_ov;     // per sector / per map object: this view's snapshot value or "no override" (Walker)
     FrameArena();
     ~FrameArena();
     FrameArena(const FrameArena &) = delete;
@@ -53,7 +54,9 @@ struct FrameArena {
 
 // Fills `arena` and `out` (pointers into arena).  Returns DG_OK or DG_ERR_RENDER with `err` set where the
 // reference would panic.  `view` must have its trig fields filled.
-int build_frame_lists(const Scene &sc, int W, int H, const dg_view &view, FrameArena &arena, dg_frame_lists &out, std::string &err);
+// `state` (optional): the view's game-state snapshot (include/doomgpu.h dg_view_state).
+int build_frame_lists(const Scene &sc, int W, int H, const dg_view &view, FrameArena &arena, dg_frame_lists &out, std::string &err,
+                      const dg_view_state *state = nullptr);
 
 void fill_view_trig(dg_view &v);
 
@@ -62,7 +65,7 @@ void fill_view_trig(dg_view &v);
 // Returns DG_OK, DG_ERR_RENDER (the reference would panic before any column is walked) or kPartsUnsupported (a case only the
 // host list path can judge: the caller redoes the frame with build_frame_lists).
 constexpr int kPartsUnsupported = 1000;
-int build_frame_parts(const Scene &sc, int W, int H, const dg_view &view, FrameArena &arena, std::string &err);
+int build_frame_parts(const Scene &sc, int W, int H, const dg_view &view, FrameArena &arena, std::string &err, const dg_view_state *state = nullptr);
 
 // Per-record constants of render_vertical_bitmap_line (bitmap_render.rs:233-251), shared by the binner and the parts builder.
 DevWallRec make_wall_rec(const BitmapInfo &bi, float lsx, float lsy, float lex, float ley, float start_offset, int32_t start_x, int32_t end_x,

@@ -74,6 +74,20 @@ typedef struct dg_view {
     int32_t trig_valid;  /* 0: the library fills the four trig fields with cosf/sinf */
 } dg_view;
 
+/* Game state of ONE view on top of the scene's: what the reference's thinkers changed before that frame was drawn — sector
+ * light levels (LightFlash / StrobeFlash / GlowingLight / FireFlicker, src/lights.rs:47-259) and map-object states
+ * (src/map_objects.rs:63-121).  Entries override the scene's value for that view only, so the frames of a recorded play-through
+ * can travel in one batch.  sprite_frame: dg_scene_sprite_frame(), or -1 for StateId::S_NULL (not drawn). */
+typedef struct dg_sector_light { int32_t sector; int32_t light_level; } dg_sector_light;
+typedef struct dg_mobj_state { int32_t mobj; int32_t sprite_frame; int32_t full_bright; int32_t reserved; } dg_mobj_state;
+typedef struct dg_view_state {
+    const dg_sector_light *lights; uint32_t n_lights;
+    const dg_mobj_state *mobjs;    uint32_t n_mobjs;
+} dg_view_state;
+/* Handle of (sprite, frame) for dg_mobj_state (Sprites::get_picture's first two arguments, src/graphics/sprites.rs:99-117);
+ * negative on error.  Like dg_scene_set_mobj_state it may decode new bitmaps: call it before dg_upload_scene. */
+int dg_scene_sprite_frame(dg_scene *s, const char *sprite, uint8_t frame);
+
 /* ---- context ------------------------------------------------------------------------------------------------ */
 typedef struct dg_config {
     int32_t device;        /* HIP device ordinal */
@@ -108,6 +122,9 @@ int dg_upload_scene(dg_ctx *ctx, const dg_scene *scene);
 int dg_render_views(dg_ctx *ctx, const dg_view *views, int n, uint8_t *rgb24_out);
 /* Asynchronous: build lists on the host (blocking), then enqueue H2D + kernels on the slot's stream. */
 int dg_submit_views(dg_ctx *ctx, int slot, const dg_view *views, int n);
+/* The same with a game-state snapshot per view (states[i] for views[i]; states == NULL: none). */
+int dg_submit_views_state(dg_ctx *ctx, int slot, const dg_view *views, const dg_view_state *states, int n);
+int dg_render_views_state(dg_ctx *ctx, const dg_view *views, const dg_view_state *states, int n, uint8_t *rgb24_out);
 int dg_wait(dg_ctx *ctx, int slot);
 /* Device address of the slot's framebuffer slab (frame i at + i*3*W*H). Valid until the slot is re-submitted. */
 int dg_slot_framebuffer(dg_ctx *ctx, int slot, void **device_ptr);

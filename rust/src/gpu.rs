@@ -1,0 +1,92 @@
+//! gpu.rs — FFI binding of libdoomgpu (include/doomgpu.h) for freewilll/doom-rust-renderer.
+//!
+//! Drop this file into the reference crate as `src/renderer/gpu.rs`, add `pub mod gpu;` to `src/renderer/mod.rs`, put
+//! `rust/build.rs` next to the crate's Cargo.toml and apply the three edits to `src/game.rs` described in rust/README.md.
+//! UNBUILT in this repository: the build image has no rustc / cargo.  The C++ mirror of the same interface
+//! (doom-rust-renderer_amd/csrc/doomgpu.hpp) and the ctypes binding are the ones the test tiers execute.
+#![allow(non_camel_case_types)]
+use std::ffi::{c_char, c_int, c_void, CStr, CString};
+
+#[repr(C)] pub struct dg_scene { _p: [u8; 0] }
+#[repr(C)] pub struct dg_ctx   { _p: [u8; 0] }
+
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct dg_view {                       // Player (src/game.rs:40-45) + Renderer::new's timestamp
+    pub x: f32, pub y: f32, pub angle: f32, pub floor_height: f32,
+    pub cos_a: f32, pub sin_a: f32, pub cos_na: f32, pub sin_na: f32,
+    pub timestamp: f32, pub trig_valid: i32,
+}
+#[repr(C)]
+pub struct dg_config { pub device: i32, pub width: i32, pub height: i32, pub max_batch: i32, pub slots: i32, pub host_threads: i32, pub front_end: i32 }
+
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct dg_bitmap_column { pub x: i16, pub clipped_top_y: i16, pub clipped_bottom_y: i16, pub bottom_y: i16, pub top_y: i16 } // bitmap_render.rs:19-25
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct dg_bitmap_render {              // bitmap_render.rs:29-45
+    pub bitmap: i32, pub light_level: i16, pub offset_x: i16, pub offset_y: i16, pub reserved: i16,
+    pub line_start_x: f32, pub line_start_y: f32, pub line_end_x: f32, pub line_end_y: f32, pub start_offset: f32,
+    pub start_x: i32, pub end_x: i32, pub bottom_height: f32, pub top_height: f32,
+    pub first_column: u32, pub n_columns: u32,
+}
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct dg_visplane { pub flat: i32, pub height: i16, pub light_level: i16, pub left: i16, pub right: i16, pub first_entry: u32 } // visplanes.rs:17-26
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct dg_draw_cmd { pub kind: u32, pub index: u32 }
+#[repr(C)]
+pub struct dg_frame_lists {
+    pub view: dg_view,
+    pub renders: *const dg_bitmap_render, pub n_renders: u32,
+    pub columns: *const dg_bitmap_column, pub n_columns: u32,
+    pub visplanes: *const dg_visplane,    pub n_visplanes: u32,
+    pub plane_tb: *const i16,             pub n_plane_tb: u32,
+    pub order: *const dg_draw_cmd,        pub n_order: u32,
+}
+
+extern "C" {
+    pub fn dg_scene_load_wad(wad: *const u8, len: usize, map_name: *const c_char, out: *mut *mut dg_scene) -> c_int;
+    pub fn dg_scene_free(s: *mut dg_scene);
+    pub fn dg_scene_player_start(s: *const dg_scene, x: *mut f32, y: *mut f32, angle: *mut f32) -> c_int;
+    pub fn dg_scene_floor_height_at(s: *const dg_scene, x: f32, y: f32, h: *mut f32) -> c_int;
+    pub fn dg_scene_set_sector_light(s: *mut dg_scene, sector: c_int, light: i16) -> c_int;
+    pub fn dg_scene_set_mobj_state(s: *mut dg_scene, mobj: c_int, sprite: *const c_char, frame: u8, full_bright: c_int) -> c_int;
+    pub fn dg_scene_texture_id(s: *const dg_scene, name: *const c_char) -> c_int;
+    pub fn dg_scene_flat_id(s: *const dg_scene, name: *const c_char, timestamp: f32) -> c_int;
+    pub fn dg_scene_sprite_bitmap_id(s: *const dg_scene, sprite: *const c_char, frame: u8, rotation: u8) -> c_int;
+    pub fn dg_create(cfg: *const dg_config, out: *mut *mut dg_ctx) -> c_int;
+    pub fn dg_destroy(ctx: *mut dg_ctx);
+    pub fn dg_upload_scene(ctx: *mut dg_ctx, scene: *const dg_scene) -> c_int;
+    pub fn dg_render_views(ctx: *mut dg_ctx, views: *const dg_view, n: c_int, rgb24_out: *mut u8) -> c_int;
+    pub fn dg_draw_lists(ctx: *mut dg_ctx, slot: c_int, frames: *const dg_frame_lists, n: c_int, rgb24_out: *mut u8) -> c_int;
+    pub fn dg_frame_checksums(ctx: *mut dg_ctx, slot: c_int, first: c_int, count: c_int, out: *mut u64) -> c_int;
+    pub fn dg_last_error() -> *const c_char;
+}
+
+/// Drop-in for `Renderer`: same life cycle as src/renderer/mod.rs:37-58,118-136 (built per frame, borrows Pixels).
+pub struct GpuRenderer<'a> { ctx: *mut dg_ctx, pixels: &'a mut super::Pixels, view: dg_view }
+
+impl<'a> GpuRenderer<'a> {
+    pub fn new(ctx: *mut dg_ctx, pixels: &'a mut super::Pixels, player: &crate::game::Player, timestamp: f32) -> Self {
+        let a = player.angle;
+        GpuRenderer { ctx, pixels, view: dg_view {
+            x: player.position.x, y: player.position.y, angle: a, floor_height: player.floor_height,
+            cos_a: a.cos(), sin_a: a.sin(), cos_na: (-a).cos(), sin_na: (-a).sin(),   // what Vertex::rotate computes (vertexes.rs:20-25)
+            timestamp, trig_valid: 1 } }
+    }
+    pub fn render(&mut self) {
+        let rc = unsafe { dg_render_views(self.ctx, &self.view, 1, self.pixels.pixels.as_mut_ptr()) };
+        if rc != 0 { panic!("doomgpu: {}", unsafe { CStr::from_ptr(dg_last_error()) }.to_string_lossy()); }  // the reference panics too
+    }
+}
+
+// ---- per-view game state (include/doomgpu.h dg_view_state): what the thinkers changed before a frame ------------------
+#[repr(C)] #[derive(Clone, Copy)] pub struct dg_sector_light { pub sector: i32, pub light_level: i32 }
+#[repr(C)] #[derive(Clone, Copy)] pub struct dg_mobj_state { pub mobj: i32, pub sprite_frame: i32, pub full_bright: i32, pub reserved: i32 }
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct dg_view_state { pub lights: *const dg_sector_light, pub n_lights: u32, pub mobjs: *const dg_mobj_state, pub n_mobjs: u32 }
+extern "C" {
+    pub fn dg_scene_sprite_frame(s: *mut dg_scene, sprite: *const c_char, frame: u8) -> c_int;
+    pub fn dg_render_views_state(ctx: *mut dg_ctx, views: *const dg_view, states: *const dg_view_state, n: c_int, rgb24_out: *mut u8) -> c_int;
+    pub fn dg_submit_views_state(ctx: *mut dg_ctx, slot: c_int, views: *const dg_view, states: *const dg_view_state, n: c_int) -> c_int;
+    pub fn dg_wait(ctx: *mut dg_ctx, slot: c_int) -> c_int;
+    pub fn dg_readback_async(ctx: *mut dg_ctx, slot: c_int, first: c_int, count: c_int, rgb24_out: *mut u8) -> c_int;
+}

@@ -176,15 +176,25 @@ int emul_set_mobj_state(void *s, int mobj, const char *sprite, uint8_t frame, in
     return 0;
 }
 
+int emul_sprite_frame(void *s, const char *sprite, uint8_t frame) { return ((Scene *)s)->find_or_add_sprite_frame(sprite, frame, g_err); }
+
+static int emul_render_impl(void *scene, int W, int H, const dg_view *view_in, const dg_view_state *state, uint8_t *rgb, uint64_t *stats);
 // stats[0..3] = spans, walls, planes, covered pixels
-int emul_render(void *scene, int W, int H, const dg_view *view_in, uint8_t *rgb, uint64_t *stats) {
+int emul_render(void *scene, int W, int H, const dg_view *view_in, uint8_t *rgb, uint64_t *stats) { return emul_render_impl(scene, W, H, view_in, nullptr, rgb, stats); }
+// the same with a per-view game-state snapshot (include/doomgpu.h dg_view_state)
+int emul_render_state(void *scene, int W, int H, const dg_view *view_in, const dg_sector_light *lights, uint32_t n_lights, const dg_mobj_state *mobjs,
+                      uint32_t n_mobjs, uint8_t *rgb) {
+    const dg_view_state st{lights, n_lights, mobjs, n_mobjs};
+    return emul_render_impl(scene, W, H, view_in, &st, rgb, nullptr);
+}
+static int emul_render_impl(void *scene, int W, int H, const dg_view *view_in, const dg_view_state *state, uint8_t *rgb, uint64_t *stats) {
     const Scene &sc = *(const Scene *)scene;
     dg_view view = *view_in;
     fill_view_trig(view);
     static thread_local FrameArena arena;
     static thread_local BinnedFrame bf;
     dg_frame_lists fl;
-    int rc = build_frame_lists(sc, W, H, view, arena, fl, g_err);
+    int rc = build_frame_lists(sc, W, H, view, arena, fl, g_err, state);
     if (rc) return rc;
     FrameConsts fk = make_consts(W, H);
     rc = bin_frame(sc, fk, fl, bf, g_err);

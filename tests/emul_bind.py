@@ -26,6 +26,9 @@ def lib():
         L.emul_last_error.restype = ctypes.c_char_p
         L.emul_render.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(DgView), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
         L.emul_render_fe.argtypes = L.emul_render.argtypes
+        L.emul_render_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(DgView), ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                                        ctypes.c_uint32, ctypes.c_void_p]
+        L.emul_sprite_frame.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint8]
         L.emul_set_sector_light.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int16]
         L.emul_set_mobj_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint8, ctypes.c_int]
         _lib = L
@@ -54,6 +57,24 @@ class EmulScene:
         if rc:
             raise RuntimeError(f"emul rc {rc}: {lib().emul_last_error().decode()}")
         return buf.tobytes(), list(st)
+
+    def sprite_frame(self, sprite, frame=0):
+        sf = lib().emul_sprite_frame(self._h, sprite.encode(), frame)
+        if sf < 0:
+            raise RuntimeError(lib().emul_last_error().decode())
+        return sf
+
+    def render_state(self, W, H, rec, lights, mobjs, timestamp=0.0):
+        """One view with a game-state snapshot: lights = [(sector, level)], mobjs = [(mobj, sprite_frame or -1, full_bright)]."""
+        v = DgView(float(rec[0]), float(rec[1]), float(rec[2]), float(rec[7]), float(rec[3]), float(rec[4]), float(rec[5]), float(rec[6]),
+                   float(timestamp), 1)
+        la = np.array([[s, l] for s, l in lights], dtype=np.int32).reshape(-1, 2)
+        ma = np.array([[m, sf, fb, 0] for m, sf, fb in mobjs], dtype=np.int32).reshape(-1, 4)
+        buf = np.empty(3 * W * H, dtype=np.uint8)
+        rc = lib().emul_render_state(self._h, W, H, ctypes.byref(v), la.ctypes.data, len(la), ma.ctypes.data, len(ma), buf.ctypes.data)
+        if rc:
+            raise RuntimeError(f"emul rc {rc}: {lib().emul_last_error().decode()}")
+        return buf.tobytes()
 
     def render_fe(self, W, H, rec, timestamp=0.0):
         """Same frame through the device column walk's bodies (fe_core.h) on the CPU.  stats = [spans, parts, sprites, overflow

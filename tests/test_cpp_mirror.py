@@ -4,6 +4,9 @@ import os
 import subprocess
 import sys
 
+import numpy as np
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SRC = r'''
@@ -47,3 +50,57 @@ def test_cpp_mirror_compiles_and_pixels_semantics(tmp_path):
                            os.path.join(ROOT, "doom-rust-renderer_amd", "libdoomgpu.so"), "-Wl,-rpath," + os.path.join(ROOT, "doom-rust-renderer_amd")])
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
     assert out.strip() == "ok"
+
+
+RENDER_SRC = r'''
+// What a C++ caller of the mirror does, shaped like Game::render (src/game.rs:505-519): a fresh Pixels and a Renderer per frame.
+#include "doom-rust-renderer_amd/csrc/doomgpu.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iterator>
+int main(int argc, char **argv) {
+    if (argc < 6) return 2;
+    std::ifstream f(argv[1], std::ios::binary);
+    std::vector<uint8_t> wad((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    const int W = std::atoi(argv[2]), H = std::atoi(argv[3]);
+    try {
+        doom::World world(wad, "e1m1");
+        doom::Device dev(W, H);
+        dev.upload(world);
+        std::FILE *out = std::fopen(argv[4], "wb"), *log = std::fopen(argv[5], "w");
+        doom::Player players[2] = {world.player_start(), world.player_start()};
+        players[1].angle += 0.7f;                               // a second frame, other heading (the game loop's next tick)
+        for (const doom::Player &pl : players) {
+            doom::Pixels pixels(W, H);                          // Pixels::new(): a fresh zeroed buffer per frame (pixels.rs:10-14)
+            doom::Renderer(pixels, world, pl, 0.0f, dev).render();
+            std::fwrite(pixels.pixels.data(), 1, pixels.pixels.size(), out);
+            std::fprintf(log, "%a %a %a %a\n", pl.position.x, pl.position.y, pl.angle, pl.floor_height);
+        }
+        std::fclose(out); std::fclose(log);
+    } catch (const doom::Error &e) { std::fprintf(stderr, "doom::Error %d: %s\n", e.code, e.what()); return 1; }
+    return 0;
+}
+'''
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_renders_on_the_gpu(tmp_path, wad1993, oracle_scene1993, campath_mod):
+    """doom::Renderer(pixels, world, player, timestamp, device).render() — the C++ spelling of src/game.rs:505-519 — executed on
+    the GPU; `pixels.pixels` must equal the oracle's frame for the same Player (trig evaluated by the caller, trig_valid = 1)."""
+    W, H = 320, 200
+    (tmp_path / "render.cpp").write_text(RENDER_SRC)
+    (tmp_path / "synth.wad").write_bytes(wad1993)
+    exe = tmp_path / "render"
+    lib = os.path.join(ROOT, "doom-rust-renderer_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", ROOT, str(tmp_path / "render.cpp"), "-o", str(exe), os.path.join(lib, "libdoomgpu.so"), "-Wl,-rpath," + lib])
+    r = subprocess.run([str(exe), str(tmp_path / "synth.wad"), str(W), str(H), str(tmp_path / "frames.rgb"), str(tmp_path / "players.txt")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    frames = np.fromfile(tmp_path / "frames.rgb", dtype=np.uint8).reshape(2, H, W, 3)
+    players = [[float.fromhex(t) for t in l.split()] for l in open(tmp_path / "players.txt")]
+    assert len(players) == 2 and frames[0].any()
+    for k, (x, y, a, fh) in enumerate(players):
+        rec = campath_mod.view_record(np.float32(x), np.float32(y), np.float32(a), np.float32(fh))
+        ref = np.frombuffer(oracle_scene1993.render(W, H, rec), dtype=np.uint8).reshape(H, W, 3)
+        assert np.array_equal(frames[k], ref), f"frame {k}"

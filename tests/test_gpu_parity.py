@@ -581,3 +581,42 @@ def test_async_readback_overlaps_and_matches(dg, scene1993, path1993):
     for b in bufs:
         dg.lib().dg_free_host(b)
     ctx.close()
+
+
+@pytest.mark.parametrize("front_end", [1, 2], ids=["host-lists", "device-column-walk"])
+def test_per_view_game_state_in_one_batch(dg, oracle, wad1993, path1993, front_end):
+    """F4 / dg_view_state: every frame of a batch carries its own light levels and map-object states, as a recorded play-through
+    would (src/lights.rs:47-259, src/map_objects.rs:63-121); each frame equals the oracle after the same changes to its scene."""
+    sc = dg.Scene(wad1993, "e1m1")
+    names = [None, "BAR1", "POSS", "TROO", "COLU", "TRED"]
+    handles = {n: sc.sprite_frame(n, 0) for n in names if n}
+    W, H = 320, 200
+    idx = list(range(0, 1000, 25))
+    rng = np.random.default_rng(99)
+    states, refs = [], []
+    for i in idx:
+        osc = oracle.Scene(wad1993, "e1m1")
+        lights, mobjs = [], []
+        for s in rng.choice(osc.sector_count(), size=osc.sector_count() // 3, replace=False):
+            lv = int(rng.choice([-20, 0, 40, 96, 200, 255, 300]))
+            lights.append((int(s), lv))
+            osc.set_sector_light(int(s), lv)
+        for m in rng.choice(osc.mobj_count(), size=osc.mobj_count() // 3, replace=False):
+            name = names[int(rng.integers(len(names)))]
+            fb = bool(rng.integers(2))
+            mobjs.append((int(m), -1 if name is None else handles[name], int(fb)))
+            osc.set_mobj_state(int(m), name, 0, fb)
+        states.append((lights, mobjs))
+        refs.append(np.frombuffer(osc.render(W, H, path1993[i]), dtype=np.uint8).reshape(H, W, 3))
+    ctx = make_ctx(dg, sc, W, H, len(idx), slots=2, front_end=front_end)      # upload after the sprite frames were registered
+    views = dg.make_views(path1993[idx])
+    st, keep = dg.make_view_states(states)
+    out = ctx.render_state(views, st)
+    for k, i in enumerate(idx):
+        assert np.array_equal(out[k], refs[k]), f"frame {i}"
+    plain = ctx.render(views)                                              # the scene itself is untouched
+    assert not np.array_equal(plain, out)
+    bad, keep2 = dg.make_view_states([([(10 ** 6, 1)], [])] + [([], [])] * (len(idx) - 1))
+    with pytest.raises(dg.DoomGpuError):
+        ctx.render_state(views, bad)
+    ctx.close()

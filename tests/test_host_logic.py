@@ -197,3 +197,34 @@ def test_device_column_walk_edge_views(synth, campath_mod):
             continue
         got, st = es.render_fe(W, H, rec, 0.4)
         assert st[3] == 0 and st[4] == 1 and got == ref, (j, W, H, st)
+
+
+def test_per_view_state_equals_scene_state(synth, oracle, path1993):
+    """F4 / dg_view_state: a view's snapshot (light levels, map-object states) overrides the scene for that view only and yields
+    exactly the frame the oracle draws after the same changes were made to its scene (src/lights.rs, src/map_objects.rs:63-121)."""
+    wad = synth.build_synth_iwad(1993)
+    es = emul_bind.EmulScene(wad)
+    handles = {name: es.sprite_frame(name, 0) for name in ("BAR1", "POSS", "TROO", "COLU", "TRED")}
+    rng = np.random.default_rng(7)
+    W, H = 160, 100
+    base = {i: es.render(W, H, path1993[i])[0] for i in (10, 400, 770)}
+    changed = 0
+    for i in (10, 400, 770):
+        osc = oracle.Scene(wad, "e1m1")                      # a fresh oracle scene per view: snapshots are not cumulative
+        lights, mobjs = [], []
+        for s in rng.choice(osc.sector_count(), size=osc.sector_count() // 2, replace=False):
+            lv = int(rng.choice([-20, 0, 40, 96, 200, 255, 300]))
+            lights.append((int(s), lv))
+            osc.set_sector_light(int(s), lv)
+        for m in rng.choice(osc.mobj_count(), size=osc.mobj_count() // 2, replace=False):
+            name = [None, "BAR1", "POSS", "TROO", "COLU", "TRED"][int(rng.integers(6))]
+            fb = bool(rng.integers(2))
+            mobjs.append((int(m), -1 if name is None else handles[name], int(fb)))
+            osc.set_mobj_state(int(m), name, 0, fb)
+        got = es.render_state(W, H, path1993[i], lights, mobjs)
+        assert got == osc.render(W, H, path1993[i]), f"view {i}"
+        changed += got != base[i]
+        assert es.render(W, H, path1993[i])[0] == base[i]    # the scene itself is untouched
+    assert changed >= 2                                      # the snapshots really changed what these views show
+    with pytest.raises(RuntimeError):
+        es.render_state(W, H, path1993[10], [(10 ** 6, 5)], [])
