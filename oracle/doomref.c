@@ -1362,3 +1362,60 @@ int dr_render(dr_scene *s, int W, int H, const dr_view *view_in, uint8_t *rgb, i
     g_stats = r.st;
     return r.err ? -1 : 0;
 }
+
+/* ---- list-level replay (KATs) --------------------------------------------------------------------------------------------
+ * The draw calls of one frame, given by the caller in the order Renderer::render issues them, through the SAME pixel functions
+ * dr_render uses (render_vertical_bitmap_line, draw_visplane / draw_sky, px_set).  Lets a test aim hand-built records at the
+ * edge cases of SURVEY.md Appendix A (vy == 0, bottom_y == top_y, uz0 == 0, saturated extents, x >= W) without having to find
+ * a map and a viewpoint that produce them. */
+int dr_draw_lists(dr_scene *s, int W, int H, const dr_view *view_in, const dr_list_render *renders, int n_renders, const dr_list_column *columns,
+                  const dr_list_visplane *visplanes, int n_visplanes, const int16_t *plane_tb, const uint32_t *order, int n_order, uint8_t *rgb) {
+    g_err[0] = 0;
+    if (W <= 0 || H <= 0 || W > 32767 || H > 32767) return fail("bad frame size");
+    dr_view view = *view_in;
+    if (!view.trig_valid) {
+        view.cos_a = cosf(view.angle); view.sin_a = sinf(view.angle);
+        view.cos_na = cosf(-view.angle); view.sin_na = sinf(-view.angle);
+    }
+    R r;
+    memset(&r, 0, sizeof r);
+    r.s = s; r.W = W; r.H = H; r.k = make_consts(W, H); r.view = &view; r.pix = rgb;
+    r.ppos.x = view.x; r.ppos.y = view.y;
+    memset(rgb, 0, (size_t)3 * (size_t)W * (size_t)H);                       /* Pixels::new pixels.rs:10-14 */
+    int16_t *top = (int16_t *)calloc((size_t)W, 2), *bottom = (int16_t *)calloc((size_t)W, 2);
+    for (int i = 0; i < n_order && !r.err; i++) {
+        const uint32_t kind = order[2 * i], idx = order[2 * i + 1];
+        if (kind == 0) {
+            if ((int)idx >= n_renders) { r.err = fail("order references a missing render"); break; }
+            const dr_list_render *br = &renders[idx];
+            TexDef *t = get_texture(s, br->texture);
+            if (!t) { r.err = -1; break; }
+            ClippedLine cl;
+            cl.line.start.x = br->line_start_x; cl.line.start.y = br->line_start_y; cl.line.end.x = br->line_end_x; cl.line.end.y = br->line_end_y;
+            cl.start_offset = br->start_offset;
+            for (uint32_t c = 0; c < br->n_columns && !r.err; c++) {          /* BitmapRender::render bitmap_render.rs:101-135 */
+                const dr_list_column *col = &columns[br->first_column + c];
+                render_vertical_bitmap_line(&r, &t->bm, br->light_level, &cl, br->start_x, br->end_x, br->bottom_height, br->top_height,
+                                            br->offset_x, br->offset_y, col->x, col->clipped_bottom_y, col->clipped_top_y, col->bottom_y, col->top_y);
+            }
+        } else {
+            if ((int)idx >= n_visplanes) { r.err = fail("order references a missing visplane"); break; }
+            const dr_list_visplane *lp = &visplanes[idx];
+            Flat *f = get_flat(s, lp->flat);
+            if (!f) { r.err = -1; break; }
+            if (lp->left < 0 || lp->right >= W || lp->right < lp->left) { r.err = fail("visplane x range"); break; }
+            Visplane vp;
+            vp.flat = f; vp.height = lp->height; vp.light_level = lp->light_level; vp.left = lp->left; vp.right = lp->right;
+            vp.top = top; vp.bottom = bottom;
+            memset(top, 0, (size_t)W * 2); memset(bottom, 0, (size_t)W * 2);   /* Visplane::new visplanes.rs:28-40 */
+            for (int x = lp->left; x <= lp->right; x++) {
+                top[x] = plane_tb[2 * ((size_t)lp->first_entry + (size_t)(x - lp->left))];
+                bottom[x] = plane_tb[2 * ((size_t)lp->first_entry + (size_t)(x - lp->left)) + 1];
+            }
+            draw_visplane(&r, &vp);
+        }
+    }
+    free(top); free(bottom);
+    return r.err ? -1 : 0;
+}
+

@@ -55,6 +55,22 @@ int dr_set_mobj_state(dr_scene *s, int mobj, const char *sprite, uint8_t frame, 
  * Returns 0, or -1 where the reference would panic. */
 int dr_render(dr_scene *s, int W, int H, const dr_view *view, uint8_t *rgb, int flags);
 
+/* List-level replay for KATs: the caller's BitmapRender / BitmapColumn / Visplane records (bitmap_render.rs:19-45,
+ * visplanes.rs:17-26) in draw order through the oracle's own pixel functions.  order = n_order pairs (kind, index): kind 0 = replay
+ * render `index` (all its columns), kind 1 = draw visplane `index`.  plane_tb = (top, bottom) pairs for [left, right]. */
+typedef struct dr_list_column { int32_t x, clipped_top_y, clipped_bottom_y, bottom_y, top_y; } dr_list_column;
+typedef struct dr_list_render {
+    const char *texture;                 /* Textures::get name */
+    int16_t light_level, offset_x, offset_y, reserved;
+    float line_start_x, line_start_y, line_end_x, line_end_y, start_offset;
+    int32_t start_x, end_x;
+    float bottom_height, top_height;
+    uint32_t first_column, n_columns;
+} dr_list_render;
+typedef struct dr_list_visplane { const char *flat; int16_t height, light_level, left, right; uint32_t first_entry; } dr_list_visplane;
+int dr_draw_lists(dr_scene *s, int W, int H, const dr_view *view, const dr_list_render *renders, int n_renders, const dr_list_column *columns,
+                  const dr_list_visplane *visplanes, int n_visplanes, const int16_t *plane_tb, const uint32_t *order, int n_order, uint8_t *rgb);
+
 /* Scalar entry points for KATs. */
 void dr_diminish_color(const uint8_t rgb_in[3], int16_t light_level, int16_t distance, uint8_t rgb_out[3]);
 int16_t dr_f32_as_i16(float f);

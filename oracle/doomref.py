@@ -15,6 +15,21 @@ class View(ctypes.Structure):
                [("trig_valid", ctypes.c_int32)]
 
 
+class ListColumn(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in "x clipped_top_y clipped_bottom_y bottom_y top_y".split()]
+
+
+class ListRender(ctypes.Structure):
+    _fields_ = [("texture", ctypes.c_char_p)] + [(n, ctypes.c_int16) for n in "light_level offset_x offset_y reserved".split()] + \
+               [(n, ctypes.c_float) for n in "line_start_x line_start_y line_end_x line_end_y start_offset".split()] + \
+               [("start_x", ctypes.c_int32), ("end_x", ctypes.c_int32), ("bottom_height", ctypes.c_float), ("top_height", ctypes.c_float),
+                ("first_column", ctypes.c_uint32), ("n_columns", ctypes.c_uint32)]
+
+
+class ListVisplane(ctypes.Structure):
+    _fields_ = [("flat", ctypes.c_char_p)] + [(n, ctypes.c_int16) for n in "height light_level left right".split()] + [("first_entry", ctypes.c_uint32)]
+
+
 class Stats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in "n_records n_columns n_visplanes n_mobj_records".split()] + \
                [(n, ctypes.c_int64) for n in "wall_pixels flat_pixels sky_pixels masked_pixels mobj_pixels".split()]
@@ -50,6 +65,9 @@ def lib():
         L.dr_f32_as_u8.argtypes = [ctypes.c_float]
         L.dr_constants.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.dr_last_stats.argtypes = [ctypes.POINTER(Stats)]
+        L.dr_draw_lists.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(View), ctypes.POINTER(ListRender), ctypes.c_int,
+                                    ctypes.POINTER(ListColumn), ctypes.POINTER(ListVisplane), ctypes.c_int, ctypes.POINTER(ctypes.c_int16),
+                                    ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_void_p]
         L.dr_sector_count.argtypes = [ctypes.c_void_p]
         L.dr_set_sector_light.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int16]
         L.dr_mobj_count.argtypes = [ctypes.c_void_p]
@@ -91,6 +109,29 @@ class Scene:
         if lib().dr_render(self._h, W, H, ctypes.byref(v), ptr, flags):
             raise OracleError(lib().dr_last_error().decode())
         return buf.raw if out is None else None
+
+    def draw_lists(self, W: int, H: int, view, lists: dict) -> bytes:
+        """Replay hand-built records (tests/np_mappers.py list dict) through the oracle's pixel functions -> bytes (3*W*H)."""
+        x, y, a, c, s, cn, sn, fh = [float(t) for t in view[:8]]
+        v = View(x, y, a, fh, c, s, cn, sn, 0.0, 1)
+        cols = (ListColumn * max(1, len(lists["columns"])))(*[ListColumn(*[int(t) for t in col]) for col in lists["columns"]])
+        rs = (ListRender * max(1, len(lists["renders"])))()
+        for i, r in enumerate(lists["renders"]):
+            rs[i] = ListRender(r["texture"].encode(), r["light_level"], r["offset_x"], r["offset_y"], 0, *[float(t) for t in r["line"]], float(r["start_offset"]),
+                               r["start_x"], r["end_x"], float(r["bottom_height"]), float(r["top_height"]), r["first_column"], r["n_columns"])
+        vs = (ListVisplane * max(1, len(lists["visplanes"])))()
+        tb = []
+        for i, p in enumerate(lists["visplanes"]):
+            vs[i] = ListVisplane(p["flat"].encode(), p["height"], p["light_level"], p["left"], p["right"], len(tb) // 2)
+            for (t, b) in p["tb"]:
+                tb += [t, b]
+        tba = (ctypes.c_int16 * max(1, len(tb)))(*tb)
+        order = (ctypes.c_uint32 * max(1, 2 * len(lists["order"])))(*[t for pair in lists["order"] for t in pair])
+        buf = ctypes.create_string_buffer(3 * W * H)
+        if lib().dr_draw_lists(self._h, W, H, ctypes.byref(v), rs, len(lists["renders"]), cols, vs, len(lists["visplanes"]), tba, order, len(lists["order"]),
+                               ctypes.cast(buf, ctypes.c_void_p)):
+            raise OracleError(lib().dr_last_error().decode())
+        return buf.raw
 
     def sector_count(self) -> int:
         return lib().dr_sector_count(self._h)
