@@ -189,6 +189,7 @@ class _Map:
         self.sidedefs: list[dict] = []
         self.sectors: list[dict] = []
         self.things: list[tuple[int, int, int, int, int]] = []
+        self.jitter = None
 
     def vertex(self, x: int, y: int) -> int:
         k = (int(x), int(y))
@@ -202,6 +203,8 @@ class _Map:
         return len(self.sidedefs) - 1
 
     def line(self, a, b, front: int, back: int = -1, flags: int = 0) -> int:
+        if self.jitter is not None:  # vanilla-shaped maps: every lattice point moves to an arbitrary integer nearby
+            a, b = self.jitter(*a), self.jitter(*b)
         self.linedefs.append(dict(v1=self.vertex(*a), v2=self.vertex(*b), flags=flags, front=front, back=back))
         return len(self.linedefs) - 1
 
@@ -213,9 +216,10 @@ def _cross(ax, ay, bx, by):
 class _BspBuilder:
     """Segs: dict(v1,v2 (coords), linedef, direction, offset, sector)."""
 
-    def __init__(self, m: _Map, rng: XorShift32):
+    def __init__(self, m: _Map, rng: XorShift32, round_splits: bool = False):
         self.m = m
         self.rng = rng
+        self.round_splits = round_splits  # vanilla node builders round split vertices to the integer VERTEXES grid
         self.segs_out: list[dict] = []
         self.ssectors: list[tuple[int, int]] = []
         self.nodes: list[dict] = []
@@ -229,7 +233,23 @@ class _BspBuilder:
         px, py, dx, dy = part
         a = self._side(px, py, dx, dy, *seg["a"])
         b = self._side(px, py, dx, dy, *seg["b"])
+        if self.round_splits and ((a > 0 and b < 0) or (a < 0 and b > 0)):
+            # a crossing whose rounded split point lands on an end point is no crossing: the seg goes to the other end's side
+            ip = self._split_point(part, seg)
+            if ip == seg["a"]:
+                a = 0
+            elif ip == seg["b"]:
+                b = 0
         return a, b
+
+    @staticmethod
+    def _split_point(part, seg):
+        px, py, dx, dy = part
+        ax, ay = seg["a"]
+        sx, sy = seg["b"][0] - ax, seg["b"][1] - ay
+        t = Fraction(_cross(dx, dy, px - ax, py - ay), _cross(dx, dy, sx, sy))  # point = a + t * s
+        fx, fy = ax + t * sx, ay + t * sy
+        return (int((2 * fx + 1) // 2), int((2 * fy + 1) // 2))  # round half up, exactly
 
     def _convex(self, segs) -> bool:
         sec = segs[0]["sector"]
@@ -292,7 +312,10 @@ class _BspBuilder:
         den = _cross(dx, dy, sx, sy)
         t = Fraction(_cross(dx, dy, px - ax, py - ay), den)  # point = a + t * s
         ix, iy = ax + t * sx, ay + t * sy
-        assert ix.denominator == 1 and iy.denominator == 1, "non-integer BSP split"
+        if self.round_splits:
+            ix, iy = self._split_point(part, seg)
+        else:
+            assert ix.denominator == 1 and iy.denominator == 1, "non-integer BSP split"
         ix, iy = int(ix), int(iy)
         first = dict(seg, b=(ix, iy))
         ln = round(((ix - ax) ** 2 + (iy - ay) ** 2) ** 0.5)
@@ -355,7 +378,13 @@ SPRITE_DEFS = [(2035, "BAR1", False, 23, 32), (2028, "COLU", False, 19, 47), (48
                (3004, "POSS", True, 41, 56), (3001, "TROO", True, 43, 57)]
 
 
-def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M1", quirks: bool = False) -> bytes:
+def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M1", quirks: bool = False,
+                     vanilla: bool = False) -> bytes:
+    """`vanilla` (used with seed 1995) bends the lattice map towards what real IWAD maps hold: every vertex moved to an arbitrary
+    integer position (so walls run at arbitrary angles and BSP split points are rounded onto the integer grid like a node
+    builder's), chamfers with unequal legs, irregular pillars, closed doors (door sector ceiling == floor, segs.rs:222-225),
+    thing angles in 1 degree steps and wall textures whose patches start above/left of the texture or run past its bottom.
+    The default maps do not consume any of the extra random numbers and stay byte-identical."""
     rng = XorShift32(seed)
     gx, gy = (16, 12) if heavy else (8, 6)
     sky_pct = 50 if heavy else 25
@@ -405,6 +434,17 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
         ("GRATE1", 64, 128, [(0, 0, p["GRT1"])]),                        # masked middle texture
         ("SKY1", 256, 128, [(64 * i, 0, p["SKY%d" % i]) for i in range(4)]),
     ]
+    wall_textures = list(WALL_TEXTURES)
+    if vanilla:
+        texdefs += [
+            # a 128-tall patch hung 100 rows above a 64-tall texture, a second one starting left of it and running past the bottom
+            ("VANT1", 64, 64, [(0, -100, p["BRK1"]), (-40, 24, p["STN2"])]),
+            # patch taller than the texture from a negative origin + one that only touches the last column / last rows
+            ("VANT2", 128, 96, [(-8, -16, p["STN1"]), (127, 90, p["MTL2"]), (40, -60, p["GRT1"])]),
+            # non-power-of-two width, patch origins that leave uncovered (None) columns at the right
+            ("VANT3", 72, 128, [(-32, 0, p["PNL1"]), (32, 64, p["MTL2"])]),
+        ]
+        wall_textures += ["VANT1", "VANT2", "VANT3"]
     pnames = struct.pack("<I", len(patches)) + b"".join(_name8(n) for n, _ in patches)
     tex_blobs = []
     for name, w, h, pl in texdefs:
@@ -453,6 +493,14 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
 
     # ---- map ----
     m = _Map()
+    if vanilla:
+        def jitter(x, y, _seed=seed):
+            h = (x * 73856093 ^ y * 19349663 ^ _seed * 83492791) & 0xFFFFFFFF
+            h = (h ^ (h >> 15)) * 0x2C1B3C6D & 0xFFFFFFFF
+            h = (h ^ (h >> 12)) * 0x297A2D39 & 0xFFFFFFFF
+            h ^= h >> 15
+            return (x + h % 11 - 5, y + (h >> 8) % 11 - 5)
+        m.jitter = jitter
     rooms = {}
     for j in range(gy):
         for i in range(gx):
@@ -468,6 +516,9 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
             m.sectors.append(dict(floor=floor, ceil=ceil, ffl=rng.choice(FLOOR_FLATS), cfl="F_SKY1" if sky else rng.choice(CEIL_FLATS),
                                   light=light, special=0, tag=0))
             chamfer = [64 if rng.chance(1, 3) else 0 for _ in range(4)]  # corners: (x0,y0) (x0,y1) (x1,y1) (x1,y0)
+            chamfer = [(c, c) for c in chamfer]                           # legs along x and along y
+            if vanilla:
+                chamfer = [(16 * (2 + rng.below(4)), 16 * (2 + rng.below(4))) if rng.chance(1, 2) else (0, 0) for _ in range(4)]
             rooms[(i, j)] = dict(x0=x0, x1=x1, y0=y0, y1=y1, sec=sec, chamfer=chamfer, doors={}, sky=sky,
                                  cx=i * CELL + CELL // 2, cy=j * CELL + CELL // 2)
 
@@ -501,7 +552,7 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
         elif rng.chance(35, 100):
             extra_edges.append((a, b))
 
-    wall_tex = lambda: rng.choice(WALL_TEXTURES)  # noqa: E731
+    wall_tex = lambda: rng.choice(wall_textures)  # noqa: E731
     doors = []
     for a, b in tree_edges + extra_edges:
         ra, rb = rooms[a], rooms[b]
@@ -511,6 +562,8 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
         ceil = min(sa["ceil"], sb["ceil"]) - rng.choice([0, 8, 16, 32])
         if ceil < floor + 64:
             ceil = floor + 64
+        if vanilla and (a, b) in extra_edges and rng.chance(1, 2):
+            ceil = floor                    # a closed door: its sector has no height (the route never passes through one)
         both_sky = ra["sky"] and rb["sky"]
         sec = len(m.sectors)
         m.sectors.append(dict(floor=floor, ceil=ceil, ffl=rng.choice(FLOOR_FLATS), cfl="F_SKY1" if both_sky else rng.choice(CEIL_FLATS),
@@ -540,17 +593,17 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
 
     for (i, j), r in rooms.items():
         x0, x1, y0, y1, sec = r["x0"], r["x1"], r["y0"], r["y1"], r["sec"]
-        c00, c01, c11, c10 = r["chamfer"]
+        (c00x, c00), (c01x, c01), (c11x, c11), (c10x, c10) = r["chamfer"]
         cx, cy = r["cx"], r["cy"]
         # clockwise boundary (interior on the right of each line), y up: W side up, N side right, E side down, S side left
         sides = [
             ("W", (x0, y0 + c00), (x0, y1 - c01), "y", cy),
-            ("N", (x0 + c01, y1), (x1 - c11, y1), "x", cx),
+            ("N", (x0 + c01x, y1), (x1 - c11x, y1), "x", cx),
             ("E", (x1, y1 - c11), (x1, y0 + c10), "y", cy),
-            ("S", (x1 - c10, y0), (x0 + c00, y0), "x", cx),
+            ("S", (x1 - c10x, y0), (x0 + c00x, y0), "x", cx),
         ]
-        corners = [((x0 + c00, y0), (x0, y0 + c00), c00), ((x0, y1 - c01), (x0 + c01, y1), c01),
-                   ((x1 - c11, y1), (x1, y1 - c11), c11), ((x1, y0 + c10), (x1 - c10, y0), c10)]
+        corners = [((x0 + c00x, y0), (x0, y0 + c00), c00), ((x0, y1 - c01), (x0 + c01x, y1), c01),
+                   ((x1 - c11x, y1), (x1, y1 - c11), c11), ((x1, y0 + c10), (x1 - c10x, y0), c10)]
         for k, (side, pa, pb, axis, centre) in enumerate(sides):
             ca, cb, cs = corners[k]
             if cs:
@@ -572,7 +625,11 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
         for (ox, oy) in ((-96, -96), (96, 96), (-96, 96), (96, -96)):
             if rng.chance(1, 5):
                 px, py, h = cx + ox, cy + oy, 16
-                if rng.chance(1, 2):
+                if vanilla:  # irregular convex quad: bottom, right, top, left (counter-clockwise)
+                    rr = [14 + rng.below(18) for _ in range(4)]
+                    ee = [rng.below(13) - 6 for _ in range(4)]
+                    pts = [(px + ee[0], py - rr[0]), (px + rr[1], py + ee[1]), (px + ee[2], py + rr[2]), (px - rr[3], py + ee[3])]
+                elif rng.chance(1, 2):
                     pts = [(px - h, py - h), (px + h, py - h), (px + h, py + h), (px - h, py + h)]
                 else:  # diamond
                     pts = [(px, py - 2 * h), (px + 2 * h, py), (px, py + 2 * h), (px - 2 * h, py)]
@@ -600,7 +657,7 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
         num = rng.choice(SPRITE_DEFS)[0]
         ox = rng.choice([-64, -48, -32, 32, 48, 64])
         oy = rng.choice([-64, -48, -32, 32, 48, 64])
-        m.things.append((r["cx"] + ox, r["cy"] + oy, 45 * rng.below(8), num, 7))
+        m.things.append((r["cx"] + ox, r["cy"] + oy, rng.below(360) if vanilla else 45 * rng.below(8), num, 7))
 
     # ---- BSP ----
     segs = []
@@ -609,7 +666,7 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
         segs.append(dict(a=a, b=b, linedef=li, direction=0, offset=0, sector=m.sidedefs[ld["front"]]["sector"]))
         if ld["back"] >= 0:
             segs.append(dict(a=b, b=a, linedef=li, direction=1, offset=0, sector=m.sidedefs[ld["back"]]["sector"]))
-    bsp = _BspBuilder(m, rng)
+    bsp = _BspBuilder(m, rng, round_splits=vanilla)
     root = bsp.build(segs)
     assert not (root & 0x8000) and root == len(bsp.nodes) - 1
 
@@ -693,23 +750,23 @@ def _apply_quirks(lumps, p, patches, map_marker):
     return out
 
 
-def synth_route(seed: int = 1993, heavy: bool = False):
+def synth_route(seed: int = 1993, heavy: bool = False, vanilla: bool = False):
     """Waypoints (x, y) of a closed walk through every room that only crosses door sectors:
     depth-first traversal of the generator's spanning tree (same RNG stream as build_synth_iwad)."""
     # Re-run the generator's RNG consumption up to the spanning tree by building the WAD's
     # connectivity again; cheaper: rebuild and introspect.
-    return _route_from_build(seed, heavy)
+    return _route_from_build(seed, heavy, vanilla)
 
 
-def _route_from_build(seed, heavy):
+def _route_from_build(seed, heavy, vanilla=False):
     # The route is derived from the door list, recovered from the WAD itself: two-sided linedefs.
-    wad = build_synth_iwad(seed, heavy)
+    wad = build_synth_iwad(seed, heavy, vanilla=vanilla)
     lumps = wad_directory(wad)
     idx = [i for i, (n, _, _) in enumerate(lumps) if n == "E1M1"][0]
     def lump(k):
         n, off, size = lumps[idx + k]
         return wad[off:off + size]
-    ld, sd, vx = lump(2), lump(3), lump(4)
+    ld, sd, vx, secs = lump(2), lump(3), lump(4), lump(8)
     gx, gy = (16, 12) if heavy else (8, 6)
     nroom = gx * gy
     adj = {c: set() for c in range(nroom)}
@@ -721,6 +778,9 @@ def _route_from_build(seed, heavy):
         sf = struct.unpack_from("<h", sd, f * 30 + 28)[0]
         sb = struct.unpack_from("<h", sd, b * 30 + 28)[0]
         room, door = (sf, sb) if sf < nroom else (sb, sf)
+        dfloor, dceil = struct.unpack_from("<hh", secs, door * 26)
+        if dceil <= dfloor:
+            continue  # closed door
         door_rooms.setdefault(door, set()).add(room)
     for door, rs in door_rooms.items():
         a, b = sorted(rs)

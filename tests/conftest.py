@@ -59,6 +59,13 @@ def wad1994(synth):
     return synth.build_synth_iwad(1994, heavy=True)
 
 
+@pytest.fixture(scope="session")
+def wad1995(synth):
+    """The vanilla-shaped variant: arbitrary integer vertices / wall angles, rounded BSP splits, closed doors, 1-degree thing
+    angles, wall textures with negative and past-the-bottom patch origins (synth_wad.build_synth_iwad, vanilla=True)."""
+    return synth.build_synth_iwad(1995, vanilla=True)
+
+
 def load_path(seed: int) -> np.ndarray:
     return np.fromfile(os.path.join(GOLDEN, f"campath_seed{seed}.f32"), dtype="<f4").reshape(1000, 8)
 
@@ -74,8 +81,13 @@ def path1994():
 
 
 @pytest.fixture(scope="session")
+def path1995():
+    return load_path(1995)
+
+
+@pytest.fixture(scope="session")
 def golden_frames():
-    return {seed: json.load(open(os.path.join(GOLDEN, f"frames_seed{seed}.json"))) for seed in (1993, 1994)}
+    return {seed: json.load(open(os.path.join(GOLDEN, f"frames_seed{seed}.json"))) for seed in (1993, 1994, 1995)}
 
 
 @pytest.fixture(scope="session")
@@ -86,6 +98,11 @@ def oracle_scene1993(oracle, wad1993):
 @pytest.fixture(scope="session")
 def oracle_scene1994(oracle, wad1994):
     return oracle.Scene(wad1994, "e1m1")
+
+
+@pytest.fixture(scope="session")
+def oracle_scene1995(oracle, wad1995):
+    return oracle.Scene(wad1995, "e1m1")
 
 
 @pytest.fixture(scope="session")

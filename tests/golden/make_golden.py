@@ -2,7 +2,9 @@
 """Regenerates the committed fixtures under tests/golden/ (run from the repo root, CPU only).
 
 What is pinned and by what:
-  * synth_wad.json       sha256 of the synthetic IWADs (pins the generator, not the renderer)
+  * synth_wad.json       sha256 of the synthetic IWADs (pins the generator, not the renderer): seed 1993 (bench map), seed 1994
+                         (heavy map), seed 1995 (the "vanilla-shaped" variant: arbitrary integer vertices and wall angles, rounded
+                         BSP splits, closed doors, 1-degree thing angles, patches with negative / past-the-bottom origins)
   * campath_*.f32        the 1000-frame camera paths: raw little-endian f32 [1000][8] =
                          x, y, angle, cos, sin, cos(-a), sin(-a), floor_height (camera_path.view_record)
   * frames_*.json        sha256 of ORACLE frames (oracle/doomref.c) at sampled path frames and sizes
@@ -58,11 +60,13 @@ def full_path_checksums(wad, path, W, H):
 
 def main():
     wads = {}
-    for seed, heavy in ((1993, False), (1994, True)):
-        wad = sw.build_synth_iwad(seed, heavy=heavy)
+    for seed, heavy, vanilla in ((1993, False, False), (1994, True, False), (1995, False, True)):
+        wad = sw.build_synth_iwad(seed, heavy=heavy, vanilla=vanilla)
         wads[str(seed)] = {"sha256": hashlib.sha256(wad).hexdigest(), "bytes": len(wad), "heavy": heavy}
+        if vanilla:
+            wads[str(seed)]["vanilla"] = True
         sc = doomref.Scene(wad, "e1m1")
-        path = cp.make_camera_path(sw.synth_route(seed, heavy=heavy), lambda x, y, d: sc.floor_height_at(x, y, d), 1000)
+        path = cp.make_camera_path(sw.synth_route(seed, heavy=heavy, vanilla=vanilla), lambda x, y, d: sc.floor_height_at(x, y, d), 1000)
         path.astype("<f4").tofile(os.path.join(OUT, f"campath_seed{seed}.f32"))
         frames = {}
         sizes = SIZES if not heavy else {"320x200": list(range(0, 1000, 100)), "1280x800": [250]}

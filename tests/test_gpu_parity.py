@@ -19,6 +19,11 @@ def scene1994(dg, wad1994):
     return dg.Scene(wad1994, "e1m1")
 
 
+@pytest.fixture(scope="module")
+def scene1995(dg, wad1995):
+    return dg.Scene(wad1995, "e1m1")
+
+
 def make_ctx(dg, scene, W, H, batch, slots=2, front_end=0):
     ctx = dg.Context(W, H, max_batch=batch, slots=slots, front_end=front_end)
     ctx.upload_scene(scene)
@@ -83,6 +88,35 @@ def test_heavy_map_bit_exact(dg, scene1994, oracle_scene1994, path1994, golden_f
     for i, h in golden_frames[1994]["320x200"].items():
         assert sha(out[idx.index(int(i))].tobytes()) == h
     ctx.close()
+
+
+@pytest.mark.parametrize("strips", ["0", "1"], ids=["tiles", "strips"])
+@pytest.mark.parametrize("front_end", [1, 2], ids=["host-lists", "device-column-walk"])
+def test_vanilla_shaped_map_bit_exact(dg, wad1995, oracle_scene1995, path1995, golden_frames, monkeypatch, front_end, strips):
+    """Seed 1995 — arbitrary integer vertices and wall angles, rounded BSP splits, closed doors (segs.rs:222-225), thing angles in
+    1 degree steps, patches with negative / past-the-bottom origins: the committed golden hashes at every size they were taken at,
+    every 8th path frame against the oracle, through both front ends and both rasterisers."""
+    monkeypatch.setenv("DOOMGPU_STRIPS", strips)
+    scene = dg.Scene(wad1995, "e1m1")
+    for size, frames in golden_frames[1995].items():
+        ts = float(size.split("@t=")[1]) if "@t=" in size else 0.0
+        W, H = map(int, size.split("@")[0].split("x"))
+        idx = sorted(int(i) for i in frames)
+        ctx = make_ctx(dg, scene, W, H, len(idx), slots=1, front_end=front_end)
+        out = ctx.render(dg.make_views(path1995[idx], timestamp=ts))
+        assert ctx.timing(0)["front_end"] == front_end
+        for k, i in enumerate(idx):
+            assert sha(out[k].tobytes()) == frames[str(i)], f"{size} frame {i}"
+        ctx.close()
+    W, H = 320, 200
+    idx = list(range(0, 1000, 8))
+    ctx = make_ctx(dg, scene, W, H, len(idx), front_end=front_end)
+    out = ctx.render(dg.make_views(path1995[idx]))
+    for k, i in enumerate(idx):
+        ref = np.frombuffer(oracle_scene1995.render(W, H, path1995[i]), dtype=np.uint8).reshape(H, W, 3)
+        assert np.array_equal(out[k], ref), f"frame {i}"
+    ctx.close()
+    scene.close()
 
 
 def _deep_copy_lists(dg, fl):
@@ -366,11 +400,11 @@ def test_device_front_end_capacity_falls_back_to_host_lists(dg, scene1994, oracl
     ctx.close()
 
 
-@pytest.mark.parametrize("seed,heavy,quirks", [(1993, False, False), (1994, True, False), (1993, False, True)])
+@pytest.mark.parametrize("seed,heavy,quirks", [(1993, False, False), (1994, True, False), (1993, False, True), (1995, False, False)])
 def test_random_views_device_walk_equals_host_lists(dg, synth, campath_mod, oracle, seed, heavy, quirks):
     """2 000 random viewpoints per map (inside and outside the map, any heading, several eye heights) through both front
     ends at two sizes: identical frames, and every 40th one also against the oracle."""
-    wad = synth.build_synth_iwad(seed=seed, heavy=heavy, quirks=quirks)
+    wad = synth.build_synth_iwad(seed=seed, heavy=heavy, quirks=quirks, vanilla=(seed == 1995))
     scene = dg.Scene(wad, "e1m1")
     osc = oracle.Scene(wad, "e1m1")
     rng = np.random.default_rng(seed + 23)
@@ -431,14 +465,14 @@ def test_full_path_2560x1600_by_checksums(dg, scene1994, oracle_scene1994, path1
         c.close()
 
 
-@pytest.mark.parametrize("seed", [1993, 1994])
-def test_every_frame_of_both_paths_at_1280x800_against_the_oracle_checksums(dg, scene1993, scene1994, path1993, path1994, seed):
+@pytest.mark.parametrize("seed", [1993, 1994, 1995])
+def test_every_frame_of_both_paths_at_1280x800_against_the_oracle_checksums(dg, scene1993, scene1994, scene1995, path1993, path1994, path1995, seed):
     """BASELINE configs 2 and 3/4 in full: all 1 000 frames at the bench size, both front ends, against the committed
     checksums of the oracle's frames (tests/golden/checksums_seed*_1280x800.json) — no frame crosses PCIe."""
     import json
     import os
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"checksums_seed{seed}_1280x800.json")))["checksums"]
-    scene, path = (scene1993, path1993) if seed == 1993 else (scene1994, path1994)
+    scene, path = {1993: (scene1993, path1993), 1994: (scene1994, path1994), 1995: (scene1995, path1995)}[seed]
     W, H, B = 1280, 800, 250
     for fe in (dg.DG_FE_DEVICE, dg.DG_FE_HOST):
         ctx = make_ctx(dg, scene, W, H, B, slots=1, front_end=fe)

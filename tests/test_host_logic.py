@@ -111,6 +111,27 @@ def test_host_lists_and_kernel_bodies_reproduce_oracle_1993(oracle_scene1993, wa
         assert st[0] > 0 and st[3] >= W * H // 2
 
 
+def test_host_lists_and_kernel_bodies_reproduce_oracle_vanilla_shaped(oracle_scene1995, wad1995, path1995, campath_mod):
+    """Seed 1995 (arbitrary vertices and wall angles, rounded BSP splits, closed doors, 1-degree thing angles, odd patch origins):
+    path frames plus random viewpoints, some of them inside closed door sectors and outside the map."""
+    es = emul_bind.EmulScene(wad1995)
+    for i in range(0, 1000, 9):
+        got, _ = es.render(320, 200, path1995[i])
+        assert got == oracle_scene1995.render(320, 200, path1995[i]), f"frame {i}"
+    rng = np.random.default_rng(1995)
+    for j in range(150):
+        rec = campath_mod.view_record(float(rng.uniform(-100, 4200)), float(rng.uniform(-100, 3200)), float(rng.uniform(-7, 7)),
+                                      float(rng.choice([-64, -8, 0, 24, 200])))
+        W, H = [(320, 200), (132, 67), (644, 400)][j % 3]
+        try:
+            ref = oracle_scene1995.render(W, H, rec)
+        except RuntimeError:
+            with pytest.raises(RuntimeError):
+                es.render(W, H, rec)
+            continue
+        assert es.render(W, H, rec)[0] == ref, f"view {j}"
+
+
 def test_host_lists_and_kernel_bodies_reproduce_oracle_heavy(oracle_scene1994, wad1994, path1994):
     es = emul_bind.EmulScene(wad1994)
     for i in range(0, 1000, 20):
@@ -163,11 +184,11 @@ def test_game_state_snapshots_match_oracle(oracle, wad1993, path1993):
 
 
 @pytest.mark.parametrize("seed,heavy,W,H,stride", [(1993, False, 320, 200, 3), (1994, True, 320, 200, 3), (1993, False, 1280, 800, 83),
-                                                   (1994, True, 644, 400, 61)])
+                                                   (1994, True, 644, 400, 61), (1995, False, 320, 200, 3), (1995, False, 1280, 800, 97)])
 def test_device_column_walk_bodies_match_host_lists(synth, seed, heavy, W, H, stride):
     """fe_core.h (the bodies of dg_fe_columns / dg_fe_finalize) on the CPU: the column-major DevRSpan list built from the
     per-seg / per-sprite records must be byte-identical to the host list path's, frame by frame."""
-    es = emul_bind.EmulScene(synth.build_synth_iwad(seed=seed, heavy=heavy), "e1m1")
+    es = emul_bind.EmulScene(synth.build_synth_iwad(seed=seed, heavy=heavy, vanilla=(seed == 1995)), "e1m1")
     path = load_path(seed)
     frames = sorted(set(range(0, len(path), stride)) | ({277} if heavy else set()))
     gaps = 0
