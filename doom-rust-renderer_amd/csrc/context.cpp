@@ -17,6 +17,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <chrono>
 #include <functional>
@@ -181,7 +182,6 @@ struct dg_ctx {
                                         // Measured on the benchmark scene (a third of its tiles hold masked walls / sprites) the two are
                                         // equal at 1280x800 and the tile rasteriser alone is faster at 320x200 (profiles/r02_strip_rasteriser.md).
     int seg_cap = 32, band_rows = 1, n_bands = 1;
-    int tile_workgroups = 512;          // persistent workgroups of dg_raster_tile_list
     bool side_tiles = true;             // ... on their own stream beside dg_raster_strips (DOOMGPU_SIDE_TILES=0: behind it)
     unsigned long long *d_checksums = nullptr;   // dg_frame_checksums scratch, max_batch entries
     uint4 *d_row_tab = nullptr;         // per-row constants of the flat / sky mappers (dg_row_table), rebuilt per scene upload
@@ -242,7 +242,6 @@ void free_ctx(dg_ctx *c) {
     if (c->d_palette) (void)hipFree(c->d_palette);
     if (c->d_texel_idx) (void)hipFree(c->d_texel_idx);
     if (c->d_texel_opq) (void)hipFree(c->d_texel_opq);
-    if (c->d_flats) (void)hipFree(c->d_flats);
     if (c->d_pool) (void)hipFree(c->d_pool);
     if (c->d_row_tab) (void)hipFree(c->d_row_tab);
     if (c->d_checksums) (void)hipFree(c->d_checksums);
@@ -257,7 +256,6 @@ void fill_strip_params(const dg_ctx *c, const Slot &s, RasterParams &P) {
     P.tile_counters = s.d_frame_flags + c->cfg.max_batch;
     P.band_ovl = reinterpret_cast<uint8_t *>(P.tile_counters + 2);
     P.tile_list = s.d_tile_list;
-    P.tile_workgroups = c->tile_workgroups;
     P.seg_cap = c->seg_cap; P.band_rows = c->band_rows; P.n_bands = c->n_bands; P.strips = c->strips ? 1 : 0;
 }
 
@@ -648,10 +646,8 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     HIP_TRY(hipSetDevice(cfg->device));
 
     dg_ctx *c = new dg_ctx();
-    c->tile_workgroups = std::max(1, prop.multiProcessorCount * 4);
     c->side_tiles = false;
     if (const char *e = std::getenv("DOOMGPU_SIDE_TILES")) c->side_tiles = std::strtol(e, nullptr, 10) != 0;
-    if (const char *e = std::getenv("DOOMGPU_TILE_WGS_PER_CU")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 8) c->tile_workgroups = prop.multiProcessorCount * (int)v; }
     c->cfg = *cfg;
     c->fk = make_consts(cfg->width, cfg->height);
     c->dk = DevConsts{c->fk.ARC, c->fk.GCFX, c->fk.CFX, c->fk.CFY, cfg->width, cfg->height};
@@ -763,7 +759,7 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     if (c->d_palette) { (void)hipFree(c->d_palette); c->d_palette = nullptr; }
     if (c->d_texel_idx) { (void)hipFree(c->d_texel_idx); c->d_texel_idx = nullptr; }
     if (c->d_texel_opq) { (void)hipFree(c->d_texel_opq); c->d_texel_opq = nullptr; }
-    if (c->d_flats) { (void)hipFree(c->d_flats); c->d_flats = nullptr; }
+    c->d_flats = nullptr;               // inside d_texel_idx's allocation
     if (c->d_pool) { (void)hipFree(c->d_pool); c->d_pool = nullptr; }
     // the slots' prepared records point into the device scene that was just freed: nothing may be replayed from them
     for (Slot &s : c->slots) { s.n_frames = 0; s.timed = false; s.fe_check = false; s.seg_check = false; s.busy = false; }
@@ -771,9 +767,12 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     for (int i = 0; i < 256; i++) pal[i] = (uint32_t)sc.palette[3 * i] | ((uint32_t)sc.palette[3 * i + 1] << 8) | ((uint32_t)sc.palette[3 * i + 2] << 16);
     const size_t nt = std::max<size_t>(sc.texel_idx.size(), 16), nf = std::max<size_t>(sc.flat_pool.size(), 16);
     HIP_TRY(hipMalloc((void **)&c->d_palette, sizeof pal));
-    HIP_TRY(hipMalloc((void **)&c->d_texel_idx, nt));
+    // [column-major texel index plane | flats] share one allocation: the tile rasteriser gathers every kind's texel with one
+    // 32-bit offset from texel_idx (flats at flats - texel_idx)
+    const size_t flats_at = (nt + 255) & ~(size_t)255;
+    HIP_TRY(hipMalloc((void **)&c->d_texel_idx, flats_at + nf));
     HIP_TRY(hipMalloc((void **)&c->d_texel_opq, nt));
-    HIP_TRY(hipMalloc((void **)&c->d_flats, nf));
+    c->d_flats = c->d_texel_idx + flats_at;
     HIP_TRY(hipMemcpy(c->d_palette, pal, sizeof pal, hipMemcpyHostToDevice));
     if (!sc.texel_idx.empty()) {
         HIP_TRY(hipMemcpy(c->d_texel_idx, sc.texel_idx.data(), sc.texel_idx.size(), hipMemcpyHostToDevice));

@@ -23,12 +23,11 @@ struct RasterParams {
     DevSeg *segs;                // [n_frames][seg_cap][W]
     uint8_t *band_first;         // [n_frames][n_bands][W] slot of the segment that contains the first row of a band
     uint32_t *frame_flags;       // [max_batch] != 0: a column needed more than seg_cap segments; the batch is redone with strips = 0
-    uint32_t *tile_counters;     // [0] tiles on the list, [1] tiles taken beyond each workgroup's first (dg_raster_tile_list)
+    uint32_t *tile_counters;     // [0] tiles on the list, [1] spare
     uint8_t *band_ovl;           // [n_frames][n_bands][ceil(W / 64)] != 0: an overlay span (strip_core.h) touches that band of that 64-column
                                  // strip -> rendered by dg_raster_tile_list (these three directly follow each other: one fill clears them)
     uint32_t *tile_list;         // frame << 16 | band << 8 | strip
     int32_t seg_cap, band_rows, n_bands;
-    int32_t tile_workgroups;     // persistent workgroups of dg_raster_tile_list
     int32_t strips;              // 0: dg_raster_tiles alone renders everything (no resolve, no strips)
 };
 
