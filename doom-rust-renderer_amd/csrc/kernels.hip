@@ -68,11 +68,6 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) { return (uint32
 //      factor 0.0 -> exactly 0,0,0).
 // No pixel is evaluated twice except under step B's overlays; nothing depends on the order of evaluation but B.
 
-__device__ __forceinline__ int winner_step(uint32_t w0, int idx, int y, int winner) {
-    const uint32_t lo = w0 & 0x3fffu, range = ((w0 >> 16) & 0x3fffu) - lo;      // wave-uniform: scalar unit
-    return ((uint32_t)y - lo) <= range ? idx : winner;
-}
-
 // One byte from a plane of the scene, address = scalar base + 32-bit lane offset, waited for here.
 __device__ __forceinline__ uint32_t gather_u8(const uint8_t *base, uint32_t o) {
     uint32_t v;
@@ -101,39 +96,63 @@ __device__ __forceinline__ uint32_t shade_f(const float4 c, float factor) {
     return o;
 }
 
-// A wall span as the tile kernel keeps it in LDS (stage_wall_tile): a.x = kind << 30 | hm with hm = h - 1 for a power-of-two bitmap
-// height, else 0x8000 | h; a.y = d; a.z = start of the texture column (column-major planes); a.w = light factor; b.x = uy1; b.y = top_y |
-// off_y << 16; b.z = h as f32; b.w = prepared reciprocal of d.
-__device__ __forceinline__ void stage_wall_tile(uint4 &a, uint4 &b) {
-    const uint32_t h = b.z & 0xffffu;
-    stage_wall_span(a.y, a.z, b.z, b.w);
-    a.x = (a.x & 0xc0000000u) | ((h & (h - 1)) == 0 ? h - 1 : 0x8000u | h);
-    b.z = f32_bits((float)h);
-}
-// Texel offset of one wall pixel (bitmap_render.rs:256-263) from the staged words; `any_npot`: some lane of the wave has a bitmap
-// height that is not a power of two (then every lane takes the general modulus, which is right for all heights).
-__device__ __forceinline__ uint32_t wall_offset_tile(const uint4 a, const uint4 b, int y) {
-    const float d = bits_f32(a.y), hf = bits_f32(b.z);
-    const int32_t top_y = lo_i16(b.y), off_y = hi_i16(b.y);
-    const float ay = div_prepared((float)(y - top_y), d, bits_f32(b.w));
-    int32_t ty = wrap_i16(f32_as_i16(hf + ay * bits_f32(b.x)) + off_y);
-    const uint32_t hm = a.x & 0xffffu;
-    if (__builtin_amdgcn_ballot_w64((hm & 0x8000u) != 0) == 0ull) return a.z + (uint32_t)(ty & (int32_t)hm);
-    const int32_t h = (int32_t)hf;
-    return a.z + (uint32_t)floor_mod_fast(ty, h, 0, approx_rcp(hf));
+// ---- spans as the tile kernel keeps them in LDS (stage_tile_span); record 0 of the staging area is the "nothing" record that an
+// unowned row points at (a sky span with factor 0 -> 0,0,0), records 1.. are the tile's spans ------------------------------------
+//   WALL  a.x = hm (< 0x4000_0000): h - 1 for a power-of-two bitmap height, else 0x8000 | h;  a.y = d;  a.z = start of the texture
+//         column (column-major planes);  a.w = light factor;  b.x = uy1;  b.y = top_y | off_y << 16;  b.z = h as f32, NEGATED when h
+//         is not a power of two;  b.w = prepared reciprocal of d
+//   FLAT  a.x = 0x4000_0000 | ..;  a.y = wz * vx;  a.z = offset of the flat from texel_idx (flats sit behind the texel plane);
+//         b.x = gwz;  b.y = light_level / 255;  b.z = fast-divide-ok << 8
+//   SKY   a.x = 0x8000_0000 | .. (negative as i32);  a.z = offset of the sky texture column (0 when the reference would index outside
+//         the bitmap);  a.w = 1.0f (0.0f in that case)
+struct RowConsts {              // per screen row = per lane, fixed for the tile
+    int y;
+    float vy, r_vy;             // CFY - y (visplanes.rs:109) and its prepared reciprocal
+    uint32_t row_fast;          // 0x100 unless vy == 0 (that row takes the plain divide: x / 0)
+    uint32_t sky_row;           // sky texture row, 0 when outside the bitmap
+    float sky_fac;              // 1.0f, 0.0f when outside the bitmap
+};
+
+__device__ __forceinline__ void stage_tile_span(uint4 &a, uint4 &b, uint32_t flats_rel) {
+    const uint32_t kind = w0_kind(a.x);
+    if (kind == SPAN_WALL) {
+        const uint32_t h = b.z & 0xffffu;
+        const bool pot = (h & (h - 1)) == 0;
+        stage_wall_span(a.y, a.z, b.z, b.w);
+        a.x = pot ? h - 1 : 0x8000u | h;
+        b.z = f32_bits(pot ? (float)h : -(float)h);
+    } else if (kind == SPAN_FLAT) {
+        a.z += flats_rel;
+    } else {
+        const bool valid = a.z != 0xffffffffu;
+        a.z = valid ? a.z : 0u;
+        a.w = f32_bits(valid ? 1.0f : 0.0f);
+    }
 }
 
-// Texel offset (relative to the flats) and light factor of one floor / ceiling pixel (visplanes.rs:108-126); see flat_texel_offset
-// (raster_core.h) for the scalar form.  The factor is left unclamped: `as u8` of (colour x negative) is 0, the same as with the
-// reference's `if factor < 0.0 { factor = 0.0 }`, and lightf - z / 4096 as one fma is exact because z / 4096 is.
-__device__ __forceinline__ uint32_t flat_offset_tile(const DevFrame &f, const uint4 a, const uint4 b, float vy, float r_vy, float &factor) {
+// Texel offset of one wall pixel (bitmap_render.rs:256-263) from the staged words.  A wave in which some lane's bitmap height is not
+// a power of two takes the general modulus for every lane (it is right for all heights).
+// `lanes`: the lanes whose span is a wall (the others compute garbage that is not used).
+__device__ __forceinline__ uint32_t wall_offset_tile(const uint4 a, const uint4 b, int y, unsigned long long lanes) {
+    const float d = bits_f32(a.y), hs = bits_f32(b.z), hf = __builtin_fabsf(hs);
+    const int32_t top_y = lo_i16(b.y), off_y = hi_i16(b.y);
+    const float ay = div_prepared_nofix((float)(y - top_y), d, bits_f32(b.w));   // d == 0: uy1 is NaN and so is the sum, whatever ay is
+    const int32_t ty = f32_as_i16(hf + ay * bits_f32(b.x));
+    if ((__builtin_amdgcn_ballot_w64(hs < 0.0f) & lanes) == 0ull) return a.z + ((uint32_t)(ty + off_y) & a.x);   // the wrap of the i16 add is above the mask
+    return a.z + (uint32_t)floor_mod_fast(wrap_i16(ty + off_y), (int32_t)hf, 0, approx_rcp(hf));
+}
+
+// Texel offset and light factor of one floor / ceiling pixel (visplanes.rs:108-126); see flat_texel_offset (raster_core.h) for the
+// scalar form.  The factor is left unclamped: `as u8` of (colour x negative) is 0, the same as with the reference's
+// `if factor < 0.0 { factor = 0.0 }`, and lightf - z / 4096 as one fma is exact because z / 4096 is.
+__device__ __forceinline__ uint32_t flat_offset_tile(const DevFrame &f, const uint4 a, const uint4 b, const RowConsts &R, unsigned long long lanes, float &factor) {
     float wx, wy;
-    if (__builtin_amdgcn_ballot_w64((b.z & 0x100u) == 0u) == 0ull) {
-        wx = div_prepared(bits_f32(b.x), vy, r_vy);
-        wy = div_prepared(bits_f32(a.y), vy, r_vy);
-    } else {                                      // a numerator outside the verified domain somewhere in the wave: plain divides
-        wx = bits_f32(b.x) / vy;
-        wy = bits_f32(a.y) / vy;
+    if ((__builtin_amdgcn_ballot_w64((b.z & R.row_fast) == 0u) & lanes) == 0ull) {
+        wx = div_prepared_nofix(bits_f32(b.x), R.vy, R.r_vy);
+        wy = div_prepared_nofix(bits_f32(a.y), R.vy, R.r_vy);
+    } else {                                      // a numerator outside the verified domain or the vy == 0 row somewhere in the wave: plain divides
+        wx = bits_f32(b.x) / R.vy;
+        wy = bits_f32(a.y) / R.vy;
     }
     const float rx = wx * f.cos_a - wy * f.sin_a;
     const float ry = wy * f.cos_a + wx * f.sin_a;
@@ -143,104 +162,131 @@ __device__ __forceinline__ uint32_t flat_offset_tile(const DevFrame &f, const ui
     return a.z + (uint32_t)(ty * 64 + tx);
 }
 
-__device__ __forceinline__ void overlay_step(const RasterParams &P, const float4 *palf, const uint4 *lsp, uint32_t w0, int idx, int y, int srow,
-                                             int winner, uint32_t &color, bool &done) {
-    const uint32_t lo = w0 & 0x3fffu, range = ((w0 >> 16) & 0x3fffu) - lo;
-    if (((uint32_t)y - lo) <= range && idx > winner) {
-        const uint4 a = lsp[2 * idx], b = lsp[2 * idx + 1];   // same address in every lane: LDS broadcast
-        uint32_t o;
-        float factor = 1.0f;                                  // sky: plain lookup, no lighting (x 1.0 is exact)
-        if (w0_kind(w0) == SPAN_WALL) {
-            o = wall_offset_tile(a, b, y);
-            factor = bits_f32(a.w);
-        } else {
-            o = sky_texel_offset(a.z, srow);
-        }
-        if (o != 0xffffffffu) {
+// Spans are addressed by their BYTE offset in the staging area (32 x record number): the owner of a row is the largest offset
+// among the opaque spans that cover it, 0 = the "nothing" record.
+//
+// Both span loops below are wave-uniform walks over a 64-bit mask whose bit i says "the span held by lane i is to be looked at".
+// Each lane holds its span's first row, row count - 1 and staging offset in three registers, so a step is three v_readlane and
+// no scalar unpacking: find-first-bit, clear it, compare, branch are the only scalar instructions.
+__device__ __forceinline__ int take_lowest(unsigned long long &m) {
+    const int j = __builtin_ctzll(m);
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
+    return j;
+}
+__device__ __forceinline__ uint32_t owner_loop(unsigned long long m, uint32_t v_lo, uint32_t v_rg, uint32_t v_off, const RowConsts &R, uint32_t winner) {
+    while (m) {
+        const int j = take_lowest(m);
+        winner = ((uint32_t)R.y - bcast(v_lo, j)) <= bcast(v_rg, j) ? bcast(v_off, j) : winner;
+    }
+    return winner;
+}
+
+__device__ __forceinline__ const uint4 *span_at(const uint4 *staged, uint32_t off) {
+    return reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(staged) + off);
+}
+
+// Possibly-transparent spans in draw order (m_wall: which of them are bitmap columns; the others are sky-with-holes spans).
+__device__ __forceinline__ void overlay_loop(const RasterParams &P, const float4 *palf, const uint4 *staged, unsigned long long m, unsigned long long m_wall,
+                                             uint32_t v_lo, uint32_t v_rg, uint32_t v_off, const RowConsts &R, uint32_t winner, uint32_t &color, bool &done) {
+    while (m) {
+        const int j = take_lowest(m);
+        const uint32_t off = bcast(v_off, j);
+        if (((uint32_t)R.y - bcast(v_lo, j)) <= bcast(v_rg, j) && off > winner) {
+            const uint4 a = span_at(staged, off)[0], b = span_at(staged, off)[1];   // same address in every lane: LDS broadcast
+            const bool wall = (m_wall >> j) & 1ull;                                   // wave-uniform
+            uint32_t o;
+            float factor;
+            if (wall) {
+                o = wall_offset_tile(a, b, R.y, ~0ull);
+                factor = bits_f32(a.w);
+            } else {                                          // sky bitmap with holes: plain lookup, no lighting (x 1.0 is exact)
+                o = a.z + R.sky_row;
+                factor = bits_f32(a.w) * R.sky_fac;           // 0.0 where the reference would index outside the bitmap: nothing drawn
+            }
             uint32_t tex, opq;
             gather_u8x2(P.scene.texel_idx, P.scene.texel_opq, o, tex, opq);
-            if (opq) { color = shade_f(palf[tex], factor); done = true; }
+            const uint32_t c = shade_f(palf[tex], factor);
+            const bool hit = opq != 0u && (wall || factor != 0.0f);
+            color = hit ? c : color;
+            done = done || hit;
         }
     }
 }
 
-__device__ __forceinline__ uint32_t shade_winner(const RasterParams &P, const DevFrame &fr, const float4 *palf, const uint4 *lsp, int winner,
-                                                 int y, float vy, float r_vy, int srow, uint32_t flats_rel) {
-    uint32_t o = 0;
-    float factor = 0.0f;
-    if (winner >= 0) {
-        const uint4 a = lsp[2 * winner], b = lsp[2 * winner + 1];
-        const uint32_t kind = w0_kind(a.x);
-        if (kind == SPAN_FLAT) {
-            o = flats_rel + flat_offset_tile(fr, a, b, vy, r_vy, factor);
-        } else if (kind == SPAN_WALL) {
-            o = wall_offset_tile(a, b, y);
-            factor = bits_f32(a.w);
-        } else {                                  // sky bitmap without holes: plain lookup, no lighting (x 1.0 is exact)
-            const uint32_t so = sky_texel_offset(a.z, srow);
-            if (so != 0xffffffffu) { o = so; factor = 1.0f; }
-        }
+// Every row evaluates its owner.  The scalar instruction stream is what this kernel is short of (profiles/r02_raster_tiles.md), so
+// there is no divergent control flow here: a kind that some row of the wave needs is computed by ALL 64 lanes (on words of another
+// kind the arithmetic is garbage but harmless) and each lane then selects — two uniform branches and a few selects instead of
+// nested exec-mask regions.  The gather comes after the select, so every address is that of the lane's real owner.
+__device__ __forceinline__ uint32_t shade_winner(const RasterParams &P, const DevFrame &fr, const float4 *palf, const uint4 *staged, uint32_t winner,
+                                                 const RowConsts &R) {
+    const uint4 a = span_at(staged, winner)[0], b = span_at(staged, winner)[1];
+    const bool is_wall = a.x < 0x40000000u, is_sky = (int32_t)a.x < 0;
+    const unsigned long long m_wall = __builtin_amdgcn_ballot_w64(is_wall), m_sky = __builtin_amdgcn_ballot_w64(is_sky);
+    uint32_t o = a.z + R.sky_row;                 // sky bitmap without holes, or nothing: plain lookup, no lighting (x 1.0 is exact)
+    float factor = bits_f32(a.w) * R.sky_fac;
+    if (~(m_wall | m_sky) != 0ull) {              // some row is owned by a floor / ceiling
+        float ff;
+        const uint32_t fo = flat_offset_tile(fr, a, b, R, ~(m_wall | m_sky), ff);
+        const bool is_flat = !is_wall && !is_sky;
+        o = is_flat ? fo : o;
+        factor = is_flat ? ff : factor;
+    }
+    if (m_wall != 0ull) {
+        const uint32_t wo = wall_offset_tile(a, b, R.y, m_wall);
+        o = is_wall ? wo : o;
+        factor = is_wall ? bits_f32(a.w) : factor;
     }
     return shade_f(palf[gather_u8(P.scene.texel_idx, o)], factor);
 }
 
-// Any number of spans (lw0 = word 0 of every span, lsp = all 8 words): lane i looks at span i of each 64-span chunk, ballots pick
-// the spans touching these rows.
+// One lane's span -> the three values the loops broadcast.
+__device__ __forceinline__ void unpack_span(uint32_t w0, uint32_t off, uint32_t &v_lo, uint32_t &v_rg, uint32_t &v_off) {
+    v_lo = w0 & 0x3fffu;
+    v_rg = ((w0 >> 16) & 0x3fffu) - v_lo;
+    v_off = off;
+}
+
+// A column with any number of spans (lw0 = word 0 of every span of the column, off0 = byte offset of its first span in the staging
+// area): lane i looks at span i of each 64-span chunk, ballots pick the spans touching these rows.
 __device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const DevFrame &fr, const float4 *pal, const uint32_t *lw0,
-                                                  const uint4 *lsp, uint32_t n, int lane, int y, int y0, float vy, float r_vy, int srow,
-                                                  uint32_t flats_rel) {
-    int winner = -1;
+                                                  const uint4 *staged, uint32_t off0, uint32_t n, int lane, int y0, const RowConsts &R) {
+    uint32_t winner = 0;
     bool any_overlay = false;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + (uint32_t)lane;
         const uint32_t w0v = i < n ? lw0[i] : 0u;
         const bool hit = i < n && w0_cbot(w0v) >= y0 && w0_ctop(w0v) <= y0 + (TILE_H - 1);
-        unsigned long long m = __ballot(hit && !w0_immediate(w0v));
+        uint32_t v_lo, v_rg, v_off;
+        unpack_span(w0v, off0 + 32u * i, v_lo, v_rg, v_off);
         any_overlay |= __ballot(hit && w0_immediate(w0v)) != 0ull;
-        while (m) {
-            const int j = __builtin_ctzll(m);
-            m &= m - 1;
-            winner = winner_step(bcast(w0v, j), (int)base + j, y, winner);
-        }
+        winner = owner_loop(__ballot(hit && !w0_immediate(w0v)), v_lo, v_rg, v_off, R, winner);
     }
+    const uint32_t base_color = shade_winner(P, fr, pal, staged, winner, R);
+    if (!any_overlay) return base_color;
     uint32_t color = 0;
     bool done = false;
-    if (any_overlay) {
-        for (uint32_t base = 0; base < n; base += 64) {
-            const uint32_t i = base + (uint32_t)lane;
-            const uint32_t w0v = i < n ? lw0[i] : 0u;
-            const bool hit = i < n && w0_cbot(w0v) >= y0 && w0_ctop(w0v) <= y0 + (TILE_H - 1);
-            unsigned long long m = __ballot(hit && w0_immediate(w0v));
-            while (m) {
-                const int j = __builtin_ctzll(m);
-                m &= m - 1;
-                overlay_step(P, pal, lsp, bcast(w0v, j), (int)base + j, y, srow, winner, color, done);
-            }
-        }
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + (uint32_t)lane;
+        const uint32_t w0v = i < n ? lw0[i] : 0u;
+        const bool hit = i < n && w0_cbot(w0v) >= y0 && w0_ctop(w0v) <= y0 + (TILE_H - 1) && w0_immediate(w0v);
+        uint32_t v_lo, v_rg, v_off;
+        unpack_span(w0v, off0 + 32u * i, v_lo, v_rg, v_off);
+        overlay_loop(P, pal, staged, __ballot(hit), __ballot(hit && w0_kind(w0v) == SPAN_WALL), v_lo, v_rg, v_off, R, winner, color, done);
     }
-    const uint32_t base_color = shade_winner(P, fr, pal, lsp, winner, y, vy, r_vy, srow, flats_rel);
     return done ? color : base_color;
 }
 
-// The same for a column with at most 8 spans whose row filter was done by the wave-level pre-filter (tile_body): bit j of
-// hm_op / hm_ov set when opaque / possibly-transparent span j touches these rows, its word 0 sits in lane `lane0 + j` of w0f.
-__device__ __forceinline__ uint32_t raster_column_small(const RasterParams &P, const DevFrame &fr, const float4 *pal, uint32_t hm_op, uint32_t hm_ov,
-                                                        uint32_t w0f, int lane0, const uint4 *lsp, int y, float vy, float r_vy, int srow,
-                                                        uint32_t flats_rel) {
-    int winner = -1;
-    while (hm_op) {
-        const int j = __builtin_ctz(hm_op);
-        hm_op &= hm_op - 1;
-        winner = winner_step(bcast(w0f, lane0 + j), j, y, winner);
-    }
+// A column with at most 8 spans whose row filter was done by the wave-level pre-filter (tile_body): m_op / m_ov = the lanes that
+// hold an opaque / a possibly-transparent span of THIS column that touches these rows.
+__device__ __forceinline__ uint32_t raster_column_small(const RasterParams &P, const DevFrame &fr, const float4 *pal, unsigned long long m_op,
+                                                        unsigned long long m_ov, unsigned long long m_ovwall, uint32_t v_lo, uint32_t v_rg, uint32_t v_off,
+                                                        const uint4 *staged, const RowConsts &R) {
+    const uint32_t winner = owner_loop(m_op, v_lo, v_rg, v_off, R, 0u);
+    const uint32_t base_color = shade_winner(P, fr, pal, staged, winner, R);
+    if (!m_ov) return base_color;
     uint32_t color = 0;
     bool done = false;
-    while (hm_ov) {
-        const int j = __builtin_ctz(hm_ov);
-        hm_ov &= hm_ov - 1;
-        overlay_step(P, pal, lsp, bcast(w0f, lane0 + j), j, y, srow, winner, color, done);
-    }
-    const uint32_t base_color = shade_winner(P, fr, pal, lsp, winner, y, vy, r_vy, srow, flats_rel);
+    overlay_loop(P, pal, staged, m_ov, m_ovwall, v_lo, v_rg, v_off, R, winner, color, done);
     return done ? color : base_color;
 }
 
@@ -248,10 +294,13 @@ constexpr int TILE_TS = 65;       // dwords per tile COLUMN in LDS
 
 struct TileLds {
     uint32_t tile[TILE_W * TILE_TS];        // [col][row]: conflict-free for lane = row writes
-    uint4 lspans[SPAN_CAP * 2];
+    uint4 lspans[(SPAN_CAP + 1) * 2];       // record 0: "nothing"; records 1 ..: the staged spans (stage_tile_span)
     uint32_t lw0[SPAN_CAP];
     float4 pal[256];                        // r, g, b as f32
     uint32_t lcoff[TILE_W + 1];
+#ifdef DG_EXP_T_LDSPAD
+    uint32_t pad[DG_EXP_T_LDSPAD / 4];
+#endif
 };
 
 // One 64 x 64 tile of frame f: columns x0 .., rows y0 ..
@@ -261,43 +310,66 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int y = y0 + lane;
-    const float vy = P.k.CFY - (float)y;      // visplanes.rs:109, a per-row constant
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
     const uint4 *gspans = reinterpret_cast<const uint4 *>(P.rspans + fr.span_base);
     const uint32_t flats_rel = (uint32_t)(P.scene.flats - P.scene.texel_idx);   // one allocation: [texel index plane | flats]
 
-    // the three prologue loads are issued together (addresses clamped instead of branching around the loads)
+    // The spans of adjacent columns are one contiguous range of the column-major span array: [col_off[x0], col_off[x0 + 64]).  The two
+    // ends are wave-uniform (scalar loads); when the range fits in LDS — the normal case — every thread fetches its span straight
+    // away, together with the palette, the 65 column offsets and the row constants, and ONE barrier publishes all of it.  Wall
+    // spans are put into their per-pixel form on the way (stage_wall_tile: texture column start, prepared 1/d, height mask).
+    const uint32_t t_first = coff[x0 < W ? x0 : W], t_last = coff[x0 + TILE_W < W ? x0 + TILE_W : W];
+    const bool fits = t_last - t_first <= (uint32_t)SPAN_CAP;
+    uint4 sa = make_uint4(0u, 0u, 0u, 0u), sb = sa;
+    const bool mine = fits && threadIdx.x < t_last - t_first;
+    if (mine) {
+        sa = gspans[2 * ((size_t)t_first + threadIdx.x)];
+        sb = gspans[2 * ((size_t)t_first + threadIdx.x) + 1];
+    }
     const uint4 rt = P.row_tab[y < H ? y : H - 1];                    // prepared reciprocal of vy and the sky row (dg_row_table)
     const uint32_t pal_v = P.scene.palette[threadIdx.x & 255];
     const int xc = x0 + (int)(threadIdx.x <= TILE_W ? threadIdx.x : 0);
     const uint32_t coff_v = coff[xc < W ? xc : W];
-    const float r_vy = bits_f32(rt.x);
-    const int srow = (int)rt.y;
+    RowConsts R;
+    R.y = y;
+    R.vy = P.k.CFY - (float)y;
+    R.r_vy = bits_f32(rt.x);
+    R.row_fast = R.vy != 0.0f ? 0x100u : 0u;
+    R.sky_row = (int)rt.y < 0 ? 0u : rt.y;
+    R.sky_fac = (int)rt.y < 0 ? 0.0f : 1.0f;
     if (threadIdx.x < 256) L.pal[threadIdx.x] = make_float4((float)(pal_v & 255u), (float)((pal_v >> 8) & 255u), (float)((pal_v >> 16) & 255u), 0.0f);
     if (threadIdx.x <= TILE_W) L.lcoff[threadIdx.x] = coff_v;
+    if (mine) {
+        L.lw0[threadIdx.x] = sa.x;
+        stage_tile_span(sa, sb, flats_rel);
+        L.lspans[2 * threadIdx.x + 2] = sa;
+        L.lspans[2 * threadIdx.x + 3] = sb;
+    }
+    if (threadIdx.x == THREADS - 1) {         // the "nothing" record: a sky span with factor 0
+        L.lspans[0] = make_uint4(0x80000000u, 0u, 0u, 0u);
+        L.lspans[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
     __syncthreads();
 
-    // The spans of adjacent columns are one contiguous range of the column-major span array.  Stage as many whole columns
-    // as fit in LDS (normally the whole tile) with one coalesced burst — every load of the workgroup in flight at once, so
-    // the dependent chain col_off -> spans is paid once per tile — then rasterise those columns; repeat if needed.
-    // Wall spans are put into their per-pixel form on the way (stage_wall_span: texture column start, prepared 1/d).
     int c_lo = 0;
     while (c_lo < TILE_W) {
         const uint32_t t0 = L.lcoff[c_lo];
         int c_hi = TILE_W;
-        if (L.lcoff[TILE_W] - t0 > SPAN_CAP) {
-            c_hi = c_lo + 1;                  // a single column always fits: the binner caps a column at SPAN_CAP spans
-            while (c_hi < TILE_W && L.lcoff[c_hi + 1] - t0 <= SPAN_CAP) c_hi++;
+        if (!fits) {                          // more than SPAN_CAP spans in the tile: as many whole columns at a time as fit
+            if (L.lcoff[TILE_W] - t0 > SPAN_CAP) {
+                c_hi = c_lo + 1;              // a single column always fits: the binner caps a column at SPAN_CAP spans
+                while (c_hi < TILE_W && L.lcoff[c_hi + 1] - t0 <= SPAN_CAP) c_hi++;
+            }
+            const uint32_t n_stage = L.lcoff[c_hi] - t0;
+            for (uint32_t i = threadIdx.x; i < n_stage; i += THREADS) {
+                uint4 a = gspans[2 * ((size_t)t0 + i)], b = gspans[2 * ((size_t)t0 + i) + 1];
+                L.lw0[i] = a.x;
+                stage_tile_span(a, b, flats_rel);
+                L.lspans[2 * i + 2] = a;
+                L.lspans[2 * i + 3] = b;
+            }
+            __syncthreads();
         }
-        const uint32_t n_stage = L.lcoff[c_hi] - t0;
-        for (uint32_t i = threadIdx.x; i < n_stage; i += THREADS) {
-            uint4 a = gspans[2 * ((size_t)t0 + i)], b = gspans[2 * ((size_t)t0 + i) + 1];
-            L.lw0[i] = a.x;
-            if (w0_kind(a.x) == SPAN_WALL) stage_wall_tile(a, b);
-            L.lspans[2 * i] = a;
-            L.lspans[2 * i + 1] = b;
-        }
-        __syncthreads();
         // Wave-level pre-filter: this wave owns columns c_lo + wave + 8k (k = 0..7).  Lane (k, slot) = (lane >> 3, lane & 7)
         // tests span `slot` of column k against the tile's rows, so ONE pass filters all eight columns (columns with more
         // than 8 spans take the general path).
@@ -313,14 +385,39 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
                 f_hit = w0_cbot(f_w0) >= y0 && w0_ctop(f_w0) <= y0 + (TILE_H - 1);
             }
         }
+        uint32_t v_lo, v_rg, v_off;
+        unpack_span(f_w0, 32u * (f_n0 + 1u + (uint32_t)fslot), v_lo, v_rg, v_off);
         const unsigned long long hit_op = __ballot(f_hit && !w0_immediate(f_w0)), hit_ov = __ballot(f_hit && w0_immediate(f_w0));
+        const unsigned long long hit_ovwall = __ballot(f_hit && w0_immediate(f_w0) && w0_kind(f_w0) == SPAN_WALL);
+        const unsigned long long big = __ballot(f_n > 8u);         // all 8 lanes of a column with more than 8 spans
         int k8 = 0;
-        for (int c = c_lo + wave; c < c_hi; c += WAVES, k8 += 8) {
-            const uint32_t n0 = bcast(f_n0, k8), n = bcast(f_n, k8);
+        unsigned long long colmask = 0xffull;
+        for (int c = c_lo + wave; c < c_hi; c += WAVES, k8 += 8, colmask <<= 8) {
             uint32_t px;
-            if (n > 8u) px = raster_column(P, fr, L.pal, L.lw0 + n0, L.lspans + 2 * n0, n, lane, y, y0, vy, r_vy, srow, flats_rel);
-            else px = raster_column_small(P, fr, L.pal, (uint32_t)(hit_op >> k8) & 0xffu, (uint32_t)(hit_ov >> k8) & 0xffu, f_w0, k8,
-                                          L.lspans + 2 * n0, y, vy, r_vy, srow, flats_rel);
+            if (big & colmask) {
+                const uint32_t n0 = bcast(f_n0, k8), n = bcast(f_n, k8);
+                px = raster_column(P, fr, L.pal, L.lw0 + n0, L.lspans, 32u * (n0 + 1u), n, lane, y0, R);
+            } else {
+                px = raster_column_small(P, fr, L.pal, hit_op & colmask, hit_ov & colmask, hit_ovwall, v_lo, v_rg, v_off, L.lspans, R);
+            }
+#ifdef DG_EXP_T_ADDVALU
+            { uint32_t d = px; 
+#pragma unroll
+              for (int q = 0; q < DG_EXP_T_ADDVALU; q++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(d) : "v"(lane));
+              if (d == 0x12345u) px ^= 1u; }
+#endif
+#ifdef DG_EXP_T_ADDSALU
+            { uint32_t d = (uint32_t)c;
+#pragma unroll
+              for (int q = 0; q < DG_EXP_T_ADDSALU; q++) asm volatile("s_add_u32 %0, %0, %1" : "+s"(d) : "s"(k8));
+              if (d == 0x12345u) px ^= 1u; }
+#endif
+#ifdef DG_EXP_T_ADDLDS
+            { uint32_t acc = 0;
+#pragma unroll
+              for (int q = 0; q < DG_EXP_T_ADDLDS; q++) acc += *(volatile uint32_t *)&L.lw0[(lane + q * 64) & (SPAN_CAP - 1)];
+              if (acc == 0x12345u) px ^= 1u; }
+#endif
             L.tile[c * TILE_TS + lane] = px;
         }
 

@@ -86,6 +86,22 @@ DG_HD float div_prepared(float n, float d, float r) {
     return n / d;
 #endif
 }
+// div_prepared without the final v_div_fixup, for callers that exclude its special cases themselves: v_div_fixup only changes the
+// result when d is 0 / Inf / NaN or n is Inf / NaN (and for results in the denormal / overflow range, which the guard band
+// excludes).  The wall mapper's d is a non-zero integer or 0 (then uy1 is NaN and the row is NaN whatever ay is); the flat
+// mapper excludes the row with vy == 0 and numerators outside div_guard_ok.  tests/gpu_numerics enumerates both domains for
+// this form too.  One difference remains and is harmless: n = -0.0 with d > 0 gives +0.0 where IEEE gives -0.0; every consumer
+// of these quotients (`as i16`, products that are summed with a non-zero term or converted) maps both zeros to the same result.
+DG_HD float div_prepared_nofix(float n, float d, float r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+#else
+    (void)r;
+    return n / d;
+#endif
+}
 // Numerators for which div_prepared is used: zero, or 2^-64 <= |n| <= 2^64 (NaN / Inf / tiny / huge take the plain divide).
 DG_HD bool div_guard_ok(float n) {
     uint32_t e = (f32_bits(n) >> 23) & 0xffu;
