@@ -10,8 +10,8 @@ WAD can be shipped, so the map is the committed synthetic IWAD (seed 1993) and `
 
 A *step* is ONE PASS OVER THE WHOLE 1 000-FRAME PATH: four batches of `--batch` consecutive frames, each going through
 the complete hot path of SURVEY.md §8(d) — host BSP walk / clip / projection / record generation on the ctx's host
-threads, pinned staging, H2D, the device column walk (dg_fe_*), dg_resolve_columns and the strip rasteriser
-(dg_raster_strips, dg_raster_strips_ov, dg_overlay_strips) — leaving 1 000 RGB24 frames in HBM.  The batches are
+threads, pinned staging, H2D, the device column walk (dg_fe_*) and the tile rasteriser dg_raster_tiles (with DOOMGPU_STRIPS=1:
+dg_resolve_columns + dg_raster_strips + dg_raster_tile_list instead) — leaving 1 000 RGB24 frames in HBM.  The batches are
 pipelined over the ctx's slots: the host builds batch i + 1 while the GPU renders batch i.  `value` = frames / time over
 exactly K steps.  This is what the reference's `Renderer::render()` (src/renderer/mod.rs:118-136) does per frame, with
 `pixels.pixels` left in device memory; the rate with every frame also copied to host memory is `e2e_host_frames` (PCIe
@@ -24,9 +24,9 @@ torch.distributed (gloo, CPU tensors) is used only for the timing barrier, the M
 report; value = sum of frames / max time (weak scaling).  Each rank pins its host threads to its share of the CPUs
 (the NUMA node of its GPU when the topology is readable) before anything touches HIP.
 
-roofline: the strip rasteriser (dg_resolve_columns + dg_raster_strips + dg_raster_strips_ov + dg_overlay_strips, launched
-back to back by one call), HBM-bound model.  achieved = algorithmic bytes per launch / mean duration from HIP events recorded
-on the kernels' own stream during the timed steps (dg_slot_timing).  Algorithmic bytes per frame = 3*W*H (RGB24 stored
+roofline: the dominant kernel, dg_raster_tiles (one launch per batch; or the strip launch group when DOOMGPU_STRIPS=1), HBM-bound
+model.  achieved = algorithmic bytes per launch / mean duration from HIP events recorded on the kernel's own stream during the
+timed steps (dg_slot_timing).  Algorithmic bytes per frame = 3*W*H (RGB24 stored
 once) + W*H (one texel byte per pixel) + list bytes read (32 B per span, 4*(W+1) column index) — SURVEY.md §8d,
 DESIGN.md "Roofline accounting".
 cpu_baseline: the CPU oracle (oracle/doomref.c, a port of the reference renderer) on 1 host core over a bounded
@@ -301,7 +301,7 @@ def run(args, backend_factory=DoomGpuBackend):
         sync_all()
         rs = dist_max(time.perf_counter() - t1, dist)
         resident = {"value": aggregate_fps(nrep * B, world, rs), "unit": "frames/s",
-                    "includes": "device column walk + resolve + strip rasteriser on per-seg / per-sprite records already resident in HBM"}
+                    "includes": "device column walk + rasteriser on per-seg / per-sprite records already resident in HBM"}
         # the rasteriser with nothing else on the GPU: replays with a wait in between
         for i in range(2 * n_slots):
             ctx.replay(i % n_slots)
@@ -326,7 +326,8 @@ def run(args, backend_factory=DoomGpuBackend):
             traffic = json.load(open(tpath)).get(f"{W}x{H}x{B}", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"kernel": "strip rasteriser: dg_resolve_columns + dg_raster_strips + dg_raster_strips_ov + dg_overlay_strips (one launch group)",
+    strip_path = float(np.mean(strips_ms)) > 0.0
+    roofline = {"kernel": "strip path: dg_resolve_columns + dg_raster_strips + dg_raster_tile_list (one launch group)" if strip_path else "dg_raster_tiles",
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                 "algorithmic_bytes_per_launch": float(np.mean(alg_bytes)), "mean_launch_ms": mean_raster_s * 1e3,
                 "strip_kernels_only_ms": float(np.mean(strips_ms)), "front_end_kernels_mean_ms": float(np.mean(setup_ms)),

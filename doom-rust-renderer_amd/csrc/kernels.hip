@@ -68,13 +68,20 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) { return (uint32
 //      factor 0.0 -> exactly 0,0,0).
 // No pixel is evaluated twice except under step B's overlays; nothing depends on the order of evaluation but B.
 
-// One byte from a plane of the scene, address = scalar base + 32-bit lane offset, waited for here.
-__device__ __forceinline__ uint32_t gather_u8(const uint8_t *base, uint32_t o) {
-    uint32_t v;
-    asm volatile("global_load_ubyte %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(o), "s"(base) : "memory");
-    return v;
+// shade_f with bit 31 of the result set: "an overlay wrote this pixel" (the tile read-out ignores the top byte).
+__device__ __forceinline__ uint32_t shade_f_marked(const float4 c, float factor) {
+    const float r = c.x * factor, g = c.y * factor, b = c.z * factor;
+    uint32_t o;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %1, 0, %4\n\t"
+                 "v_cvt_pk_u8_f32 %0, %2, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %3, 2, %0\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(o) : "v"(r), "v"(g), "v"(b), "s"(0x80000000u));
+    return o;
 }
-// Both planes of one texel (palette index, opacity) with one round trip.
+
+// Both planes of one texel (palette index, opacity) with one round trip: address = scalar base + 32-bit lane offset, waited for here.
 __device__ __forceinline__ void gather_u8x2(const uint8_t *base0, const uint8_t *base1, uint32_t o, uint32_t &v0, uint32_t &v1) {
     asm volatile("global_load_ubyte %0, %2, %3\n\tglobal_load_ubyte %1, %2, %4\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(v0), "=&v"(v1) : "v"(o), "s"(base0), "s"(base1) : "memory");
@@ -185,9 +192,11 @@ __device__ __forceinline__ const uint4 *span_at(const uint4 *staged, uint32_t of
     return reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(staged) + off);
 }
 
-// Possibly-transparent spans in draw order (m_wall: which of them are bitmap columns; the others are sky-with-holes spans).
-__device__ __forceinline__ void overlay_loop(const RasterParams &P, const float4 *palf, const uint4 *staged, unsigned long long m, unsigned long long m_wall,
-                                             uint32_t v_lo, uint32_t v_rg, uint32_t v_off, const RowConsts &R, uint32_t winner, uint32_t &color, bool &done) {
+// Possibly-transparent spans in draw order (m_wall: which of them are bitmap columns; the others are sky-with-holes spans).  A
+// written pixel carries bit 31 (shade_f_marked); returns the colour so far.  (Fetching two spans' texels per trip without exec
+// masking was measured: slower at 1280x800 — most columns meet one such span — and no faster at 320x200.)
+__device__ __forceinline__ uint32_t overlay_loop(const RasterParams &P, const float4 *palf, const uint4 *staged, unsigned long long m, unsigned long long m_wall,
+                                                 uint32_t v_lo, uint32_t v_rg, uint32_t v_off, const RowConsts &R, uint32_t winner, uint32_t color) {
     while (m) {
         const int j = take_lowest(m);
         const uint32_t off = bcast(v_off, j);
@@ -205,20 +214,18 @@ __device__ __forceinline__ void overlay_loop(const RasterParams &P, const float4
             }
             uint32_t tex, opq;
             gather_u8x2(P.scene.texel_idx, P.scene.texel_opq, o, tex, opq);
-            const uint32_t c = shade_f(palf[tex], factor);
-            const bool hit = opq != 0u && (wall || factor != 0.0f);
-            color = hit ? c : color;
-            done = done || hit;
+            const uint32_t c = shade_f_marked(palf[tex], factor);
+            color = (opq != 0u && (wall || factor != 0.0f)) ? c : color;
         }
     }
+    return color;
 }
 
 // Every row evaluates its owner.  The scalar instruction stream is what this kernel is short of (profiles/r02_raster_tiles.md), so
 // there is no divergent control flow here: a kind that some row of the wave needs is computed by ALL 64 lanes (on words of another
 // kind the arithmetic is garbage but harmless) and each lane then selects — two uniform branches and a few selects instead of
 // nested exec-mask regions.  The gather comes after the select, so every address is that of the lane's real owner.
-__device__ __forceinline__ uint32_t shade_winner(const RasterParams &P, const DevFrame &fr, const float4 *palf, const uint4 *staged, uint32_t winner,
-                                                 const RowConsts &R) {
+__device__ __forceinline__ uint32_t owner_texel(const DevFrame &fr, const uint4 *staged, uint32_t winner, const RowConsts &R, float &factor_out) {
     const uint4 a = span_at(staged, winner)[0], b = span_at(staged, winner)[1];
     const bool is_wall = a.x < 0x40000000u, is_sky = (int32_t)a.x < 0;
     const unsigned long long m_wall = __builtin_amdgcn_ballot_w64(is_wall), m_sky = __builtin_amdgcn_ballot_w64(is_sky);
@@ -236,7 +243,8 @@ __device__ __forceinline__ uint32_t shade_winner(const RasterParams &P, const De
         o = is_wall ? wo : o;
         factor = is_wall ? bits_f32(a.w) : factor;
     }
-    return shade_f(palf[gather_u8(P.scene.texel_idx, o)], factor);
+    factor_out = factor;
+    return o;
 }
 
 // One lane's span -> the three values the loops broadcast.
@@ -246,48 +254,39 @@ __device__ __forceinline__ void unpack_span(uint32_t w0, uint32_t off, uint32_t 
     v_off = off;
 }
 
-// A column with any number of spans (lw0 = word 0 of every span of the column, off0 = byte offset of its first span in the staging
-// area): lane i looks at span i of each 64-span chunk, ballots pick the spans touching these rows.
-__device__ __forceinline__ uint32_t raster_column(const RasterParams &P, const DevFrame &fr, const float4 *pal, const uint32_t *lw0,
-                                                  const uint4 *staged, uint32_t off0, uint32_t n, int lane, int y0, const RowConsts &R) {
+// A column is rendered in two stages so that the texel gather of one column is in flight while the next column's owners are worked
+// out (tile_body interleaves them):  stage 1 = the row owners and their (texel offset, light factor);  stage 2 = palette + shade of
+// the gathered texel, then the possibly-transparent spans on top.
+//
+// Stage 1 for a column with any number of spans (lw0 = word 0 of every span of the column, off0 = byte offset of its first span in
+// the staging area): lane i looks at span i of each 64-span chunk, ballots pick the spans touching these rows.
+__device__ __forceinline__ uint32_t big_column_owner(const uint32_t *lw0, uint32_t off0, uint32_t n, int lane, int y0, const RowConsts &R) {
     uint32_t winner = 0;
-    bool any_overlay = false;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + (uint32_t)lane;
         const uint32_t w0v = i < n ? lw0[i] : 0u;
-        const bool hit = i < n && w0_cbot(w0v) >= y0 && w0_ctop(w0v) <= y0 + (TILE_H - 1);
+        const bool hit = i < n && w0_cbot(w0v) >= y0 && w0_ctop(w0v) <= y0 + (TILE_H - 1) && !w0_immediate(w0v);
         uint32_t v_lo, v_rg, v_off;
         unpack_span(w0v, off0 + 32u * i, v_lo, v_rg, v_off);
-        any_overlay |= __ballot(hit && w0_immediate(w0v)) != 0ull;
-        winner = owner_loop(__ballot(hit && !w0_immediate(w0v)), v_lo, v_rg, v_off, R, winner);
+        winner = owner_loop(__ballot(hit), v_lo, v_rg, v_off, R, winner);
     }
-    const uint32_t base_color = shade_winner(P, fr, pal, staged, winner, R);
-    if (!any_overlay) return base_color;
+    return winner;
+}
+// Stage 2 for such a column.
+__device__ __forceinline__ uint32_t big_column_overlays(const RasterParams &P, const float4 *pal, const uint32_t *lw0, const uint4 *staged, uint32_t off0,
+                                                        uint32_t n, int lane, int y0, const RowConsts &R, uint32_t winner, uint32_t base_color) {
     uint32_t color = 0;
-    bool done = false;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + (uint32_t)lane;
         const uint32_t w0v = i < n ? lw0[i] : 0u;
         const bool hit = i < n && w0_cbot(w0v) >= y0 && w0_ctop(w0v) <= y0 + (TILE_H - 1) && w0_immediate(w0v);
+        const unsigned long long m = __ballot(hit);
+        if (!m) continue;
         uint32_t v_lo, v_rg, v_off;
         unpack_span(w0v, off0 + 32u * i, v_lo, v_rg, v_off);
-        overlay_loop(P, pal, staged, __ballot(hit), __ballot(hit && w0_kind(w0v) == SPAN_WALL), v_lo, v_rg, v_off, R, winner, color, done);
+        color = overlay_loop(P, pal, staged, m, __ballot(hit && w0_kind(w0v) == SPAN_WALL), v_lo, v_rg, v_off, R, winner, color);
     }
-    return done ? color : base_color;
-}
-
-// A column with at most 8 spans whose row filter was done by the wave-level pre-filter (tile_body): m_op / m_ov = the lanes that
-// hold an opaque / a possibly-transparent span of THIS column that touches these rows.
-__device__ __forceinline__ uint32_t raster_column_small(const RasterParams &P, const DevFrame &fr, const float4 *pal, unsigned long long m_op,
-                                                        unsigned long long m_ov, unsigned long long m_ovwall, uint32_t v_lo, uint32_t v_rg, uint32_t v_off,
-                                                        const uint4 *staged, const RowConsts &R) {
-    const uint32_t winner = owner_loop(m_op, v_lo, v_rg, v_off, R, 0u);
-    const uint32_t base_color = shade_winner(P, fr, pal, staged, winner, R);
-    if (!m_ov) return base_color;
-    uint32_t color = 0;
-    bool done = false;
-    overlay_loop(P, pal, staged, m_ov, m_ovwall, v_lo, v_rg, v_off, R, winner, color, done);
-    return done ? color : base_color;
+    return (int32_t)color < 0 ? color : base_color;
 }
 
 constexpr int TILE_TS = 65;       // dwords per tile COLUMN in LDS
@@ -305,6 +304,12 @@ struct TileLds {
 
 // One 64 x 64 tile of frame f: columns x0 .., rows y0 ..
 __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int f, int x0, int y0) {
+#ifdef DG_EXP_T_TIMING
+    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define DG_PHASE(k) { const unsigned long long tnow = __builtin_readcyclecounter(); tm[k] += tnow - tprev; tprev = tnow; }
+#else
+#define DG_PHASE(k)
+#endif
     const DevFrame fr = P.frames[f];
     const int W = P.k.W, H = P.k.H;
     const int lane = threadIdx.x & 63;
@@ -349,7 +354,9 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
         L.lspans[0] = make_uint4(0x80000000u, 0u, 0u, 0u);
         L.lspans[1] = make_uint4(0u, 0u, 0u, 0u);
     }
+    DG_PHASE(0)
     __syncthreads();
+    DG_PHASE(1)
 
     int c_lo = 0;
     while (c_lo < TILE_W) {
@@ -390,41 +397,62 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
         const unsigned long long hit_op = __ballot(f_hit && !w0_immediate(f_w0)), hit_ov = __ballot(f_hit && w0_immediate(f_w0));
         const unsigned long long hit_ovwall = __ballot(f_hit && w0_immediate(f_w0) && w0_kind(f_w0) == SPAN_WALL);
         const unsigned long long big = __ballot(f_n > 8u);         // all 8 lanes of a column with more than 8 spans
-        int k8 = 0;
-        unsigned long long colmask = 0xffull;
-        for (int c = c_lo + wave; c < c_hi; c += WAVES, k8 += 8, colmask <<= 8) {
-            uint32_t px;
+        // Two columns in flight per wave: stage 1 of a column and its gather are issued before stage 2 of the column before it.
+        struct Col { uint32_t tex, winner; float factor; };
+        auto stage1 = [&](int k, Col &C) {
+            DG_PHASE(2)
+            const unsigned long long colmask = 0xffull << (8 * k);
             if (big & colmask) {
-                const uint32_t n0 = bcast(f_n0, k8), n = bcast(f_n, k8);
-                px = raster_column(P, fr, L.pal, L.lw0 + n0, L.lspans, 32u * (n0 + 1u), n, lane, y0, R);
+                const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
+                C.winner = big_column_owner(L.lw0 + n0, 32u * (n0 + 1u), n, lane, y0, R);
             } else {
-                px = raster_column_small(P, fr, L.pal, hit_op & colmask, hit_ov & colmask, hit_ovwall, v_lo, v_rg, v_off, L.lspans, R);
+                C.winner = owner_loop(hit_op & colmask, v_lo, v_rg, v_off, R, 0u);
             }
-#ifdef DG_EXP_T_ADDVALU
-            { uint32_t d = px; 
-#pragma unroll
-              for (int q = 0; q < DG_EXP_T_ADDVALU; q++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(d) : "v"(lane));
-              if (d == 0x12345u) px ^= 1u; }
-#endif
-#ifdef DG_EXP_T_ADDSALU
-            { uint32_t d = (uint32_t)c;
-#pragma unroll
-              for (int q = 0; q < DG_EXP_T_ADDSALU; q++) asm volatile("s_add_u32 %0, %0, %1" : "+s"(d) : "s"(k8));
-              if (d == 0x12345u) px ^= 1u; }
-#endif
-#ifdef DG_EXP_T_ADDLDS
-            { uint32_t acc = 0;
-#pragma unroll
-              for (int q = 0; q < DG_EXP_T_ADDLDS; q++) acc += *(volatile uint32_t *)&L.lw0[(lane + q * 64) & (SPAN_CAP - 1)];
-              if (acc == 0x12345u) px ^= 1u; }
-#endif
-            L.tile[c * TILE_TS + lane] = px;
+            const uint32_t o = owner_texel(fr, L.lspans, C.winner, R, C.factor);
+            C.tex = P.scene.texel_idx[o];                    // in flight until stage 2
+            DG_PHASE(3)
+        };
+        auto stage2 = [&](int k, const Col &C) {
+            const unsigned long long colmask = 0xffull << (8 * k);
+            uint32_t px = shade_f(L.pal[C.tex], C.factor);
+            DG_PHASE(4)
+            if (big & colmask) {
+                const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
+                px = big_column_overlays(P, L.pal, L.lw0 + n0, L.lspans, 32u * (n0 + 1u), n, lane, y0, R, C.winner, px);
+            } else if (hit_ov & colmask) {
+                // (issuing the first such span's texel fetch in stage 1, unmasked, was measured: slower — 0.60 against 0.57 ms)
+                const uint32_t color = overlay_loop(P, L.pal, L.lspans, hit_ov & colmask, hit_ovwall, v_lo, v_rg, v_off, R, C.winner, 0u);
+                px = (int32_t)color < 0 ? color : px;
+            }
+            L.tile[(c_lo + wave + WAVES * k) * TILE_TS + lane] = px;
+            DG_PHASE(5)
+        };
+        const int nk = (c_hi - c_lo - wave + WAVES - 1) / WAVES;     // columns of this chunk that are this wave's
+        Col A, B;
+        if (nk == WAVES) {                                           // a whole tile's worth (the normal case): one loop shape, no conditionals
+            stage1(0, A);                                            // A and B alternate so that an in-flight texel never changes register
+            for (int k = 1; k < WAVES - 1; k += 2) {
+                stage1(k, B);
+                stage2(k - 1, A);
+                stage1(k + 1, A);
+                stage2(k, B);
+            }
+            stage1(WAVES - 1, B);
+            stage2(WAVES - 2, A);
+            stage2(WAVES - 1, B);
+        } else {
+            for (int k = 0; k < nk; k++) {
+                stage1(k, A);
+                stage2(k, A);
+            }
         }
 
         c_lo = c_hi;
         if (c_lo < TILE_W) __syncthreads();   // before the staging area is reused
     }
+    DG_PHASE(2)
     __syncthreads();
+    DG_PHASE(6)
 
     // Read-out: groups of 4 pixels of a row (4 LDS words -> 12 B of RGB24), 16 groups per tile row; the 64 lanes of a wave take
     // 4 rows x 16 groups in an order that is conflict-free in LDS; 8 adjacent lanes write 96 contiguous bytes.
@@ -443,6 +471,12 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
             dst[2] = ((p2 >> 16) & 0xffu) | (p3 << 8);
         }
     }
+#ifdef DG_EXP_T_TIMING
+    DG_PHASE(7)
+    if (lane == 0 && f == 100 && (x0 / TILE_W) % 5 == 2 && (y0 / TILE_H) % 4 == 1)
+        printf("[tile %d,%d wave %d] load+stage %llu barrier %llu between %llu stage1 %llu gather+shade %llu overlays+write %llu end-barrier %llu readout %llu\n", x0 / TILE_W,
+               y0 / TILE_H, wave, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7]);
+#endif
 }
 
 // Every tile of every frame (the strip path is off, or a batch is redone because a column exceeded the segment slots).
