@@ -454,7 +454,7 @@ def host_frames_rate(args, be, ctx, n_slots, views, B, batches_per_step, barrier
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=800)

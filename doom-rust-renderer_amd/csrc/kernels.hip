@@ -290,6 +290,7 @@ __device__ __forceinline__ uint32_t big_column_overlays(const RasterParams &P, c
 }
 
 constexpr int TILE_TS = 65;       // dwords per tile COLUMN in LDS
+constexpr int PACK_ROWS = 8;      // a tile with no more live rows than this is rendered eight columns per wavefront pass
 
 struct TileLds {
     uint32_t tile[TILE_W * TILE_TS];        // [col][row]: conflict-free for lane = row writes
@@ -332,16 +333,26 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
         sb = gspans[2 * ((size_t)t_first + threadIdx.x) + 1];
     }
     const uint4 rt = P.row_tab[y < H ? y : H - 1];                    // prepared reciprocal of vy and the sky row (dg_row_table)
+    // A tile with at most 8 live rows (the last tile row of a 200-row frame): a wave can take all eight of its columns in ONE pass,
+    // lane = (column, row) = (lane >> 3, lane & 7).  Its row constants:
+    const bool few_rows = H - y0 <= PACK_ROWS;
+    const int yp = y0 + (lane & (PACK_ROWS - 1));
+    uint4 rtp = make_uint4(0u, 0u, 0u, 0u);
+    if (few_rows) rtp = P.row_tab[yp < H ? yp : H - 1];
     const uint32_t pal_v = P.scene.palette[threadIdx.x & 255];
     const int xc = x0 + (int)(threadIdx.x <= TILE_W ? threadIdx.x : 0);
     const uint32_t coff_v = coff[xc < W ? xc : W];
-    RowConsts R;
-    R.y = y;
-    R.vy = P.k.CFY - (float)y;
-    R.r_vy = bits_f32(rt.x);
-    R.row_fast = R.vy != 0.0f ? 0x100u : 0u;
-    R.sky_row = (int)rt.y < 0 ? 0u : rt.y;
-    R.sky_fac = (int)rt.y < 0 ? 0.0f : 1.0f;
+    auto row_consts = [&](int yy, const uint4 t) {
+        RowConsts r;
+        r.y = yy;
+        r.vy = P.k.CFY - (float)yy;
+        r.r_vy = bits_f32(t.x);
+        r.row_fast = r.vy != 0.0f ? 0x100u : 0u;
+        r.sky_row = (int)t.y < 0 ? 0u : t.y;
+        r.sky_fac = (int)t.y < 0 ? 0.0f : 1.0f;
+        return r;
+    };
+    const RowConsts R = row_consts(y, rt);
     if (threadIdx.x < 256) L.pal[threadIdx.x] = make_float4((float)(pal_v & 255u), (float)((pal_v >> 8) & 255u), (float)((pal_v >> 16) & 255u), 0.0f);
     if (threadIdx.x <= TILE_W) L.lcoff[threadIdx.x] = coff_v;
     if (mine) {
@@ -397,6 +408,28 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
         const unsigned long long hit_op = __ballot(f_hit && !w0_immediate(f_w0)), hit_ov = __ballot(f_hit && w0_immediate(f_w0));
         const unsigned long long hit_ovwall = __ballot(f_hit && w0_immediate(f_w0) && w0_kind(f_w0) == SPAN_WALL);
         const unsigned long long big = __ballot(f_n > 8u);         // all 8 lanes of a column with more than 8 spans
+        const int nk = (c_hi - c_lo - wave + WAVES - 1) / WAVES;     // columns of this chunk that are this wave's
+        if (few_rows && nk == WAVES && (hit_ov | big) == 0ull) {
+            // ---- eight columns x eight rows in one pass.  Lane (k, r) owns row r of the wave's column k; that column's spans sit in the
+            // eight lanes of its own group (the pre-filter's layout), so the owner search is eight lane-permutes of one packed word
+            // (first row | row count - 1 << 16; a span that does not count can never match).
+            const RowConsts Rp = row_consts(yp, rtp);
+            const uint32_t mine_word = (f_hit && !w0_immediate(f_w0)) ? (v_lo | (v_rg << 16)) : 0x0000ffffu;
+            const uint32_t off_first = v_off - 32u * (uint32_t)fslot;          // staging offset of the column's first span
+            uint32_t winner = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & ~7) + j) * 4, (int)mine_word);
+                winner = ((uint32_t)Rp.y - (w & 0xffffu)) <= (w >> 16) ? off_first + 32u * (uint32_t)j : winner;
+            }
+            float factor;
+            const uint32_t o = owner_texel(fr, L.lspans, winner, Rp, factor);
+            const uint32_t px = shade_f(L.pal[P.scene.texel_idx[o]], factor);
+            L.tile[(c_lo + wave + WAVES * fk) * TILE_TS + fslot] = px;
+            c_lo = c_hi;
+            if (c_lo < TILE_W) __syncthreads();
+            continue;
+        }
         // Two columns in flight per wave: stage 1 of a column and its gather are issued before stage 2 of the column before it.
         struct Col { uint32_t tex, winner; float factor; };
         auto stage1 = [&](int k, Col &C) {
@@ -427,7 +460,6 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
             L.tile[(c_lo + wave + WAVES * k) * TILE_TS + lane] = px;
             DG_PHASE(5)
         };
-        const int nk = (c_hi - c_lo - wave + WAVES - 1) / WAVES;     // columns of this chunk that are this wave's
         Col A, B;
         if (nk == WAVES) {                                           // a whole tile's worth (the normal case): one loop shape, no conditionals
             stage1(0, A);                                            // A and B alternate so that an in-flight texel never changes register
@@ -479,8 +511,9 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
 #endif
 }
 
+// (launch bounds: 8 waves per SIMD = at most 64 VGPRs; one more register costs a fourth of the resident workgroups, 0.58 -> 0.67 ms)
 // Every tile of every frame (the strip path is off, or a batch is redone because a column exceeded the segment slots).
-__global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
+__global__ __launch_bounds__(THREADS, 8) void dg_raster_tiles(RasterParams P) {
     __shared__ __attribute__((aligned(16))) TileLds L;
     tile_body(P, L, (int)blockIdx.z, (int)blockIdx.x * TILE_W, (int)blockIdx.y * TILE_H);
 }
@@ -489,7 +522,7 @@ __global__ __launch_bounds__(THREADS) void dg_raster_tiles(RasterParams P) {
 // winner of a pixel depends on texels and dg_raster_strips therefore does not go.  The list length is only known on the device:
 // the grid covers the longest possible list and the surplus workgroups leave at once.  (A persistent-workgroup version that
 // pulled tiles off a shared counter was bound by that counter: same-address device-scope atomics cost ~11 ns each.)
-__global__ __launch_bounds__(THREADS) void dg_raster_tile_list(RasterParams P) {
+__global__ __launch_bounds__(THREADS, 8) void dg_raster_tile_list(RasterParams P) {
     __shared__ __attribute__((aligned(16))) TileLds L;
     if (blockIdx.x >= P.tile_counters[0]) return;
     const uint32_t t = P.tile_list[blockIdx.x];
