@@ -127,6 +127,7 @@ _SIGNATURES = {
     "dg_readback": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "dg_readback_async": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "dg_ctx_fallbacks": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    "dg_ctx_redone_frames": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64)]),
     "dg_frame_checksums": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     "dg_alloc_host": (_P, [ctypes.c_size_t]),
     "dg_free_host": (None, [_P]),
@@ -297,9 +298,10 @@ class Context:
         _check(lib().dg_readback_async(self._h, slot, first, count, _P(host_ptr)))
 
     def fallbacks(self) -> dict:
-        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        a, b, f = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
         _check(lib().dg_ctx_fallbacks(self._h, ctypes.byref(a), ctypes.byref(b)))
-        return {"front_end": a.value, "segments": b.value}
+        _check(lib().dg_ctx_redone_frames(self._h, ctypes.byref(f)))
+        return {"front_end": a.value, "segments": b.value, "redone_frames": f.value}
 
     def readback_into(self, slot: int, first: int, count: int, host_ptr: int):
         _check(lib().dg_readback(self._h, slot, first, count, _P(host_ptr)))

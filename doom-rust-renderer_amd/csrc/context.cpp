@@ -198,6 +198,9 @@ struct dg_ctx {
     bool fe_enabled = false;            // cfg.front_end asks for it
     bool fe_scene_ok = false;           // ... and the uploaded scene allows it (sky bitmap >= 256x128, see bin_frame)
     uint64_t fallbacks_fe = 0, fallbacks_seg = 0;   // batches redone because a device-side capacity was exceeded (dg_ctx_fallbacks)
+    uint64_t redone_frames = 0;         // frames redone through the host list path, one at a time (dg_ctx_redone_frames)
+    DevRSpan *d_redo_rspans = nullptr;  // resolved spans of ONE frame being redone (allocated on first use)
+    size_t redo_span_cap = 0;
     std::vector<FeFrameOut> fe_out;     // one per frame of a batch
     uint32_t fe_col_slots = FE_DEFAULT_COL_SLOTS;
     size_t fe_part_cap = 0, fe_sprite_cap = 0, fe_behind_cap = 0, fe_bin_cap = 0, fe_sbin_cap = 0, fe_slab_cap = 0;
@@ -244,6 +247,7 @@ void free_ctx(dg_ctx *c) {
     if (c->d_texel_opq) (void)hipFree(c->d_texel_opq);
     if (c->d_pool) (void)hipFree(c->d_pool);
     if (c->d_row_tab) (void)hipFree(c->d_row_tab);
+    if (c->d_redo_rspans) (void)hipFree(c->d_redo_rspans);
     if (c->d_checksums) (void)hipFree(c->d_checksums);
     if (c->d_fe_cnt) (void)hipFree(c->d_fe_cnt);
     if (c->d_fe_cspans) (void)hipFree(c->d_fe_cspans);
@@ -487,6 +491,55 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
     return DG_OK;
 }
 
+// One frame of a device-column-walk batch again, through the host list path, into its place in the slot's framebuffer.  The
+// slot's own prepared state (records, column index, resolved spans of the other frames) is not touched: the host list slab of
+// the slot, unused in device mode, carries the one frame, its resolved spans go to a ctx-wide scratch.  Returns DG_ERR_CAPACITY
+// when the frame does not fit that scratch (the caller then redoes the whole batch).
+int redo_frame_host(dg_ctx *c, Slot &s, int i) {
+    const Scene &sc = *c->scene;
+    const int W = c->cfg.width, H = c->cfg.height;
+    BinnedFrame &bf = c->binned[0];
+    std::string err;
+    dg_view v = s.views[(size_t)i];
+    fill_view_trig(v);
+    dg_frame_lists fl;
+    int rc = build_frame_lists(sc, W, H, v, *c->arenas[0], fl, err, s.states.empty() ? nullptr : &s.states[(size_t)i]);
+    if (!rc) rc = bin_frame(sc, c->fk, fl, bf, err);
+    if (rc) return set_err(rc, "frame " + std::to_string(i) + ": " + err);
+    bf.hdr.span_base = 0; bf.hdr.wall_base = 0; bf.hdr.plane_base = 0;
+    const size_t off_col = align_up(sizeof(DevFrame), 256);
+    const size_t off_walls = align_up(off_col + (size_t)(W + 1) * 4, 256);
+    const size_t off_planes = align_up(off_walls + bf.walls.size() * sizeof(DevWallRec), 256);
+    const size_t off_spans = align_up(off_planes + bf.planes.size() * sizeof(DevPlaneRec), 256);
+    const size_t total = off_spans + bf.spans.size() * sizeof(DevSpan);
+    if (total > s.lists_cap) return DG_ERR_CAPACITY;
+    if (!c->d_redo_rspans) {
+        c->redo_span_cap = (size_t)W * 64;                                   // 64 spans per column on average: far beyond any real frame
+        if (hipMalloc((void **)&c->d_redo_rspans, c->redo_span_cap * sizeof(DevRSpan)) != hipSuccess) { c->d_redo_rspans = nullptr; return DG_ERR_CAPACITY; }
+    }
+    if (bf.spans.size() > c->redo_span_cap) return DG_ERR_CAPACITY;
+    std::memcpy(s.h_lists, &bf.hdr, sizeof(DevFrame));
+    std::memcpy(s.h_lists + off_col, bf.col_off.data(), (size_t)(W + 1) * 4);
+    if (!bf.walls.empty()) std::memcpy(s.h_lists + off_walls, bf.walls.data(), bf.walls.size() * sizeof(DevWallRec));
+    if (!bf.planes.empty()) std::memcpy(s.h_lists + off_planes, bf.planes.data(), bf.planes.size() * sizeof(DevPlaneRec));
+    if (!bf.spans.empty()) std::memcpy(s.h_lists + off_spans, bf.spans.data(), bf.spans.size() * sizeof(DevSpan));
+    HIP_TRY(hipMemcpyAsync(s.d_lists, s.h_lists, total, hipMemcpyHostToDevice, s.stream));
+    RasterParams Q = s.P;
+    Q.frames = reinterpret_cast<const DevFrame *>(s.d_lists);
+    Q.col_off = reinterpret_cast<const uint32_t *>(s.d_lists + off_col);
+    Q.walls = reinterpret_cast<const DevWallRec *>(s.d_lists + off_walls);
+    Q.planes = reinterpret_cast<const DevPlaneRec *>(s.d_lists + off_planes);
+    Q.spans = reinterpret_cast<const DevSpan *>(s.d_lists + off_spans);
+    Q.rspans = c->d_redo_rspans;
+    Q.fb = s.d_fb + (size_t)i * (size_t)3 * (size_t)W * (size_t)H;
+    Q.n_frames = 1;
+    Q.strips = 0;
+    HIP_TRY(launch_setup(Q, (uint32_t)bf.spans.size(), s.stream));
+    HIP_TRY(launch_raster(Q, s.stream));
+    HIP_TRY(hipStreamSynchronize(s.stream));                                 // the host slab is reused by the next frame
+    return DG_OK;
+}
+
 // After the slot's stream has been synchronised: look at the overflow flags of a device-column-walk submission; a batch
 // that overflowed a per-column / per-frame capacity is redone through the host list path (which has the larger limits).
 int settle_slot(dg_ctx *c, Slot &s) {
@@ -499,8 +552,23 @@ int settle_slot(dg_ctx *c, Slot &s) {
             spans += s.h_status[c->cfg.max_batch + i];
         }
         s.n_spans = spans;
+        bool whole_batch = overflow;
         if (overflow) {
+            // Only the frames that overflowed are redone (through the host list path, one at a time); if one of them does not fit the
+            // single-frame scratch either, or the strip rasteriser still has to vet the batch, the whole batch is.
             c->fallbacks_fe++;
+            if (!s.P.strips) {
+                whole_batch = false;
+                for (int i = 0; i < s.n_frames && !whole_batch; i++) {
+                    if (s.h_status[i] == 0) continue;
+                    const int rc = redo_frame_host(c, s, i);
+                    if (rc == DG_ERR_CAPACITY) whole_batch = true;
+                    else if (rc) return rc;
+                    else c->redone_frames++;
+                }
+            }
+        }
+        if (whole_batch) {
             s.seg_check = false;
             const std::vector<dg_view> views = s.views;
             int rc = build_batch_host(c, s, views.data(), nullptr, (int)views.size(), s.states.empty() ? nullptr : s.states.data());
@@ -847,6 +915,12 @@ int dg_readback_async(dg_ctx *c, int slot, int first, int count, uint8_t *out) {
     return DG_OK;
 }
 
+int dg_ctx_redone_frames(const dg_ctx *c, uint64_t *frames) {
+    if (!c || !frames) return set_err(DG_ERR_INVALID, "null argument");
+    *frames = c->redone_frames;
+    return DG_OK;
+}
+
 int dg_ctx_fallbacks(const dg_ctx *c, uint64_t *front_end, uint64_t *segments) {
     if (!c) return set_err(DG_ERR_INVALID, "null ctx");
     if (front_end) *front_end = c->fallbacks_fe;
@@ -927,8 +1001,8 @@ int dg_prepare_views(dg_ctx *c, int slot, const dg_view *views, int n) {
     s.busy = false; s.fe_check = false;
     rc = build_batch(c, s, views, nullptr, n);
     if (rc) return rc;
-    if (s.fe_mode) {              // run the column walk once so that a capacity overflow is found (and the slot re-prepared
-        rc = enqueue_kernels(c, s);   // through the host list path) now, not on a replay
+    if (s.fe_mode) {              // run the column walk once so that a batch that has to go through the host list path as a whole
+        rc = enqueue_kernels(c, s);   // is re-prepared that way now, not on a replay
         if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(s.stream));
@@ -948,9 +1022,7 @@ int dg_replay_slot(dg_ctx *c, int slot) {
         if (rc) return rc;
     }
     s.P.strips = c->strips ? 1 : 0;   // (a settled overflow switched the slot to dg_raster_tiles: a replay of that batch overflows again)
-    rc = enqueue_kernels(c, s);
-    s.fe_check = false;           // same records as the run that was checked: the flags cannot differ
-    return rc;
+    return enqueue_kernels(c, s);  // (the overflow flags are looked at again: frames that overflowed are redone on every replay)
 }
 
 int dg_draw_lists(dg_ctx *c, int slot, const dg_frame_lists *frames, int n, uint8_t *out) {

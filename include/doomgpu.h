@@ -110,10 +110,18 @@ int dg_create(const dg_config *cfg, dg_ctx **out);
 void dg_destroy(dg_ctx *ctx);
 /* Number of host threads the ctx uses for list generation (after the default / cap has been applied). */
 int dg_ctx_host_threads(const dg_ctx *ctx);
-/* Batches that had to be rendered a second time because a device-side capacity was exceeded: the column scratch of the device
- * column walk (redone through DG_FE_HOST) / the segment slots of the strip rasteriser (redone by the tile rasteriser).  Same
- * pixels either way; a workload that keeps hitting them should raise DOOMGPU_FE_COLUMN_SLOTS / DOOMGPU_SEG_SLOTS. */
+/* Submissions in which a device-side capacity was exceeded: the column scratch of the device column walk (the frames concerned
+ * are redone through the host list path, see dg_ctx_redone_frames) / the segment slots of the strip rasteriser (the batch is
+ * redone by the tile rasteriser).  Same pixels either way; a workload that keeps hitting them should raise
+ * DOOMGPU_FE_COLUMN_SLOTS / DOOMGPU_SEG_SLOTS.
+ * Error reporting differs from the reference in one documented way: BSP subtrees that cannot contribute to the frame are not
+ * walked, so a panic the reference would raise while processing a seg in such a subtree
+ * (segs.rs:140-145,431-436) is not reported as DG_ERR_RENDER; missing texture / flat lookups disable the skipping for the map. */
 int dg_ctx_fallbacks(const dg_ctx *ctx, uint64_t *front_end, uint64_t *segments);
+/* Frames that were redone one at a time through the host list path because THEY overflowed a capacity of the device column walk
+ * (the other frames of their batch were kept); a frame that does not fit the single-frame scratch either makes the whole batch go
+ * through DG_FE_HOST, which dg_ctx_fallbacks counts like every overflow event. */
+int dg_ctx_redone_frames(const dg_ctx *ctx, uint64_t *frames);
 /* Copy palette, texel planes, flats to HBM (immutable per map). The scene must outlive the ctx's use of it. */
 int dg_upload_scene(dg_ctx *ctx, const dg_scene *scene);
 

@@ -386,7 +386,9 @@ def test_device_front_end_capacity_falls_back_to_host_lists(dg, scene1994, oracl
     monkeypatch.delenv("DOOMGPU_FE_COLUMN_SLOTS")
     views = dg.make_views(path1994[idx])
     out = ctx.render(views)
-    assert ctx.timing(0)["front_end"] == dg.DG_FE_HOST
+    fb = ctx.fallbacks()
+    # only the frames that overflowed are redone (one at a time, through the host lists); the batch stays a device-walk batch
+    assert ctx.timing(0)["front_end"] == dg.DG_FE_DEVICE and fb["front_end"] == 1 and 1 <= fb["redone_frames"] <= len(idx), fb
     for k, i in enumerate(idx):
         assert np.array_equal(out[k], np.frombuffer(oracle_scene1994.render(W, H, path1994[i]), dtype=np.uint8).reshape(H, W, 3)), f"frame {i}"
     # asynchronous slots + prepared replays take the same route
@@ -396,7 +398,8 @@ def test_device_front_end_capacity_falls_back_to_host_lists(dg, scene1994, oracl
     ctx.prepare(0, views)
     ctx.replay(0)
     ctx.wait(0)
-    assert np.array_equal(ctx.readback(0, 0, len(idx)), out) and ctx.timing(0)["front_end"] == dg.DG_FE_HOST
+    assert np.array_equal(ctx.readback(0, 0, len(idx)), out) and ctx.timing(0)["front_end"] == dg.DG_FE_DEVICE
+    assert ctx.fallbacks()["front_end"] == 4 and ctx.fallbacks()["redone_frames"] == 4 * fb["redone_frames"]   # render, submit, prepare (it runs the walk once), replay
     ctx.close()
 
 
