@@ -23,6 +23,9 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (contraction would break bit-exactness; the IEEE
 // divide expansion keeps its own internal FMAs, which is what makes it correctly rounded).
+// Experiment builds (make variant VARIANT=x EXTRA="-D..."; never defined in the product build; results in profiles/r02_*.md):
+//   DG_EXP_T_LDSPAD=bytes   pad the tile kernel's LDS (occupancy experiment)      DG_EXP_T_TIMING   per-wave s_memtime phase probe (device printf)
+//   DG_EXP_NOLOAD / DG_EXP_NOSTORE / DG_EXP_NOPAL   strip kernel without texel loads / stores / palette reads
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
