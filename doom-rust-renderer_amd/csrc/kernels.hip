@@ -5,21 +5,22 @@
 //                            (bitmap_render.rs:241-251: 3 f32 divides -> texture column + light factor),
 //                            sky texture column, floor/ceiling vx; merges the span with its record into one
 //                            self-contained 32-byte DevRSpan.
-// Kernel 2  dg_raster_tiles  one workgroup (8 wavefronts) per (frame, 64-column x 64-row tile):
-//                              * the spans of the tile's 64 columns are ONE contiguous range of the column-major span
-//                                array; they are staged in LDS with a single coalesced burst (16 KB), together with the
-//                                palette (1 KB) and the tile's column offsets;
-//                              * a wavefront owns eight of the tile's columns.  One pre-filter pass with lane = (column,
-//                                span slot) finds, for all eight at once, the spans that touch the tile's rows; then the
-//                                wave takes one column at a time with lane = row.  Pass 1 walks the column's touching
-//                                spans in draw order and records per row the last span covering it (one v_readlane per
-//                                span); pass 2 evaluates every row ONCE with its winner's parameters fetched from LDS —
-//                                exact last-writer-wins, no overdraw evaluation, one pass per span kind;
+// Kernel 2  dg_raster_tiles  one workgroup (8 wavefronts) per (frame, 64-column x 64-row tile), lane = row:
+//                              * the spans of the tile's 64 columns are ONE contiguous range of the column-major span array; they
+//                                are staged in LDS in their per-pixel form (stage_tile_span) with a single coalesced burst (16 KB),
+//                                together with the palette (as f32x4) and the tile's column offsets — one barrier;
+//                              * a wavefront owns eight of the tile's columns.  One pre-filter pass with lane = (column, span slot)
+//                                finds, for all eight at once, the spans that touch the tile's rows; then the wave takes one column
+//                                at a time with lane = row, in two stages that overlap between columns: stage 1 walks the column's
+//                                opaque spans in draw order and records per row the last one covering it (three v_readlane per
+//                                span), then every row evaluates its owner ONCE — exact last-writer-wins, no overdraw evaluation, no
+//                                divergent control flow — and issues its texel gather; stage 2 (after stage 1 of the next column)
+//                                shades and lays the possibly-transparent spans (sprites, masked walls) on top;
 //                              * a wall column reads one texture column ([x][y] texel layout => consecutive bytes);
-//                              * finished pixels go to an LDS tile [row][col] and leave the CU as fully
-//                                coalesced 12-byte-per-lane RGB24 row segments (192 B contiguous per tile row).
-//                            Every pixel of the tile is stored (uncovered = 0,0,0) which fuses the reference's
-//                            per-frame `Pixels::new()` clear (pixels.rs:10-14) into the one write pass.
+//                              * finished pixels go to an LDS tile [col][row] and leave the CU as 12-byte-per-lane RGB24 row
+//                                segments.  Every pixel of the tile is stored (uncovered = 0,0,0) which fuses the reference's
+//                                per-frame `Pixels::new()` clear (pixels.rs:10-14) into the one write pass.
+//            dg_resolve_columns / dg_raster_strips / dg_raster_tile_list   the optional strip path (DOOMGPU_STRIPS=1, strip_core.h)
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (contraction would break bit-exactness; the IEEE
 // divide expansion keeps its own internal FMAs, which is what makes it correctly rounded).
