@@ -1,5 +1,6 @@
 """GPU tier: the HIP path, called through the C-ABI, against the oracle (bit-exact RGB24) and the golden fixtures."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -657,3 +658,31 @@ def test_per_view_game_state_in_one_batch(dg, oracle, wad1993, path1993, front_e
     with pytest.raises(dg.DoomGpuError):
         ctx.render_state(views, bad)
     ctx.close()
+
+
+def test_the_eight_rank_paths_of_config_4_on_one_gpu(dg, synth, campath_mod, oracle):
+    """BASELINE config 4 as bench.py shards it: rank r of 8 renders camera path seed 1993 + r on map seed 1993 / 1994 alternating.
+    Here all eight (map, path) pairs on one GPU: 25 frames of each path at 320x200 through the device column walk against the
+    oracle, and two of them at 1280x800 — the frames every rank of the scaling run will produce."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    scenes = {}
+    for rank in range(8):
+        map_seed, path_seed = bench.rank_plan(rank, 8)
+        if map_seed not in scenes:
+            wad = synth.build_synth_iwad(map_seed)
+            scenes[map_seed] = (dg.Scene(wad, "e1m1"), oracle.Scene(wad, "e1m1"), synth.synth_route(map_seed))
+        scene, osc, route = scenes[map_seed]
+        path = campath_mod.make_camera_path(bench.seeded_route(route, path_seed), lambda x, y, d: scene.floor_height_at(x, y, d), bench.PATH_FRAMES)
+        for (W, H, idx) in ((320, 200, list(range(0, 1000, 40))), (1280, 800, [137, 733])):
+            ctx = make_ctx(dg, scene, W, H, len(idx), slots=1, front_end=dg.DG_FE_DEVICE)
+            out = ctx.render(dg.make_views(path[idx]))
+            for k, i in enumerate(idx):
+                ref = np.frombuffer(osc.render(W, H, path[i]), dtype=np.uint8).reshape(H, W, 3)
+                assert np.array_equal(out[k], ref), f"rank {rank} (map {map_seed}, path {path_seed}) frame {i} at {W}x{H}"
+            ctx.close()
+    assert len(scenes) == 2
+    for scene, osc, _ in scenes.values():
+        scene.close()
+        osc.close()
