@@ -43,17 +43,8 @@ __device__ __forceinline__ T unpack_words(uint32_t v) {
 // record is at most 32 dwords: lanes 0-31 fetch an even entry, lanes 32-63 the odd one), so the ~1 us load latency is
 // paid once per 16 records instead of once per record; fn(index, record) is then called for each, in order, with the
 // record broadcast from LDS into scalar registers, until it returns false (wave-uniform).
-#ifdef DG_EXP_FE_TIMING
-#define FE_PHASE(k) { const unsigned long long tnow = __builtin_readcyclecounter(); tm[k] += tnow - tprev; tprev = tnow; }
-#else
-#define FE_PHASE(k)
-#endif
 template <typename T, typename Fn>
-__device__ __forceinline__ void walk_bin(const uint16_t *list, uint32_t n, const T *recs, uint32_t *lrec, int lane, Fn fn
-#ifdef DG_EXP_FE_TIMING
-                                         , unsigned long long *tm, unsigned long long &tprev, int ph
-#endif
-                                         ) {
+__device__ __forceinline__ void walk_bin(const uint16_t *list, uint32_t n, const T *recs, uint32_t *lrec, int lane, Fn fn) {
     constexpr uint32_t NW = (uint32_t)(sizeof(T) / 4);
     static_assert(NW <= 32, "record larger than half a wave");
     for (uint32_t g64 = 0; g64 < n; g64 += 64) {
@@ -69,23 +60,17 @@ __device__ __forceinline__ void walk_bin(const uint16_t *list, uint32_t n, const
             }
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++) lrec[k * 64 + (uint32_t)lane] = v[k];
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            FE_PHASE(ph)
             const uint32_t nh = min(16u, m - g);
             for (uint32_t h = 0; h < nh; h++) {
                 const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane(my, (int)(g + h));
-                if (!fn(idx, unpack_words<T>(lrec[h * 32 + (uint32_t)(lane & 31)]))) { FE_PHASE(ph + 1) return; }
+                if (!fn(idx, unpack_words<T>(lrec[h * 32 + (uint32_t)(lane & 31)]))) return;
             }
-            FE_PHASE(ph + 1)
         }
     }
 }
 
 __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
     __shared__ uint32_t lrec_all[(FE_COL_THREADS / 64) * 16 * 32];
-#ifdef DG_EXP_FE_TIMING
-    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
-#endif
     const int f = blockIdx.y;
     const int W = P.k.W;
     const int x = (int)(blockIdx.x * FE_COL_THREADS + threadIdx.x);
@@ -102,8 +87,6 @@ __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
     const uint32_t part_base = __builtin_amdgcn_readfirstlane(ff.part_base), sprite_base = __builtin_amdgcn_readfirstlane(ff.sprite_base);
 
     FeColumn c = fe_column_start(P, f, x);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    FE_PHASE(0)
 
     // parts in BSP order: the ones whose column range touches this wave's 64 columns (listed by the host)
     walk_bin(P.bin_parts + ff.bin_base + b0, b1 - b0, P.parts + part_base, lrec, lane, [&](uint32_t pi, const FePart &p) {
@@ -121,28 +104,14 @@ __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
         // Once every column of the wave is horizontally occluded nothing behind can draw, clip or add a visplane entry
         // (segs.rs:211,337-341): the rest of the bin only yields flush events, which is what the event words are preset to.
         return __ballot(active && !c.hor) != 0;
-    }
-#ifdef DG_EXP_FE_TIMING
-    , tm, tprev, 1
-#endif
-    );
+    });
     // then the sprites (their clip arrays need the finished wall-record columns of this screen column)
     walk_bin(P.sbin_sprites + ff.sbin_base + s0, s1 - s0, P.sprites + sprite_base, lrec, lane, [&](uint32_t si, const FeSprite &s) {
         if (active && x >= s.x0 && x < s.x1) fe_sprite_column(P, f, ff, s, si, c);
         return true;
-    }
-#ifdef DG_EXP_FE_TIMING
-    , tm, tprev, 3
-#endif
-    );
+    });
     if (active) P.cnt[(size_t)f * (size_t)W + (size_t)x] = c.nsp;
     if (c.ovf) atomicOr(&P.flags[f], c.ovf);
-#ifdef DG_EXP_FE_TIMING
-    FE_PHASE(5)
-    if (lane == 0 && f == 100 && (threadIdx.x >> 6) == 1)
-        printf("[fe bin %u] parts %u sprites %u | prologue %llu part-staging %llu part-walk %llu sprite-staging %llu sprite-walk %llu tail %llu\n", bin, b1 - b0, s1 - s0,
-               tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
-#endif
 }
 
 // One wave per (frame, sky part): the zero-filled entries of sky visplanes draw one sky pixel at row 0
