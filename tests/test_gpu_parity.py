@@ -404,11 +404,11 @@ def test_device_front_end_capacity_falls_back_to_host_lists(dg, scene1994, oracl
     ctx.close()
 
 
-@pytest.mark.parametrize("seed,heavy,quirks", [(1993, False, False), (1994, True, False), (1993, False, True), (1995, False, False)])
+@pytest.mark.parametrize("seed,heavy,quirks", [(1993, False, False), (1994, True, False), (1993, False, True), (1995, False, False), (1996, True, False)])
 def test_random_views_device_walk_equals_host_lists(dg, synth, campath_mod, oracle, seed, heavy, quirks):
     """2 000 random viewpoints per map (inside and outside the map, any heading, several eye heights) through both front
     ends at two sizes: identical frames, and every 40th one also against the oracle."""
-    wad = synth.build_synth_iwad(seed=seed, heavy=heavy, quirks=quirks, vanilla=(seed == 1995))
+    wad = synth.build_synth_iwad(seed=seed, heavy=heavy, quirks=quirks, vanilla=(seed >= 1995))   # 1995 / 1996: vanilla-shaped, 1996 at the heavy size
     scene = dg.Scene(wad, "e1m1")
     osc = oracle.Scene(wad, "e1m1")
     rng = np.random.default_rng(seed + 23)

@@ -132,6 +132,28 @@ def test_host_lists_and_kernel_bodies_reproduce_oracle_vanilla_shaped(oracle_sce
         assert es.render(W, H, rec)[0] == ref, f"view {j}"
 
 
+def test_heavy_vanilla_shaped_map_without_fixtures(synth, oracle, campath_mod):
+    """Seed 1996: the vanilla-shaped generator at the heavy size (192 rooms, 300 things) — no committed goldens, the three CPU paths
+    (oracle, host lists + kernel bodies, device-walk emulation) against each other on path frames and random viewpoints."""
+    wad = synth.build_synth_iwad(1996, heavy=True, vanilla=True)
+    sc = oracle.Scene(wad, "e1m1")
+    es = emul_bind.EmulScene(wad, "e1m1")
+    path = campath_mod.make_camera_path(synth.synth_route(1996, heavy=True, vanilla=True), lambda x, y, d: sc.floor_height_at(x, y, d), 1000)
+    recs = [path[i] for i in range(0, 1000, 37)]
+    rng = np.random.default_rng(1996)
+    recs += [campath_mod.view_record(float(rng.uniform(-100, 8400)), float(rng.uniform(-100, 6400)), float(rng.uniform(-7, 7)),
+                                     float(rng.choice([-64, -8, 0, 24, 200]))) for _ in range(60)]
+    for j, rec in enumerate(recs):
+        try:
+            ref = sc.render(320, 200, rec)
+        except RuntimeError:
+            continue
+        a, _ = es.render(320, 200, rec)
+        b, st = es.render_fe(320, 200, rec)
+        assert a == ref and b == ref and st[3] == 0 and st[4] == 1, (j, st)
+    sc.close()
+
+
 def test_host_lists_and_kernel_bodies_reproduce_oracle_heavy(oracle_scene1994, wad1994, path1994):
     es = emul_bind.EmulScene(wad1994)
     for i in range(0, 1000, 20):
