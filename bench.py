@@ -66,6 +66,16 @@ def seeded_route(route, path_seed: int):
     return r[::-1] if (path_seed - 1993) % 2 else r
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def rank_plan(rank: int, world: int):
     """(map seed, path seed) of a rank: paths 1993 + rank, maps alternating."""
     return MAP_SEEDS[rank % len(MAP_SEEDS)] if world > 1 else MAP_SEEDS[0], 1993 + rank
@@ -381,7 +391,7 @@ def cpu_baseline(args, be, ctx, n_slots, np):
     cpu = {"value": len(idx) / dt, "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": f"every {args.cpu_sample}th frame of the same 1000-frame path at {W}x{H} ({len(idx)} frames, {dt:.1f} s), "
                      "oracle/doomref.c -O2 -ffp-contract=off, cos/sin hoisted per frame",
-           "host_cpus": os.cpu_count()}
+           "host_cpus": os.cpu_count(), "cpu_model": cpu_model()}
     # the same oracle with the sampled frames sharded over the host cores this process may use (one scene per thread: the
     # oracle's lazy texture caches are per scene; ctypes releases the GIL around dr_render)
     try:
