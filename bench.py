@@ -94,6 +94,16 @@ def dist_max(seconds: float, dist) -> float:
     return float(t.item())
 
 
+def dist_all(ok: bool, dist) -> bool:
+    """True when `ok` on every rank (the side measurements are collective: either every rank runs one or none does)."""
+    if dist is None:
+        return ok
+    import torch
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
 def gather_reports(report: dict, dist, world: int):
     if dist is None:
         return [report]
@@ -439,23 +449,30 @@ def host_frames_rate(args, be, ctx, n_slots, views, B, batches_per_step, barrier
     dg = be.dg
     nb = max(2 * n_slots, min(4 * batches_per_step, 16))
     bufs = [dg.lib().dg_alloc_host(B * ctx.frame_bytes) for _ in range(n_slots)]
-    if not all(bufs):
-        return None
     try:
+        if not dist_all(all(bufs), dist):             # a rank that could not page-lock its buffers: nobody measures this mode
+            return None
         for s in range(n_slots):
             ctx.wait(s)
         barrier()
         t2 = time.perf_counter()
-        for i in range(nb):
-            s = i % n_slots
-            ctx.submit(s, views[s])                   # waits for the slot's previous readback if it is still in flight
-            ctx.readback_async(s, 0, B, bufs[s])      # queued behind the slot's kernels on its copy stream
-        for s in range(n_slots):
-            ctx.wait(s)
+        err = None
+        try:
+            for i in range(nb):
+                s = i % n_slots
+                ctx.submit(s, views[s])               # waits for the slot's previous readback if it is still in flight
+                ctx.readback_async(s, 0, B, bufs[s])  # queued behind the slot's kernels on its copy stream
+            for s in range(n_slots):
+                ctx.wait(s)
+        except Exception as e:                        # a side measurement must not take the headline line down with it
+            err = repr(e)
         h_s = dist_max(time.perf_counter() - t2, dist)
+        if not dist_all(err is None, dist):
+            return {"error": err or "failed on another rank"}
     finally:
         for b in bufs:
-            dg.lib().dg_free_host(b)
+            if b:
+                dg.lib().dg_free_host(b)
     return {"value": aggregate_fps(nb * B, world, h_s), "unit": "frames/s",
             "includes": "the headline path + D2H of every RGB24 frame to pinned host memory, copy of batch i overlapped with the kernels of batch i + 1",
             "d2h_GBps": nb * B * ctx.frame_bytes / h_s / 1e9}
