@@ -175,3 +175,22 @@ def test_raster_strips_never_touches_a_texel_in_flight(kernels_asm, mangled):
     assert sum(1 for b in blocks for (m, _) in b["insts"] if m == "global_load_ubyte") >= 2, "the asm texel loads are gone?"
     v = check(blocks)
     assert not v, "\n".join(f"{lab}: {m} {ops}: {why}" for (lab, m, ops, why) in v[:20])
+
+
+def test_tile_rasteriser_keeps_four_workgroups_per_cu():
+    """dg_raster_tiles / dg_raster_tile_list are sized for four resident 8-wave workgroups per CU: at most 64 VGPRs (8 waves per SIMD),
+    no scratch (a spill makes every wave set up scratch), at most 40 KB of LDS (4 x 40 KB = the CU's 160 KB).  Losing one resident
+    workgroup costs 17 % (profiles/r02_raster_tiles.md, occupancy experiment; a 72-VGPR build measured 0.667 against 0.58 ms)."""
+    asm = subprocess.run([HIPCC, *FLAGS, "-S", "--cuda-device-only", "-o", "-", os.path.join(CSRC, "kernels.hip")],
+                         capture_output=True, text=True, check=True).stdout
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm, re.S):
+        name, body = m.group(1), m.group(2)
+        if "dg_raster_tiles" not in name and "dg_raster_tile_list" not in name:
+            continue
+        seen += 1
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        assert vgpr <= 64 and scratch == 0 and lds <= 40960, (name, vgpr, scratch, lds)
+    assert seen == 2
