@@ -633,7 +633,7 @@ int check_slot(dg_ctx *c, int slot) {
 extern "C" {
 
 const char *dg_last_error(void) { return t_err.c_str(); }
-const char *dg_version(void) { return "doomgpu 0.1 (gfx950)"; }
+const char *dg_version(void) { return "doomgpu 0.2 (gfx950)"; }
 
 int dg_scene_load_wad(const uint8_t *wad, size_t len, const char *map_name, dg_scene **out) {
     if (!wad || !map_name || !out) return set_err(DG_ERR_INVALID, "null argument");
