@@ -339,11 +339,13 @@ def run(args, backend_factory=DoomGpuBackend):
     # ---- roofline of the rasteriser --------------------------------------------------------------------------------
     mean_raster_s = float(np.mean(raster_ms)) / 1e3
     achieved = float(np.mean(alg_bytes)) / mean_raster_s / 1e9
-    traffic = None
+    traffic, achievable_fill = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f"{W}x{H}x{B}", {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get(f"{W}x{H}x{B}", {}).get("hbm_bytes_per_launch")
+            achievable_fill = tj.get("_achievable", {}).get("fill_GBps")      # measured on the box with tools/microbench/hbm_copy.py
         except Exception:
             traffic = None
     strip_path = float(np.mean(strips_ms)) > 0.0
@@ -352,6 +354,7 @@ def run(args, backend_factory=DoomGpuBackend):
                 "algorithmic_bytes_per_launch": float(np.mean(alg_bytes)), "mean_launch_ms": mean_raster_s * 1e3,
                 "strip_kernels_only_ms": float(np.mean(strips_ms)), "front_end_kernels_mean_ms": float(np.mean(setup_ms)),
                 "frames_per_launch": B, "pixels_per_s": B * W * H / mean_raster_s,
+                "achievable_write_GBps": achievable_fill, "frac_of_achievable_write": (achieved / achievable_fill) if achievable_fill else None,
                 "note": "achieved/frac are measured over the timed steps, where the next batch's column-walk kernels and H2D overlap these kernels; "
                         "isolated_* is the same launch group measured with nothing else on the GPU"}
     if iso_ms:
