@@ -77,7 +77,7 @@ def _worker(rank, world, port, q):
     dist.barrier()
     slow = bench.dist_max(0.5 + rank, dist)            # rank 1 is the slow one
     # bench.run end to end (rank plan, CPU binding, barriers, timed steps, MAX over ranks, report gather) on a stub context
-    args = bench.parse_args(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    args = bench.parse_args(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch", "250"])
     holder = {}
 
     def factory(a, device):
