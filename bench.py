@@ -8,7 +8,7 @@ Workload (config.workload): BASELINE config 2 — the 1 000-frame scripted camer
 map, rendered natively at 1280x800 (the size the ">= 10 000 fps" target is quoted on), one MI355X per rank.  No id
 WAD can be shipped, so the map is the committed synthetic IWAD (seed 1993) and `data` says "synthetic".
 
-A *step* is ONE PASS OVER THE WHOLE 1 000-FRAME PATH: four batches of `--batch` consecutive frames, each going through
+A *step* is ONE PASS OVER THE WHOLE 1 000-FRAME PATH: 1000 / `--batch` batches (default: two of 500) of consecutive frames, each going through
 the complete hot path of SURVEY.md §8(d) — host BSP walk / clip / projection / record generation on the ctx's host
 threads, pinned staging, H2D, the device column walk (dg_fe_*) and the tile rasteriser dg_raster_tiles (with DOOMGPU_STRIPS=1:
 dg_resolve_columns + dg_raster_strips + dg_raster_tile_list instead) — leaving 1 000 RGB24 frames in HBM.  The batches are
