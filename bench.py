@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — frames/sec of the MI355X rasteriser on the fixed e1m1 camera path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1280 --height 800] [--batch 250]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3,4,5}] [--width W --height H] [--batch 500]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-Workload (config.workload): BASELINE config 2 — the 1 000-frame scripted camera path through the e1m1-like
+Workload (config.workload): by default BASELINE config 3 — the 1 000-frame scripted camera path through the e1m1-like
 map, rendered natively at 1280x800 (the size the ">= 10 000 fps" target is quoted on), one MI355X per rank.  No id
-WAD can be shipped, so the map is the committed synthetic IWAD (seed 1993) and `data` says "synthetic".
+WAD can be shipped, so the maps are the committed synthetic IWADs and `data` says "synthetic" (with --wad FILE the same
+command runs a real IWAD).  --config selects the other BASELINE.json configurations (CONFIGS below): 1 = the Player-1 start
+frame at 320x200, 2 = the path at 320x200, 4 = eight paths over two maps at 1280x800, 5 = the heavy map at 2560x1600.
 
 A *step* is ONE PASS OVER THE WHOLE 1 000-FRAME PATH: 1000 / `--batch` batches (default: two of 500) of consecutive frames, each going through
 the complete hot path of SURVEY.md §8(d) — host BSP walk / clip / projection / record generation on the ctx's host
-threads, pinned staging, H2D, the device column walk (dg_fe_*) and the tile rasteriser dg_raster_tiles (with DOOMGPU_STRIPS=1:
-dg_resolve_columns + dg_raster_strips + dg_raster_tile_list instead) — leaving 1 000 RGB24 frames in HBM.  The batches are
+threads, pinned staging, H2D, the device column walk (dg_fe_*) and the tile rasteriser dg_raster_tiles — leaving 1 000 RGB24
+frames in HBM.  The batches are
 pipelined over the ctx's slots: the host builds batch i + 1 while the GPU renders batch i.  `value` = frames / time over
 exactly K steps.  This is what the reference's `Renderer::render()` (src/renderer/mod.rs:118-136) does per frame, with
 `pixels.pixels` left in device memory; the rate with every frame also copied to host memory is `e2e_host_frames` (PCIe
@@ -24,8 +26,7 @@ torch.distributed (gloo, CPU tensors) is used only for the timing barrier, the M
 report; value = sum of frames / max time (weak scaling).  Each rank pins its host threads to its share of the CPUs
 (the NUMA node of its GPU when the topology is readable) before anything touches HIP.
 
-roofline: the dominant kernel, dg_raster_tiles (one launch per batch; or the strip launch group when DOOMGPU_STRIPS=1), HBM-bound
-model.  achieved = algorithmic bytes per launch / mean duration from HIP events recorded on the kernel's own stream during the
+roofline: the dominant kernel, dg_raster_tiles (one launch per batch), HBM-bound model.  achieved = algorithmic bytes per launch / mean duration from HIP events recorded on the kernel's own stream during the
 timed steps (dg_slot_timing).  Algorithmic bytes per frame = 3*W*H (RGB24 stored
 once) + W*H (one texel byte per pixel) + list bytes read (32 B per span, 4*(W+1) column index) — SURVEY.md §8d,
 DESIGN.md "Roofline accounting".
@@ -44,7 +45,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PATH_FRAMES = 1000
-MAP_SEEDS = (1993, 1994)          # two maps, alternated across ranks (BASELINE config 4: map01 + map07)
+# The synthetic stand-ins of BASELINE.json's maps: (generator seed, heavy).  Seed 1994 heavy = the 16x12-room map with more
+# visplanes and sprites per frame (stand-in for config 4's second map and config 5's e2m1).
+LIGHT_MAP, HEAVY_MAP = (1993, False), (1994, True)
+# BASELINE.json configs -> (name, width, height, frames per batch, maps the ranks alternate between, camera: "path" | "start")
+CONFIGS = {
+    1: ("config 1: e1m1 stand-in at 320x200, the single Player-1 start viewpoint", 320, 200, 1000, (LIGHT_MAP,), "start"),
+    2: ("config 2: e1m1 stand-in at 320x200, 1000-frame scripted camera path", 320, 200, 1000, (LIGHT_MAP,), "path"),
+    3: ("config 3: e1m1 stand-in at 1280x800, 1000-frame scripted camera path", 1280, 800, 500, (LIGHT_MAP,), "path"),
+    4: ("config 4: two maps (map01 + map07 stand-ins) at 1280x800, eight independent camera paths, one per GPU", 1280, 800, 500, (LIGHT_MAP, HEAVY_MAP), "path"),
+    5: ("config 5: heavy map (e2m1 stand-in: more visplanes + sprites) at 2560x1600", 2560, 1600, 125, (HEAVY_MAP,), "path"),
+}
 
 
 def xorshift32(x: int) -> int:
@@ -76,9 +87,15 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def rank_plan(rank: int, world: int):
-    """(map seed, path seed) of a rank: paths 1993 + rank, maps alternating."""
-    return MAP_SEEDS[rank % len(MAP_SEEDS)] if world > 1 else MAP_SEEDS[0], 1993 + rank
+def rank_plan(rank: int, world: int, config: int = 3):
+    """((map seed, heavy), path seed) of a rank: camera paths 1993 + rank, the config's maps alternating over the ranks."""
+    maps = CONFIGS[config][4]
+    return maps[rank % len(maps)], 1993 + rank
+
+
+def pick_device(local_rank: int, visible: int) -> int:
+    """HIP ordinal of a rank: LOCAL_RANK, wrapped when the launcher masked the GPUs per rank (HIP_VISIBLE_DEVICES = one GPU each)."""
+    return local_rank % visible if visible > 0 else local_rank
 
 
 def aggregate_fps(frames_per_rank: int, world: int, max_seconds: float) -> float:
@@ -178,17 +195,22 @@ class DoomGpuBackend:
         self.cp = importlib.import_module("doom-rust-renderer_amd.camera_path")
         self.args, self.device = args, device
 
-    def load(self, map_seed: int, path_seed: int):
+    def load(self, map_id, path_seed: int, camera: str = "path"):
         import numpy as np
         a = self.args
+        map_seed, heavy = map_id
         if a.wad:
             self.wad = open(a.wad, "rb").read()          # a user-supplied IWAD (BASELINE configs verbatim); data = "file"
             route = self.cp.route_from_wad(self.wad, a.map)
         else:
-            self.wad = self.sw.build_synth_iwad(map_seed)
-            route = self.sw.synth_route(map_seed)
+            self.wad = self.sw.build_synth_iwad(map_seed, heavy=heavy)
+            route = self.sw.synth_route(map_seed, heavy=heavy)
         self.scene = self.dg.Scene(self.wad, a.map)
-        self.path = self.cp.make_camera_path(seeded_route(route, path_seed), lambda x, y, d: self.scene.floor_height_at(x, y, d), PATH_FRAMES)
+        if camera == "start":                             # BASELINE config 1: the Player-1 start, Game::new's view (src/game.rs:151-156)
+            x, y, ang = self.scene.player_start()
+            self.path = np.tile(self.cp.view_record(x, y, ang, self.scene.floor_height_at(x, y, 0.0)), (PATH_FRAMES, 1))
+        else:
+            self.path = self.cp.make_camera_path(seeded_route(route, path_seed), lambda x, y, d: self.scene.floor_height_at(x, y, d), PATH_FRAMES)
         B = a.batch
         self.n_slots = max(1, a.slots)                # (with fewer batches per step than slots, a slot holds the same batch every other step)
         fe = self.dg.DG_FE_HOST if a.front_end == "host" else self.dg.DG_FE_DEVICE
@@ -210,11 +232,13 @@ def run(args, backend_factory=DoomGpuBackend):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    device = int(os.environ.get("DOOMGPU_BENCH_DEVICE", local_rank))   # override only to rehearse N > 1 on a 1-GPU box
     cpus, cpu_how = bind_rank_cpus(local_rank, local_world)           # before torch / HIP are touched
 
     # torch first: its bundled HIP runtime must be the one libdoomgpu.so binds to (same soname, loaded once).
     import torch
+    visible = torch.cuda.device_count()                               # counting devices does not initialise HIP on this image
+    device = int(os.environ.get("DOOMGPU_BENCH_DEVICE", pick_device(local_rank, visible)))   # override only to rehearse N > 1 on a 1-GPU box
+    print(f"[bench rank {rank}/{world}] local_rank {local_rank}, {visible} visible GPU(s) -> device {device}; {len(cpus)} CPUs ({cpu_how})", file=sys.stderr, flush=True)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -235,11 +259,12 @@ def run(args, backend_factory=DoomGpuBackend):
 
     import numpy as np
     W, H, B = args.width, args.height, args.batch
-    map_seed, path_seed = rank_plan(rank, world)
+    map_id, path_seed = rank_plan(rank, world, args.config)
+    map_seed = map_id[0]
     be = backend_factory(args, device)
-    ctx = be.load(map_seed, path_seed)
+    ctx = be.load(map_id, path_seed, CONFIGS[args.config][5])
     n_slots, views = be.n_slots, be.views
-    batches_per_step = (PATH_FRAMES + B - 1) // B
+    batches_per_step = PATH_FRAMES // B                # --batch divides the path (parse_args)
     frames_per_step = batches_per_step * B
 
     def sync_all():
@@ -273,13 +298,12 @@ def run(args, backend_factory=DoomGpuBackend):
     sync_all()
     barrier()
     sync_all()
-    raster_ms, strips_ms, setup_ms, host_ms, alg_bytes = [], [], [], [], []
+    raster_ms, setup_ms, host_ms, alg_bytes = [], [], [], []
     stats = {}
 
     def collect(slot):
         t = ctx.timing(slot)
         raster_ms.append(t["raster_ms"])
-        strips_ms.append(t.get("strips_ms", 0.0))
         setup_ms.append(t["setup_ms"])
         host_ms.append(t["host_ms"])
         nf = t["n_frames"]
@@ -307,7 +331,7 @@ def run(args, backend_factory=DoomGpuBackend):
 
     # ---- the kernels alone: records resident in HBM, replayed (no host work, no H2D) --------------------------------
     resident = None
-    iso_ms, iso_strips = [], []
+    iso_ms = []
     if not args.no_resident:
         for s in range(n_slots):
             ctx.prepare(s, views[s])
@@ -332,8 +356,7 @@ def run(args, backend_factory=DoomGpuBackend):
             ctx.wait(i % n_slots)
             t = ctx.timing(i % n_slots)
             iso_ms.append(t["raster_ms"])
-            iso_strips.append(t.get("strips_ms", 0.0))
-        iso_ms, iso_strips = iso_ms[n_slots:], iso_strips[n_slots:]
+        iso_ms = iso_ms[n_slots:]
 
     # ---- every frame also copied to page-locked host memory (what the reference's `pixels.pixels` literally is) -------
     e2e_host = None
@@ -352,21 +375,20 @@ def run(args, backend_factory=DoomGpuBackend):
             achievable_fill = tj.get("_achievable", {}).get("fill_GBps")      # measured on the box with tools/microbench/hbm_copy.py
         except Exception:
             traffic = None
-    strip_path = float(np.mean(strips_ms)) > 0.0
-    roofline = {"kernel": "strip path: dg_resolve_columns + dg_raster_strips + dg_raster_tile_list (one launch group)" if strip_path else "dg_raster_tiles",
+    roofline = {"kernel": "dg_raster_tiles",
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                 "algorithmic_bytes_per_launch": float(np.mean(alg_bytes)), "mean_launch_ms": mean_raster_s * 1e3,
-                "strip_kernels_only_ms": float(np.mean(strips_ms)), "front_end_kernels_mean_ms": float(np.mean(setup_ms)),
+                "front_end_kernels_mean_ms": float(np.mean(setup_ms)),
                 "frames_per_launch": B, "pixels_per_s": B * W * H / mean_raster_s,
                 "achievable_write_GBps": achievable_fill, "frac_of_achievable_write": (achieved / achievable_fill) if achievable_fill else None,
                 "note": "achieved/frac are measured over the timed steps, where the next batch's column-walk kernels and H2D overlap these kernels; "
-                        "isolated_* is the same launch group measured with nothing else on the GPU"}
+                        "isolated_* is the same launch measured with nothing else on the GPU"}
     if iso_ms:
         iso = float(np.mean(iso_ms)) / 1e3
-        roofline.update({"isolated_launch_ms": iso * 1e3, "isolated_strip_kernels_only_ms": float(np.mean(iso_strips)),
+        roofline.update({"isolated_launch_ms": iso * 1e3,
                          "isolated_achieved": float(np.mean(alg_bytes)) / iso / 1e9, "isolated_frac": float(np.mean(alg_bytes)) / iso / 1e9 / 8000.0})
 
-    report = {"rank": rank, "map_seed": map_seed, "path_seed": path_seed, "frames_per_s": args.steps * frames_per_step / elapsed_local,
+    report = {"rank": rank, "map_seed": map_seed, "heavy_map": bool(map_id[1]), "path_seed": path_seed, "device": device, "frames_per_s": args.steps * frames_per_step / elapsed_local,
               "host_ms_per_batch": float(np.mean(host_ms)), "host_threads": getattr(ctx, "host_threads", None), "cpus": len(cpus), "cpu_binding": cpu_how}
     reports = gather_reports(report, dist, world)
 
@@ -377,11 +399,15 @@ def run(args, backend_factory=DoomGpuBackend):
             "metric": "frames/sec (fixed e1m1 camera path)", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "file" if args.wad else "synthetic",
-            "config": {"workload": (f"{os.path.basename(args.wad)} {args.map}" if args.wad else "synthetic e1m1-like IWAD (seed 1993)") +
-                                   f", 1000-frame scripted camera path, {W}x{H} native; one step = the whole path in {batches_per_step} batches of {B} frames through "
+            "config": {"workload": f"BASELINE {CONFIGS[args.config][0]}; " +
+                                   (f"{os.path.basename(args.wad)} {args.map}" if args.wad else
+                                    "synthetic IWAD(s) " + " + ".join(f"seed {m}{' (heavy)' if hv else ''}" for (m, hv) in CONFIGS[args.config][4]) + " (no id WAD in the environment)") +
+                                   f", {W}x{H} native; one step = 1000 frames in {batches_per_step} batches of {B} through "
                                    "host record generation + H2D + all kernels, frames left in HBM (SURVEY 8d)",
+                       "baseline_config": args.config,
                        "front_end": fe_name, "width": W, "height": H, "frames_per_step": frames_per_step, "frames_per_batch": B, "slots": n_slots,
-                       "parallelism": f"{world} independent camera path(s) (seeds 1993..{1993 + world - 1}), one per GPU, maps alternating {list(MAP_SEEDS[:min(world, 2)])}, no collective"},
+                       "parallelism": f"{world} independent camera path(s) (seeds 1993..{1993 + world - 1}), one per GPU, maps alternating over the ranks "
+                                      f"{[m for (m, _) in CONFIGS[args.config][4]]}, no collective"},
             "roofline": roofline, "cpu_baseline": cpu, "resident_replay": resident, "e2e_host_frames": e2e_host,
             "host": {"ms_per_batch": float(np.mean(host_ms)), "threads": getattr(ctx, "host_threads", None),
                      "list_bytes_per_frame": int(stats.get("list_bytes", 0) // max(1, stats.get("n_frames", 1)))},
@@ -435,6 +461,7 @@ def cpu_baseline(args, be, ctx, n_slots, np):
         cpu["all_cores"] = {"error": str(e)}
     # parity of the frames the timed, pipelined steps left in the slots: every sampled frame, byte for byte
     bad = checked = 0
+    distinct = set()
     for s in range(n_slots):
         ctx.wait(s)
         got = ctx.readback(s, 0, B)
@@ -445,7 +472,9 @@ def cpu_baseline(args, be, ctx, n_slots, np):
                 ref = np.frombuffer(refs[k], dtype=np.uint8).reshape(H, W, 3)
                 bad += not np.array_equal(got[j], ref)
                 checked += 1
-    cpu["gpu_frames_checked"] = checked
+                distinct.add(i)
+    cpu["gpu_frames_checked"] = checked               # slot frames compared (with more slots than batches per step a batch sits in two slots)
+    cpu["gpu_distinct_frames_checked"] = len(distinct)
     cpu["gpu_frames_bit_exact"] = bool(bad == 0)
     cpu["gpu_frames_source"] = "the slots as the timed pipelined steps left them"
     return cpu
@@ -494,9 +523,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--height", type=int, default=800)
-    ap.add_argument("--batch", type=int, default=500)
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=3, help="BASELINE.json configuration (1-based); sets width / height / batch / maps")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="frames per batch; must divide the 1000-frame path")
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--front-end", choices=["device", "host"], default="device", help="where the per-column half of the seg / sprite processing runs")
@@ -506,7 +536,14 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resident", action="store_true")
     ap.add_argument("--no-host-frames", action="store_true")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    _, cw, ch, cb, _, _ = CONFIGS[a.config]
+    a.width = a.width or cw
+    a.height = a.height or ch
+    a.batch = a.batch or cb
+    if a.batch <= 0 or PATH_FRAMES % a.batch:
+        ap.error(f"--batch must divide the {PATH_FRAMES}-frame path (a step is one pass over the whole path)")
+    return a
 
 
 def main(argv=None, backend_factory=DoomGpuBackend):

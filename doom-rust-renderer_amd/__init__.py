@@ -57,7 +57,7 @@ class DgTiming(ctypes.Structure):
                 ("host_ms", ctypes.c_float),
                 ("n_spans", ctypes.c_uint64), ("n_frames", ctypes.c_uint64), ("covered_pixels", ctypes.c_uint64),
                 ("n_walls", ctypes.c_uint64), ("n_planes", ctypes.c_uint64), ("list_bytes", ctypes.c_uint64),
-                ("front_end", ctypes.c_int32), ("strips_ms", ctypes.c_float)]
+                ("front_end", ctypes.c_int32)]
 
 
 class DgBitmapColumn(ctypes.Structure):
@@ -126,7 +126,7 @@ _SIGNATURES = {
     "dg_slot_framebuffer": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(_P)]),
     "dg_readback": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     "dg_readback_async": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
-    "dg_ctx_fallbacks": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    "dg_ctx_fallbacks": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64)]),
     "dg_ctx_redone_frames": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint64)]),
     "dg_frame_checksums": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     "dg_alloc_host": (_P, [ctypes.c_size_t]),
@@ -298,10 +298,10 @@ class Context:
         _check(lib().dg_readback_async(self._h, slot, first, count, _P(host_ptr)))
 
     def fallbacks(self) -> dict:
-        a, b, f = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
-        _check(lib().dg_ctx_fallbacks(self._h, ctypes.byref(a), ctypes.byref(b)))
+        a, f = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(lib().dg_ctx_fallbacks(self._h, ctypes.byref(a)))
         _check(lib().dg_ctx_redone_frames(self._h, ctypes.byref(f)))
-        return {"front_end": a.value, "segments": b.value, "redone_frames": f.value}
+        return {"front_end": a.value, "redone_frames": f.value}
 
     def readback_into(self, slot: int, first: int, count: int, host_ptr: int):
         _check(lib().dg_readback(self._h, slot, first, count, _P(host_ptr)))

@@ -33,7 +33,6 @@
 #include "frontend.hpp"
 #include "kernels.hpp"
 #include "scene.hpp"
-#include "strip_core.h"
 
 using namespace dg;
 
@@ -107,9 +106,7 @@ private:
 
 struct Slot {
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_raster = nullptr, ev_rstart = nullptr, ev_resolved = nullptr;
-    hipStream_t tile_stream = nullptr;   // dg_raster_tile_list beside dg_raster_strips
-    hipEvent_t ev_tiles = nullptr;
+    hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_raster = nullptr, ev_rstart = nullptr;
     hipStream_t copy_stream = nullptr;   // dg_readback_async: D2H of this slot's frames while another slot's kernels run
     uint8_t *copy_out = nullptr;         // pending asynchronous readback (re-issued if the batch has to be redone)
     int copy_first = 0, copy_count = 0;
@@ -119,11 +116,6 @@ struct Slot {
     DevRSpan *d_rspans = nullptr;
     uint8_t *d_fb = nullptr;
     size_t lists_cap = 0;
-    // strip path (dg_resolve_columns -> dg_raster_strips): segments [F][seg_cap][W], band index, overlay index, flags
-    DevSeg *d_segs = nullptr;
-    uint8_t *d_band_first = nullptr;
-    uint32_t *d_tile_list = nullptr;                               // [F][n_bands][strips] at most
-    uint32_t *d_frame_flags = nullptr, *h_frame_flags = nullptr;   // device: [F] flags, 2 tile counters, band overlay bytes [F][n_bands][strips]
     // last submission
     RasterParams P{};
     uint32_t max_spans = 0;
@@ -137,7 +129,6 @@ struct Slot {
     uint32_t *d_status = nullptr, *h_status = nullptr;   // [F] overflow flags, [F] spans per frame; on the device followed by the
                                                          // sky event bits (fe_event_words) so that one fill clears both
     FeParams FP{};
-    bool seg_check = false;       // the strip path ran and its per-frame "segment slots exceeded" flags have not been looked at yet
     bool fe_mode = false;         // the last submission went through the device column walk
     bool fe_check = false;        // ... and its overflow flags have not been looked at yet
     std::vector<dg_view> views;   // the views of that submission (to redo it on the host if a capacity overflowed)
@@ -177,12 +168,6 @@ struct dg_ctx {
     // device scene
     uint32_t *d_palette = nullptr;
     uint8_t *d_texel_idx = nullptr, *d_texel_opq = nullptr, *d_flats = nullptr;
-    uint8_t *d_pool = nullptr;          // row-major texel plane + flats, the strip rasteriser's texel source
-    bool strips = false;                // DOOMGPU_STRIPS=1: dg_resolve_columns + dg_raster_strips + dg_raster_tile_list instead of dg_raster_tiles alone.
-                                        // Measured on the benchmark scene (a third of its tiles hold masked walls / sprites) the two are
-                                        // equal at 1280x800 and the tile rasteriser alone is faster at 320x200 (profiles/r02_strip_rasteriser.md).
-    int seg_cap = 32, band_rows = 1, n_bands = 1;
-    bool side_tiles = true;             // ... on their own stream beside dg_raster_strips (DOOMGPU_SIDE_TILES=0: behind it)
     unsigned long long *d_checksums = nullptr;   // dg_frame_checksums scratch, max_batch entries
     uint4 *d_row_tab = nullptr;         // per-row constants of the flat / sky mappers (dg_row_table), rebuilt per scene upload
     DevScene dscene{};
@@ -197,7 +182,7 @@ struct dg_ctx {
     // device column walk
     bool fe_enabled = false;            // cfg.front_end asks for it
     bool fe_scene_ok = false;           // ... and the uploaded scene allows it (sky bitmap >= 256x128, see bin_frame)
-    uint64_t fallbacks_fe = 0, fallbacks_seg = 0;   // batches redone because a device-side capacity was exceeded (dg_ctx_fallbacks)
+    uint64_t fallbacks_fe = 0;          // batches in which frames were redone because a device-side capacity was exceeded (dg_ctx_fallbacks)
     uint64_t redone_frames = 0;         // frames redone through the host list path, one at a time (dg_ctx_redone_frames)
     DevRSpan *d_redo_rspans = nullptr;  // resolved spans of ONE frame being redone (allocated on first use)
     size_t redo_span_cap = 0;
@@ -222,11 +207,6 @@ void free_ctx(dg_ctx *c) {
         if (s.d_lists) (void)hipFree(s.d_lists);
         if (s.d_rspans) (void)hipFree(s.d_rspans);
         if (s.d_fb) (void)hipFree(s.d_fb);
-        if (s.d_segs) (void)hipFree(s.d_segs);
-        if (s.d_band_first) (void)hipFree(s.d_band_first);
-        if (s.d_tile_list) (void)hipFree(s.d_tile_list);
-        if (s.d_frame_flags) (void)hipFree(s.d_frame_flags);
-        if (s.h_frame_flags) (void)hipHostFree(s.h_frame_flags);
         if (s.h_fe) (void)hipHostFree(s.h_fe);
         if (s.d_fe) (void)hipFree(s.d_fe);
         if (s.d_fe_coloff) (void)hipFree(s.d_fe_coloff);
@@ -236,16 +216,12 @@ void free_ctx(dg_ctx *c) {
         if (s.ev_setup) (void)hipEventDestroy(s.ev_setup);
         if (s.ev_raster) (void)hipEventDestroy(s.ev_raster);
         if (s.ev_rstart) (void)hipEventDestroy(s.ev_rstart);
-        if (s.ev_resolved) (void)hipEventDestroy(s.ev_resolved);
         if (s.copy_stream) { (void)hipStreamSynchronize(s.copy_stream); (void)hipStreamDestroy(s.copy_stream); }
-        if (s.tile_stream) { (void)hipStreamSynchronize(s.tile_stream); (void)hipStreamDestroy(s.tile_stream); }
-        if (s.ev_tiles) (void)hipEventDestroy(s.ev_tiles);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     if (c->d_palette) (void)hipFree(c->d_palette);
     if (c->d_texel_idx) (void)hipFree(c->d_texel_idx);
     if (c->d_texel_opq) (void)hipFree(c->d_texel_opq);
-    if (c->d_pool) (void)hipFree(c->d_pool);
     if (c->d_row_tab) (void)hipFree(c->d_row_tab);
     if (c->d_redo_rspans) (void)hipFree(c->d_redo_rspans);
     if (c->d_checksums) (void)hipFree(c->d_checksums);
@@ -253,14 +229,6 @@ void free_ctx(dg_ctx *c) {
     if (c->d_fe_cspans) (void)hipFree(c->d_fe_cspans);
     if (c->d_fe_recs) (void)hipFree(c->d_fe_recs);
     delete c;
-}
-
-void fill_strip_params(const dg_ctx *c, const Slot &s, RasterParams &P) {
-    P.segs = s.d_segs; P.band_first = s.d_band_first; P.frame_flags = s.d_frame_flags;
-    P.tile_counters = s.d_frame_flags + c->cfg.max_batch;
-    P.band_ovl = reinterpret_cast<uint8_t *>(P.tile_counters + 2);
-    P.tile_list = s.d_tile_list;
-    P.seg_cap = c->seg_cap; P.band_rows = c->band_rows; P.n_bands = c->n_bands; P.strips = c->strips ? 1 : 0;
 }
 
 // Build + bin the lists of n views in parallel, pack them into the slot's pinned slab, fill slot.P.
@@ -328,10 +296,9 @@ int build_batch_host(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_li
     P.fb = s.d_fb;
     P.row_tab = c->d_row_tab;
     P.n_frames = n;
-    fill_strip_params(c, s, P);
     s.max_spans = max_spans; s.n_spans = spans; s.covered = covered; s.n_frames = n; s.n_walls = walls; s.n_planes = planes;
     s.list_bytes = total;
-    s.fe_mode = false; s.fe_check = false; s.seg_check = false;
+    s.fe_mode = false; s.fe_check = false;
     s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIP_TRY(hipMemcpyAsync(s.d_lists, s.h_lists, total, hipMemcpyHostToDevice, s.stream));
     return DG_OK;
@@ -436,10 +403,9 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_vie
     P.fb = s.d_fb;
     P.row_tab = c->d_row_tab;
     P.n_frames = n;
-    fill_strip_params(c, s, P);
     s.max_spans = 0; s.n_spans = 0; s.covered = 0; s.n_frames = n; s.n_walls = parts; s.n_planes = sprites;
     s.list_bytes = total;
-    s.fe_mode = true; s.fe_check = false; s.seg_check = false;
+    s.fe_mode = true; s.fe_check = false;
     s.views.assign(views, views + n);
     s.keep_states(states, n);
     s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -476,16 +442,12 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
         HIP_TRY(hipEventRecord(s.ev_setup, s.stream));
     }
     HIP_TRY(hipEventRecord(s.ev_rstart, s.stream));
-    HIP_TRY(launch_raster(s.P, s.stream, s.ev_resolved, c->side_tiles ? s.tile_stream : nullptr, s.ev_tiles));
+    HIP_TRY(launch_raster(s.P, s.stream));
     HIP_TRY(hipEventRecord(s.ev_raster, s.stream));
     c->last_raster = s.ev_raster;
     if (s.fe_mode) {
         HIP_TRY(hipMemcpyAsync(s.h_status, s.d_status, (size_t)2 * (size_t)c->cfg.max_batch * 4, hipMemcpyDeviceToHost, s.stream));
         s.fe_check = true;
-    }
-    if (s.P.strips) {
-        HIP_TRY(hipMemcpyAsync(s.h_frame_flags, s.d_frame_flags, (size_t)s.n_frames * 4, hipMemcpyDeviceToHost, s.stream));
-        s.seg_check = true;
     }
     s.busy = true; s.timed = true;
     return DG_OK;
@@ -533,7 +495,6 @@ int redo_frame_host(dg_ctx *c, Slot &s, int i) {
     Q.rspans = c->d_redo_rspans;
     Q.fb = s.d_fb + (size_t)i * (size_t)3 * (size_t)W * (size_t)H;
     Q.n_frames = 1;
-    Q.strips = 0;
     HIP_TRY(launch_setup(Q, (uint32_t)bf.spans.size(), s.stream));
     HIP_TRY(launch_raster(Q, s.stream));
     HIP_TRY(hipStreamSynchronize(s.stream));                                 // the host slab is reused by the next frame
@@ -555,41 +516,24 @@ int settle_slot(dg_ctx *c, Slot &s) {
         bool whole_batch = overflow;
         if (overflow) {
             // Only the frames that overflowed are redone (through the host list path, one at a time); if one of them does not fit the
-            // single-frame scratch either, or the strip rasteriser still has to vet the batch, the whole batch is.
+            // single-frame scratch either, the whole batch is.
             c->fallbacks_fe++;
-            if (!s.P.strips) {
-                whole_batch = false;
-                for (int i = 0; i < s.n_frames && !whole_batch; i++) {
-                    if (s.h_status[i] == 0) continue;
-                    const int rc = redo_frame_host(c, s, i);
-                    if (rc == DG_ERR_CAPACITY) whole_batch = true;
-                    else if (rc) return rc;
-                    else c->redone_frames++;
-                }
+            whole_batch = false;
+            for (int i = 0; i < s.n_frames && !whole_batch; i++) {
+                if (s.h_status[i] == 0) continue;
+                const int rc = redo_frame_host(c, s, i);
+                if (rc == DG_ERR_CAPACITY) whole_batch = true;
+                else if (rc) return rc;
+                else c->redone_frames++;
             }
         }
         if (whole_batch) {
-            s.seg_check = false;
             const std::vector<dg_view> views = s.views;
             int rc = build_batch_host(c, s, views.data(), nullptr, (int)views.size(), s.states.empty() ? nullptr : s.states.data());
             if (rc) return rc;
             rc = enqueue_kernels(c, s);
             if (rc) return rc;
             HIP_TRY(hipStreamSynchronize(s.stream));
-        }
-    }
-    // A column that needed more segment slots than the ctx was created with: dg_raster_strips skipped that frame; the batch
-    // is rasterised again from the same span lists by dg_raster_tiles, which has no such limit (same pixels either way).
-    if (s.seg_check) {
-        s.seg_check = false;
-        bool overflow = false;
-        for (int i = 0; i < s.n_frames; i++) overflow |= s.h_frame_flags[i] != 0;
-        if (overflow) {
-            c->fallbacks_seg++;
-            s.P.strips = 0;
-            hipError_t e = launch_raster(s.P, s.stream, s.ev_resolved, nullptr, nullptr);
-            if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
-            if (e != hipSuccess) return set_err(DG_ERR_HIP, std::string("strip fallback: ") + hipGetErrorString(e));
         }
     }
     return DG_OK;
@@ -607,12 +551,12 @@ int enqueue_copy(dg_ctx *c, Slot &s) {
 int finish_slot(dg_ctx *c, Slot &s) {
     HIP_TRY(hipStreamSynchronize(s.stream));
     s.busy = false;
-    const uint64_t redone = c->fallbacks_fe + c->fallbacks_seg;
+    const uint64_t redone = c->fallbacks_fe;
     int rc = settle_slot(c, s);
     if (rc) return rc;
     if (s.copy_pending) {
         HIP_TRY(hipStreamSynchronize(s.copy_stream));
-        if (c->fallbacks_fe + c->fallbacks_seg != redone) {
+        if (c->fallbacks_fe != redone) {
             rc = enqueue_copy(c, s);
             if (rc) return rc;
             HIP_TRY(hipStreamSynchronize(s.copy_stream));
@@ -714,8 +658,6 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     HIP_TRY(hipSetDevice(cfg->device));
 
     dg_ctx *c = new dg_ctx();
-    c->side_tiles = false;
-    if (const char *e = std::getenv("DOOMGPU_SIDE_TILES")) c->side_tiles = std::strtol(e, nullptr, 10) != 0;
     c->cfg = *cfg;
     c->fk = make_consts(cfg->width, cfg->height);
     c->dk = DevConsts{c->fk.ARC, c->fk.GCFX, c->fk.CFX, c->fk.CFY, cfg->width, cfg->height};
@@ -740,15 +682,6 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     const size_t lists_cap = align_up(F * sizeof(DevFrame), 256) + align_up(F * (W + 1) * 4, 256) +
                              align_up(c->wall_cap_per_batch * sizeof(DevWallRec), 256) +
                              align_up(c->plane_cap_per_batch * sizeof(DevPlaneRec), 256) + c->span_cap_per_batch * sizeof(DevSpan) + 1024;
-    // Strip rasteriser: segment slots per screen column (a frame with a column that needs more is rendered by dg_raster_tiles
-    // alone; DOOMGPU_SEG_SLOTS trades HBM, 32 B x slots x width x max_batch per slot, against that), rows per band.
-    if (const char *e = std::getenv("DOOMGPU_STRIPS")) c->strips = std::strtol(e, nullptr, 10) != 0;
-    if (const char *e = std::getenv("DOOMGPU_SEG_SLOTS")) {
-        const long v = std::strtol(e, nullptr, 10);
-        if (v >= 1 && v <= 255) c->seg_cap = (int)v;
-    }
-    c->band_rows = strip_band_rows(cfg->height);
-    c->n_bands = (cfg->height + c->band_rows - 1) / c->band_rows;
     c->fe_enabled = cfg->front_end != DG_FE_HOST;
     if (c->fe_enabled) {
         // Scratch slots per screen column (spans and wall-record columns).  A column that needs more sends its batch through
@@ -787,21 +720,11 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         CTX_TRY(hipEventCreate(&s.ev_setup));
         CTX_TRY(hipEventCreate(&s.ev_raster));
         CTX_TRY(hipEventCreate(&s.ev_rstart));
-        CTX_TRY(hipEventCreate(&s.ev_resolved));
         CTX_TRY(hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking));
-        CTX_TRY(hipStreamCreateWithFlags(&s.tile_stream, hipStreamNonBlocking));
-        CTX_TRY(hipEventCreate(&s.ev_tiles));
         CTX_TRY(hipHostMalloc((void **)&s.h_lists, lists_cap, hipHostMallocDefault));
         CTX_TRY(hipMalloc((void **)&s.d_lists, lists_cap));
         CTX_TRY(hipMalloc((void **)&s.d_rspans, c->span_cap_per_batch * sizeof(DevRSpan)));
         CTX_TRY(hipMalloc((void **)&s.d_fb, F * 3 * W * H));
-        if (c->strips) {
-            CTX_TRY(hipMalloc((void **)&s.d_segs, F * (size_t)c->seg_cap * W * sizeof(DevSeg)));
-            CTX_TRY(hipMalloc((void **)&s.d_band_first, F * (size_t)c->n_bands * W));
-            CTX_TRY(hipMalloc((void **)&s.d_tile_list, F * (size_t)c->n_bands * ((W + 63) / 64) * 4));
-            CTX_TRY(hipMalloc((void **)&s.d_frame_flags, F * 4 + 8 + F * (size_t)c->n_bands * ((W + 63) / 64)));
-            CTX_TRY(hipHostMalloc((void **)&s.h_frame_flags, F * 4, hipHostMallocDefault));
-        }
         if (c->fe_enabled) {
             CTX_TRY(hipHostMalloc((void **)&s.h_fe, c->fe_slab_cap, hipHostMallocDefault));
             CTX_TRY(hipMalloc((void **)&s.d_fe, c->fe_slab_cap));
@@ -822,15 +745,18 @@ int dg_ctx_host_threads(const dg_ctx *ctx) { return ctx ? ctx->n_threads : DG_ER
 int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     if (!c || !scene) return set_err(DG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    for (Slot &s : c->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+    for (Slot &s : c->slots) {             // nothing may still read the old scene or write into a buffer a pending readback is copying from
+        HIP_TRY(hipStreamSynchronize(s.stream));
+        HIP_TRY(hipStreamSynchronize(s.copy_stream));
+        s.copy_pending = false;
+    }
     const Scene &sc = *scene->sc;
     if (c->d_palette) { (void)hipFree(c->d_palette); c->d_palette = nullptr; }
     if (c->d_texel_idx) { (void)hipFree(c->d_texel_idx); c->d_texel_idx = nullptr; }
     if (c->d_texel_opq) { (void)hipFree(c->d_texel_opq); c->d_texel_opq = nullptr; }
     c->d_flats = nullptr;               // inside d_texel_idx's allocation
-    if (c->d_pool) { (void)hipFree(c->d_pool); c->d_pool = nullptr; }
     // the slots' prepared records point into the device scene that was just freed: nothing may be replayed from them
-    for (Slot &s : c->slots) { s.n_frames = 0; s.timed = false; s.fe_check = false; s.seg_check = false; s.busy = false; }
+    for (Slot &s : c->slots) { s.n_frames = 0; s.timed = false; s.fe_check = false; s.busy = false; }
     uint32_t pal[256];
     for (int i = 0; i < 256; i++) pal[i] = (uint32_t)sc.palette[3 * i] | ((uint32_t)sc.palette[3 * i + 1] << 8) | ((uint32_t)sc.palette[3 * i + 2] << 16);
     const size_t nt = std::max<size_t>(sc.texel_idx.size(), 16), nf = std::max<size_t>(sc.flat_pool.size(), 16);
@@ -847,12 +773,8 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
         HIP_TRY(hipMemcpy(c->d_texel_opq, sc.texel_opq.data(), sc.texel_opq.size(), hipMemcpyHostToDevice));
     }
     if (!sc.flat_pool.empty()) HIP_TRY(hipMemcpy(c->d_flats, sc.flat_pool.data(), sc.flat_pool.size(), hipMemcpyHostToDevice));
-    std::vector<uint8_t> pool;
-    const uint32_t pool_flats = sc.build_strip_pool(pool);
-    HIP_TRY(hipMalloc((void **)&c->d_pool, std::max<size_t>(pool.size(), 16)));
-    if (!pool.empty()) HIP_TRY(hipMemcpy(c->d_pool, pool.data(), pool.size(), hipMemcpyHostToDevice));
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
-    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, c->d_pool, pool_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
+    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
     if (!c->d_row_tab) HIP_TRY(hipMalloc((void **)&c->d_row_tab, (size_t)c->cfg.height * sizeof(uint4)));
     HIP_TRY(launch_row_table(c->dscene, c->dk, c->d_row_tab, nullptr));
     HIP_TRY(hipDeviceSynchronize());
@@ -888,7 +810,7 @@ int dg_submit_views_state(dg_ctx *c, int slot, const dg_view *views, const dg_vi
     HIP_TRY(hipSetDevice(c->cfg.device));
     Slot &s = c->slots[(size_t)slot];
     if (s.busy || s.copy_pending) { rc = finish_slot(c, s); if (rc) return rc; }
-    s.fe_check = false; s.seg_check = false;
+    s.fe_check = false;
     rc = build_batch(c, s, views, nullptr, n, states);
     if (rc) return rc;
     return enqueue_kernels(c, s);
@@ -921,10 +843,9 @@ int dg_ctx_redone_frames(const dg_ctx *c, uint64_t *frames) {
     return DG_OK;
 }
 
-int dg_ctx_fallbacks(const dg_ctx *c, uint64_t *front_end, uint64_t *segments) {
-    if (!c) return set_err(DG_ERR_INVALID, "null ctx");
-    if (front_end) *front_end = c->fallbacks_fe;
-    if (segments) *segments = c->fallbacks_seg;
+int dg_ctx_fallbacks(const dg_ctx *c, uint64_t *front_end) {
+    if (!c || !front_end) return set_err(DG_ERR_INVALID, "null argument");
+    *front_end = c->fallbacks_fe;
     return DG_OK;
 }
 
@@ -943,7 +864,7 @@ int dg_readback(dg_ctx *c, int slot, int first, int count, uint8_t *out) {
     if (!out || first < 0 || count < 0 || first + count > s.n_frames) return set_err(DG_ERR_INVALID, "bad readback range");
     HIP_TRY(hipSetDevice(c->cfg.device));
     const size_t fsz = (size_t)3 * (size_t)c->cfg.width * (size_t)c->cfg.height;
-    if (s.fe_check || s.seg_check) {
+    if (s.fe_check) {
         HIP_TRY(hipStreamSynchronize(s.stream));
         rc = settle_slot(c, s);
         if (rc) return rc;
@@ -961,7 +882,7 @@ int dg_frame_checksums(dg_ctx *c, int slot, int first, int count, uint64_t *out)
     if (!out || first < 0 || count < 0 || first + count > s.n_frames) return set_err(DG_ERR_INVALID, "bad frame range");
     if (count == 0) return DG_OK;
     HIP_TRY(hipSetDevice(c->cfg.device));
-    if (s.fe_check || s.seg_check) {
+    if (s.fe_check) {
         HIP_TRY(hipStreamSynchronize(s.stream));
         rc = settle_slot(c, s);
         if (rc) return rc;
@@ -997,6 +918,7 @@ int dg_prepare_views(dg_ctx *c, int slot, const dg_view *views, int n) {
     if (!views) return set_err(DG_ERR_INVALID, "null views");
     HIP_TRY(hipSetDevice(c->cfg.device));
     Slot &s = c->slots[(size_t)slot];
+    if (s.busy || s.copy_pending) { rc = finish_slot(c, s); if (rc) return rc; }   // incl. a readback still copying out of the slot's framebuffer
     HIP_TRY(hipStreamSynchronize(s.stream));
     s.busy = false; s.fe_check = false;
     rc = build_batch(c, s, views, nullptr, n);
@@ -1016,12 +938,15 @@ int dg_replay_slot(dg_ctx *c, int slot) {
     Slot &s = c->slots[(size_t)slot];
     if (s.n_frames <= 0) return set_err(DG_ERR_INVALID, "slot has no prepared lists");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    if (s.fe_check || s.seg_check) {   // a submission that was never waited for
+    if (s.copy_pending) {   // a dg_readback_async is still reading the framebuffer these kernels are about to overwrite
+        rc = finish_slot(c, s);
+        if (rc) return rc;
+    }
+    if (s.fe_check) {   // a submission that was never waited for
         HIP_TRY(hipStreamSynchronize(s.stream));
         rc = settle_slot(c, s);
         if (rc) return rc;
     }
-    s.P.strips = c->strips ? 1 : 0;   // (a settled overflow switched the slot to dg_raster_tiles: a replay of that batch overflows again)
     return enqueue_kernels(c, s);  // (the overflow flags are looked at again: frames that overflowed are redone on every replay)
 }
 
@@ -1031,7 +956,7 @@ int dg_draw_lists(dg_ctx *c, int slot, const dg_frame_lists *frames, int n, uint
     if (!frames) return set_err(DG_ERR_INVALID, "null frames");
     HIP_TRY(hipSetDevice(c->cfg.device));
     Slot &s = c->slots[(size_t)slot];
-    if (s.busy) { HIP_TRY(hipStreamSynchronize(s.stream)); s.busy = false; }
+    if (s.busy || s.copy_pending) { rc = finish_slot(c, s); if (rc) return rc; }
     s.fe_check = false;
     rc = build_batch(c, s, nullptr, frames, n);
     if (rc) return rc;
@@ -1049,7 +974,7 @@ int dg_slot_timing(dg_ctx *c, int slot, dg_timing *out) {
     if (!s.timed) return set_err(DG_ERR_INVALID, "slot has not run yet");
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipEventSynchronize(s.ev_raster));
-    if (s.fe_check || s.seg_check) {
+    if (s.fe_check) {
         HIP_TRY(hipStreamSynchronize(s.stream));
         rc = settle_slot(c, s);
         if (rc) return rc;
@@ -1062,8 +987,6 @@ int dg_slot_timing(dg_ctx *c, int slot, dg_timing *out) {
     out->host_ms = s.host_ms; out->list_bytes = s.list_bytes;
     out->n_walls = s.n_walls; out->n_planes = s.n_planes;
     out->front_end = s.fe_mode ? DG_FE_DEVICE : DG_FE_HOST;
-    out->strips_ms = 0.0f;
-    if (s.P.strips) HIP_TRY(hipEventElapsedTime(&out->strips_ms, s.ev_resolved, s.ev_raster));
     return DG_OK;
 }
 

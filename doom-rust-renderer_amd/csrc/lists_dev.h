@@ -32,7 +32,7 @@ struct DevSpanAux {           // setup-kernel output
 };
 static_assert(sizeof(DevSpanAux) == 8, "DevSpanAux must be 8 bytes");
 
-// The column-major, draw-ordered list both raster paths start from: one self-contained 32-byte record per span, written by
+// The column-major, draw-ordered list the rasteriser starts from: one self-contained 32-byte record per span, written by
 // the setup kernel (host lists) or dg_fe_scatter (device column walk) from DevSpan + its wall/plane record.
 //   word   WALL (bitmap_render.rs:241-263)                    FLAT (visplanes.rs:103-126)           SKY (visplanes.rs:65-72)
 //   w0     ctop | imm << 15 | cbot << 16 | kind << 30          same                                   same      (imm: may be transparent)
@@ -45,22 +45,6 @@ static_assert(sizeof(DevSpanAux) == 8, "DevSpanAux must be 8 bytes");
 //   w7     tx (texture column)                                -                                      tx (sky texture column, or ~0)
 struct DevRSpan { uint32_t w[8]; };
 static_assert(sizeof(DevRSpan) == 32, "DevRSpan must be 32 bytes");
-
-// What dg_raster_strips walks (strip_core.h): dg_resolve_columns turns the draw-ordered prefix of opaque spans of a screen
-// column into sorted, disjoint segments that cover rows 0 .. H-1 without gaps (uncovered rows become SEG_NONE segments).  A
-// segment starts where its predecessor ended.  Stored slot-major, [frame][slot][W], so that the 64 lanes of a wavefront
-// (64 adjacent columns) read 64 adjacent records.
-//   word   WALL                                               FLAT                                  SKY / NONE
-//   w0     end row | kind << 30                               same                                  same
-//   w1     d (f32)                                            wz * vx (f32)                         -
-//   w2     pool offset of (bitmap row 0, column tx), row-major pool offset of the flat              pool offset of (sky row 0, column tx) / 0
-//   w3     light factor (f32)                                 -                                     1.0f / 0.0f
-//   w4     uy1 (NaN if d == 0)                                gwz (f32)                             -
-//   w5     top_y | off_y << 16                                light_level / 255 (f32)               -
-//   w6     h | w << 16                                        fast-divide-ok (bit 0)                -
-//   w7     prepared reciprocal of d (raster_core.h)           -                                     -
-typedef DevRSpan DevSeg;
-enum : uint32_t { SEG_NONE = 3 };
 
 struct DevWallRec {           // bitmap_render.rs:233-251 hoisted per record
     float A, B, C, D;         // ux0/uz0 (= 0.0/uz0), ux1/uz1 (= len/uz1), 1.0/uz0, 1.0/uz1
@@ -99,8 +83,6 @@ struct DevScene {             // immutable, uploaded once per map
     const uint8_t *texel_idx; // column-major per bitmap (off + x*h + y): dg_raster_tiles, lane = row
     const uint8_t *texel_opq;
     const uint8_t *flats;
-    const uint8_t *pool;      // dg_raster_strips (lane = column): [row-major texel index plane (off + y*w + x) | flats]
-    uint32_t pool_flats;      // byte offset of the flats inside pool
     uint32_t sky_texel_off;   // sky bitmap (256 x 128 expected)
     int32_t sky_w, sky_h;
     uint32_t sky_has_holes;   // any transparent texel in the sky bitmap (then sky spans are evaluated in draw order)

@@ -291,17 +291,6 @@ static inline bool left_of_partition(const NodeRec &n, float px, float py) {
     return ax * by - ay * bx <= 0.0f;
 }
 
-uint32_t Scene::build_strip_pool(std::vector<uint8_t> &pool) const {
-    const size_t flats_at = (texel_idx.size() + 255) / 256 * 256;
-    pool.assign(flats_at + flat_pool.size(), 0);
-    for (const BitmapInfo &b : bitmaps)
-        for (int x = 0; x < b.w; x++)
-            for (int y = 0; y < b.h; y++)
-                pool[(size_t)b.texel_off + (size_t)y * (size_t)b.w + (size_t)x] = texel_idx[(size_t)b.texel_off + (size_t)x * (size_t)b.h + (size_t)y];
-    std::copy(flat_pool.begin(), flat_pool.end(), pool.begin() + (long)flats_at);
-    return (uint32_t)flats_at;
-}
-
 int Scene::sector_from_vertex(float x, float y) const {
     int ni = (int)nodes.size() - 1;
     for (;;) {

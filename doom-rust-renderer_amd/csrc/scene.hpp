@@ -89,9 +89,6 @@ struct Scene {
     int sprite_bitmap_id(const std::string &sprite, uint8_t frame, uint8_t rotation) const;
     int sector_from_vertex(float x, float y) const;                              // renderer/bsp.rs:9-44
     int find_or_add_sprite_frame(const std::string &sprite, uint8_t frame, std::string &err);
-    // Texel source of the strip rasteriser (lane = column): every bitmap's index plane row-major (texel_off + y*w + x: the 64
-    // adjacent columns of a wall row then read a few cache lines), followed by the flats.  Returns the offset of the flats.
-    uint32_t build_strip_pool(std::vector<uint8_t> &pool) const;
 };
 
 // Returns nullptr and fills err on any condition where the reference's loaders panic.

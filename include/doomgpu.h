@@ -111,13 +111,12 @@ void dg_destroy(dg_ctx *ctx);
 /* Number of host threads the ctx uses for list generation (after the default / cap has been applied). */
 int dg_ctx_host_threads(const dg_ctx *ctx);
 /* Submissions in which a device-side capacity was exceeded: the column scratch of the device column walk (the frames concerned
- * are redone through the host list path, see dg_ctx_redone_frames) / the segment slots of the strip rasteriser (the batch is
- * redone by the tile rasteriser).  Same pixels either way; a workload that keeps hitting them should raise
- * DOOMGPU_FE_COLUMN_SLOTS / DOOMGPU_SEG_SLOTS.
+ * are redone through the host list path, see dg_ctx_redone_frames).  Same pixels either way; a workload that keeps hitting it
+ * should raise DOOMGPU_FE_COLUMN_SLOTS.
  * Error reporting differs from the reference in one documented way: BSP subtrees that cannot contribute to the frame are not
  * walked, so a panic the reference would raise while processing a seg in such a subtree
  * (segs.rs:140-145,431-436) is not reported as DG_ERR_RENDER; missing texture / flat lookups disable the skipping for the map. */
-int dg_ctx_fallbacks(const dg_ctx *ctx, uint64_t *front_end, uint64_t *segments);
+int dg_ctx_fallbacks(const dg_ctx *ctx, uint64_t *front_end);
 /* Frames that were redone one at a time through the host list path because THEY overflowed a capacity of the device column walk
  * (the other frames of their batch were kept); a frame that does not fit the single-frame scratch either makes the whole batch go
  * through DG_FE_HOST, which dg_ctx_fallbacks counts like every overflow event. */
@@ -143,8 +142,9 @@ void dg_free_host(void *p);
 int dg_readback(dg_ctx *ctx, int slot, int first, int count, uint8_t *rgb24_out);
 /* The same without waiting: the copy is queued behind the slot's kernels on the slot's own copy stream, so it overlaps the
  * kernels of the NEXT submission on another slot (the reference's caller consumes `pixels.pixels` on the host every frame,
- * src/game.rs:521-525).  rgb24_out should be page-locked (dg_alloc_host) and is complete after dg_wait(slot); submitting to the
- * slot again waits for it.  One readback in flight per slot. */
+ * src/game.rs:521-525).  rgb24_out should be page-locked (dg_alloc_host) and is complete after dg_wait(slot); every call that renders
+ * into the slot again (dg_submit_views*, dg_render_views*, dg_prepare_views, dg_replay_slot, dg_draw_lists) and dg_upload_scene
+ * complete it first, so the copy never sees a half-overwritten frame.  One readback in flight per slot. */
 int dg_readback_async(dg_ctx *ctx, int slot, int first, int count, uint8_t *rgb24_out);
 /* Frame sink without the PCIe copy: one 64-bit checksum per frame of a finished slot, computed on the GPU over the frame's
  * RGB24 bytes taken as little-endian dwords d[0 .. 3*W*H/4):
@@ -225,7 +225,6 @@ typedef struct dg_timing {
     int32_t front_end;        /* DG_FE_HOST or DG_FE_DEVICE: what that submission actually used; with DG_FE_DEVICE setup_ms is
                                  the column walk (dg_fe_columns, dg_fe_gaps, dg_fe_scan, dg_fe_scatter), n_walls = wall records,
                                  n_planes = sprites, covered_pixels is not tracked (0) */
-    float strips_ms;          /* of raster_ms (= dg_resolve_columns + dg_raster_strips + dg_raster_tile_list): the two pixel kernels */
 } dg_timing;
 int dg_slot_timing(dg_ctx *ctx, int slot, dg_timing *out);
 

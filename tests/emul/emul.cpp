@@ -15,12 +15,10 @@
 #include "../../doom-rust-renderer_amd/csrc/frontend.hpp"
 #include "../../doom-rust-renderer_amd/csrc/raster_core.h"
 #include "../../doom-rust-renderer_amd/csrc/scene.hpp"
-#include "../../doom-rust-renderer_amd/csrc/strip_core.h"
 
 using namespace dg;
 
 static std::string g_err;
-static uint64_t g_ov_stats[6];
 
 // What dg_raster_tiles does for every column: spans in order, every row of the span (lane = row), later span overwrites.
 static void raster_spans(const DevScene &ds, const DevConsts &k, const DevFrame &hdr, const uint32_t *pal, const uint32_t *col_off,
@@ -54,112 +52,9 @@ static void raster_spans(const DevScene &ds, const DevConsts &k, const DevFrame 
     }
 }
 
-// The strip path on the same span lists: resolve every column's opaque prefix into segments (dg_resolve_columns); 64-row
-// bands of 64-column strips that no overlay span touches are then walked segment by segment (dg_raster_strips, lane =
-// column), the other tiles are replayed from the draw-ordered spans (dg_raster_tile_list = raster_spans restricted to the
-// tile).  Returns false (and says why) when the result differs from raster_spans' or when a band index is off.
-static bool raster_strips_check(const Scene &sc, DevScene ds, const DevConsts &k, const DevFrame &hdr, const uint32_t *pal, const uint32_t *col_off,
-                                const DevRSpan *rs, int W, int H, const uint8_t *expect) {
-    std::vector<uint8_t> pool;
-    ds.pool_flats = sc.build_strip_pool(pool);
-    ds.pool = pool.data();
-    const int band_rows = 64;                                          // = strip_band_rows(H), kernels.hip
-    const int n_bands = (H + band_rows - 1) / band_rows, n_strips = (W + 63) / 64;
-    const uint32_t cap = 255;
-    std::vector<std::vector<DevSeg>> segs((size_t)W);
-    std::vector<uint8_t> bands((size_t)n_bands), rgb((size_t)3 * W * H, 0), ovl((size_t)n_bands * n_strips, 0);
-    std::vector<DevSeg> tmp((size_t)cap);
-    for (int x = 0; x < W; x++) {                                      // dg_resolve_columns
-        const uint32_t n = col_off[x + 1] - col_off[x];
-        const DevRSpan *sp = rs + col_off[x];
-        const ResolveResult r = resolve_column([&](uint32_t j) { return sp[j].w[0]; }, sp, n, ds, H, band_rows, cap, tmp.data(), 1, bands.data(), 1);
-        if (r.n_segs == 0xffffffffu) { g_err = "strip path: more than 255 segments in a column"; return false; }
-        if (r.n_segs == 0 || seg_end(tmp[r.n_segs - 1].w[0]) != H - 1) { g_err = "strip path: segments do not end at H - 1"; return false; }
-        segs[(size_t)x].assign(tmp.begin(), tmp.begin() + r.n_segs);
-        int start = 0;
-        for (uint32_t s = 0; s < r.n_segs; s++) {
-            const int end = seg_end(tmp[s].w[0]);
-            if (end < start) { g_err = "strip path: empty or unsorted segment"; return false; }
-            for (int b = 0; b < n_bands; b++)
-                if (b * band_rows >= start && b * band_rows <= end && bands[(size_t)b] != s) { g_err = "strip path: band_first is wrong"; return false; }
-            start = end + 1;
-        }
-        g_ov_stats[n - r.n_base ? 1 : 0]++;
-        for (uint32_t j = r.n_base; j < n; j++) {
-            if (w0_ctop(sp[j].w[0]) < r.ov_lo || w0_cbot(sp[j].w[0]) > r.ov_hi) { g_err = "strip path: overlay rows outside the reported range"; return false; }
-            for (int b = w0_ctop(sp[j].w[0]) / band_rows; b <= w0_cbot(sp[j].w[0]) / band_rows; b++) ovl[(size_t)b * n_strips + (size_t)(x / 64)] = 1;
-        }
-    }
-    for (int b = 0; b < n_bands; b++)
-        for (int st = 0; st < n_strips; st++) {
-            const int y_lo = b * band_rows, y_hi = std::min(H, y_lo + band_rows) - 1;
-            g_ov_stats[ovl[(size_t)b * n_strips + (size_t)st] ? 3 : 2]++;
-            for (int x = st * 64; x < std::min(W, st * 64 + 64); x++) {
-                if (!ovl[(size_t)b * n_strips + (size_t)st]) {         // dg_raster_strips: one lane, the band's rows
-                    int start = 0;
-                    for (const DevSeg &sg : segs[(size_t)x]) {
-                        const uint32_t *w = sg.w;
-                        const int end = seg_end(w[0]);
-                        for (int y = std::max(start, y_lo); y <= std::min(end, y_hi); y++) {
-                            const uint32_t kind = seg_kind(w[0]);
-                            uint32_t off = w[2];
-                            float fac = bits_f32(w[3]);
-                            const float vy = k.CFY - (float)y;
-                            if (kind == SPAN_FLAT) off = seg_flat_offset(hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), fac);
-                            else if (kind == SPAN_WALL) off = seg_wall_offset(w[1], w[2], w[4], w[5], w[6], w[7], y);
-                            else if (kind == SPAN_SKY) {
-                                const int srow = sky_row(ds, k, y);
-                                if (srow >= 0) off = w[2] + (uint32_t)srow * (uint32_t)ds.sky_w; else { off = 0; fac = 0.0f; }
-                            }
-                            const uint32_t c = shade(pal[pool[off]], fac);
-                            uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
-                            p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
-                        }
-                        start = end + 1;
-                    }
-                } else {                                               // dg_raster_tile_list: all spans of the column in draw order, the tile's rows
-                    for (uint32_t i = col_off[x]; i < col_off[x + 1]; i++) {
-                        uint32_t w[8];
-                        std::memcpy(w, rs[i].w, sizeof w);
-                        const uint32_t kind = w0_kind(w[0]);
-                        if (kind == SPAN_WALL) stage_wall_span(w[1], w[2], w[6], w[7]);
-                        for (int y = std::max(w0_ctop(w[0]), y_lo); y <= std::min(w0_cbot(w[0]), y_hi); y++) {
-                            uint32_t c = 0;
-                            bool wr = false;
-                            if (kind == SPAN_WALL) {
-                                const uint32_t o = wall_texel_offset_staged(w[1], w[2], w[4], w[5], w[6], w[7], y);
-                                if (!w0_immediate(w[0]) || ds.texel_opq[o]) { c = shade(pal[ds.texel_idx[o]], bits_f32(w[3])); wr = true; }
-                            } else if (kind == SPAN_FLAT) {
-                                float factor;
-                                const float vy = k.CFY - (float)y;
-                                const uint32_t o = flat_texel_offset(hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), factor);
-                                c = shade(pal[ds.flats[o]], factor); wr = true;
-                            } else {
-                                const uint32_t o = sky_texel_offset(w[2], sky_row(ds, k, y));
-                                if (o != 0xffffffffu && ds.texel_opq[o]) { c = pal[ds.texel_idx[o]]; wr = true; }
-                            }
-                            if (wr) {
-                                uint8_t *p = rgb.data() + 3 * ((size_t)y * W + x);
-                                p[0] = c & 255; p[1] = (c >> 8) & 255; p[2] = (c >> 16) & 255;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    if (std::memcmp(rgb.data(), expect, rgb.size()) != 0) {
-        size_t i = 0;
-        while (rgb[i] == expect[i]) i++;
-        g_err = "strip path: pixel (" + std::to_string(i / 3 % (size_t)W) + ", " + std::to_string(i / 3 / (size_t)W) + ") differs from the draw-order replay";
-        return false;
-    }
-    return true;
-}
-
 extern "C" {
 
 const char *emul_last_error() { return g_err.c_str(); }
-void emul_overlay_stats(uint64_t *out, int reset) { for (int i = 0; i < 6; i++) { out[i] = g_ov_stats[i]; if (reset) g_ov_stats[i] = 0; } }
 
 void *emul_load(const uint8_t *wad, size_t len, const char *map_name) {
     return load_scene_from_wad(wad, len, map_name, g_err);
@@ -216,7 +111,6 @@ static int emul_render_impl(void *scene, int W, int H, const dg_view *view_in, c
                                      : resolve_sky_span(sp, ds, k, bf.hdr);
     }
     raster_spans(ds, k, bf.hdr, pal.data(), bf.col_off.data(), rs.data(), W, H, rgb);
-    if (!raster_strips_check(sc, ds, k, bf.hdr, pal.data(), bf.col_off.data(), rs.data(), W, H, rgb)) return DG_ERR_INVALID;
     if (stats) { stats[0] = bf.spans.size(); stats[1] = bf.walls.size(); stats[2] = bf.planes.size(); stats[3] = bf.covered_pixels; }
     return 0;
 }
@@ -339,7 +233,6 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
         same = std::memcmp(&r, &rspans[i], sizeof r) == 0;
     }
     raster_spans(ds, k, fr, pal.data(), col_off.data(), rspans.data(), W, H, rgb);
-    if (!raster_strips_check(sc, ds, k, fr, pal.data(), col_off.data(), rspans.data(), W, H, rgb)) return DG_ERR_INVALID;
     if (stats) { stats[0] = off; stats[1] = ff.n_parts; stats[2] = ff.n_sprites; stats[3] = flags[0]; stats[4] = same ? 1 : 0; stats[5] = n_gaps; }
     return 0;
 }

@@ -43,11 +43,11 @@ class _StubCtx:
         self.replays += 1
 
     def timing(self, slot):
-        return {"raster_ms": 0.5, "strips_ms": 0.3, "setup_ms": 0.1, "host_ms": 0.25 * (1 + self.rank), "n_frames": self.batch, "n_spans": 1000 * self.batch,
+        return {"raster_ms": 0.5, "setup_ms": 0.1, "host_ms": 0.25 * (1 + self.rank), "n_frames": self.batch, "n_spans": 1000 * self.batch,
                 "list_bytes": 4096 * self.batch, "front_end": 2}
 
     def fallbacks(self):
-        return {"front_end": 0, "segments": 0}
+        return {"front_end": 0, "redone_frames": 0}
 
     def close(self):
         pass
@@ -57,9 +57,9 @@ class _StubBackend:
     def __init__(self, args, device):
         self.args = args
 
-    def load(self, map_seed, path_seed):
+    def load(self, map_id, path_seed, camera="path"):
         import bench
-        self.map_seed, self.path_seed = map_seed, path_seed
+        self.map_seed, self.heavy, self.path_seed, self.camera = map_id[0], map_id[1], path_seed, camera
         B = self.args.batch
         self.n_slots = max(1, min(self.args.slots, (bench.PATH_FRAMES + B - 1) // B))
         self.views = [object()] * self.n_slots
@@ -77,7 +77,7 @@ def _worker(rank, world, port, q):
     dist.barrier()
     slow = bench.dist_max(0.5 + rank, dist)            # rank 1 is the slow one
     # bench.run end to end (rank plan, CPU binding, barriers, timed steps, MAX over ranks, report gather) on a stub context
-    args = bench.parse_args(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch", "250"])
+    args = bench.parse_args(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch", "250", "--config", "4"])
     holder = {}
 
     def factory(a, device):
@@ -116,6 +116,8 @@ def test_two_rank_gloo_bench_run():
     per = line["per_rank"]
     assert [p["rank"] for p in per] == [0, 1]
     assert [(p["map_seed"], p["path_seed"]) for p in per] == [(1993, 1993), (1994, 1994)] == [(r[3], r[4]) for r in res]
+    assert [p["heavy_map"] for p in per] == [False, True] and [p["device"] for p in per] == [0, 1]
+    assert line["config"]["baseline_config"] == 4 and "config 4" in line["config"]["workload"]
     assert per[0]["frames_per_s"] > per[1]["frames_per_s"]                  # rank 0 really was faster; the headline is not its rate
     assert per[1]["host_ms_per_batch"] == pytest.approx(0.5)
     if ncpu >= 2:                                                            # each rank pinned itself to its half before starting
@@ -132,8 +134,33 @@ def test_seeded_routes_are_permutations_of_the_same_loop():
         assert sorted(rr) == sorted(route) and len(rr) == len(route)
         starts.add(rr[0])
     assert len(starts) >= 5                             # eight paths, (almost) all entering the loop somewhere else
-    assert [bench.rank_plan(r, 8) for r in range(4)] == [(1993, 1993), (1994, 1994), (1993, 1995), (1994, 1996)]
-    assert bench.rank_plan(0, 1) == (1993, 1993)
+    assert bench.rank_plan(0, 1) == ((1993, False), 1993)
+
+
+def test_eight_rank_plans_of_every_config():
+    """BASELINE configs -> what each of eight ranks renders: config 4 alternates the light and the heavy map, config 5 is the heavy
+    map on every rank, the others the light one; camera paths are always 1993 + rank; sizes and batches divide the path."""
+    import bench
+    for cfg, (name, W, H, B, maps, camera) in bench.CONFIGS.items():
+        plans = [bench.rank_plan(r, 8, cfg) for r in range(8)]
+        assert [p[1] for p in plans] == list(range(1993, 2001))
+        assert bench.PATH_FRAMES % B == 0 and W % 4 == 0 and f"config {cfg}" in name
+        a = bench.parse_args(["--config", str(cfg)])
+        assert (a.width, a.height, a.batch) == (W, H, B)
+    assert [bench.rank_plan(r, 8, 4)[0] for r in range(4)] == [(1993, False), (1994, True), (1993, False), (1994, True)]
+    assert {bench.rank_plan(r, 8, 5)[0] for r in range(8)} == {(1994, True)}
+    assert {bench.rank_plan(r, 8, 3)[0] for r in range(8)} == {(1993, False)}
+    assert bench.CONFIGS[5][1:3] == (2560, 1600) and bench.CONFIGS[1][5] == "start"
+    with pytest.raises(SystemExit):
+        bench.parse_args(["--batch", "300"])            # does not divide the 1000-frame path
+
+
+def test_device_ordinal_survives_masked_visibility():
+    """A launcher that gives every rank ONE visible GPU (HIP_VISIBLE_DEVICES per rank): LOCAL_RANK 5 must use ordinal 0."""
+    import bench
+    assert [bench.pick_device(r, 8) for r in range(8)] == list(range(8))
+    assert [bench.pick_device(r, 1) for r in range(8)] == [0] * 8
+    assert bench.pick_device(3, 0) == 3                 # no GPU visible (CPU rehearsal): unchanged, dg_create reports it
 
 
 def test_route_from_wad_gives_a_closed_walk(synth, campath_mod):

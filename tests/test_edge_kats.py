@@ -144,10 +144,8 @@ def to_dg_lists(dg, scene, rec, lists):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("strips", ["0", "1"], ids=["tiles", "strips"])
-def test_gpu_equals_independent_restatement(dg, wad1993, expected, monkeypatch, strips):
+def test_gpu_equals_independent_restatement(dg, wad1993, expected):
     """dg_draw_lists (the literal "host feeds lists" boundary) on the hand-built lists, all cases in one batch."""
-    monkeypatch.setenv("DOOMGPU_STRIPS", strips)
     scene = dg.Scene(wad1993, "e1m1")
     ctx = dg.Context(W, H, max_batch=len(CASES), slots=1)
     ctx.upload_scene(scene)

@@ -91,13 +91,11 @@ def test_heavy_map_bit_exact(dg, scene1994, oracle_scene1994, path1994, golden_f
     ctx.close()
 
 
-@pytest.mark.parametrize("strips", ["0", "1"], ids=["tiles", "strips"])
 @pytest.mark.parametrize("front_end", [1, 2], ids=["host-lists", "device-column-walk"])
-def test_vanilla_shaped_map_bit_exact(dg, wad1995, oracle_scene1995, path1995, golden_frames, monkeypatch, front_end, strips):
+def test_vanilla_shaped_map_bit_exact(dg, wad1995, oracle_scene1995, path1995, golden_frames, front_end):
     """Seed 1995 — arbitrary integer vertices and wall angles, rounded BSP splits, closed doors (segs.rs:222-225), thing angles in
     1 degree steps, patches with negative / past-the-bottom origins: the committed golden hashes at every size they were taken at,
-    every 8th path frame against the oracle, through both front ends and both rasterisers."""
-    monkeypatch.setenv("DOOMGPU_STRIPS", strips)
+    every 8th path frame against the oracle, through both front ends."""
     scene = dg.Scene(wad1995, "e1m1")
     for size, frames in golden_frames[1995].items():
         ts = float(size.split("@t=")[1]) if "@t=" in size else 0.0
@@ -489,55 +487,25 @@ def test_every_frame_of_both_paths_at_1280x800_against_the_oracle_checksums(dg, 
         ctx.close()
 
 
-# ---- round 2: the strip rasteriser and its fallbacks, overlapped submission, the remaining C-ABI entry points -------------
+# ---- round 2: frame sizes with partial tiles, overlapped submission, the remaining C-ABI entry points -------------
 
-def test_segment_capacity_falls_back_to_the_tile_rasteriser(dg, scene1994, oracle_scene1994, path1994, monkeypatch):
-    """dg_resolve_columns flags a frame whose column needs more segment slots than the ctx has; dg_wait then redoes the batch
-    with dg_raster_tiles (same pixels), and dg_ctx_fallbacks counts it.  With two slots per column every frame overflows."""
-    W, H = 320, 200
-    idx = list(range(0, 1000, 100))
-    monkeypatch.setenv("DOOMGPU_STRIPS", "1")
-    monkeypatch.setenv("DOOMGPU_SEG_SLOTS", "2")
-    ctx = make_ctx(dg, scene1994, W, H, len(idx), slots=2)
-    monkeypatch.delenv("DOOMGPU_SEG_SLOTS")
-    views = dg.make_views(path1994[idx])
-    out = ctx.render(views)
-    assert ctx.fallbacks()["segments"] == 1
-    for k, i in enumerate(idx):
-        assert np.array_equal(out[k], np.frombuffer(oracle_scene1994.render(W, H, path1994[i]), dtype=np.uint8).reshape(H, W, 3)), f"frame {i}"
-    # a prepared slot replays through the same route, and so does an asynchronous readback queued before the redo
-    ctx.prepare(1, views)
-    ctx.replay(1)
-    host = np.empty_like(out)
-    ctx.readback_async(1, 0, len(idx), host.ctypes.data)
-    ctx.wait(1)
-    assert np.array_equal(host, out) and ctx.fallbacks()["segments"] >= 3
-    ctx.close()
-
-
-@pytest.mark.parametrize("side", ["0", "1"], ids=["tile-list-behind", "tile-list-beside"])
-def test_strip_rasteriser_is_bit_exact(dg, scene1993, scene1994, oracle_scene1993, oracle_scene1994, path1993, path1994, monkeypatch, side):
-    """DOOMGPU_STRIPS=1: dg_resolve_columns + dg_raster_strips (tiles made of opaque spans only) + dg_raster_tile_list (tiles a
-    masked wall / sprite touches), against the oracle at sizes with full and partial strips and bands, both maps."""
-    monkeypatch.setenv("DOOMGPU_STRIPS", "1")
-    monkeypatch.setenv("DOOMGPU_SIDE_TILES", side)
+def test_sizes_with_partial_tiles_are_bit_exact(dg, scene1993, scene1994, oracle_scene1993, oracle_scene1994, path1993, path1994):
+    """Frame sizes whose last tile column / tile row is partial (132x67, 64x48), the reference's native 1024x768 and 2560x1600, both
+    maps, against the oracle (constants.rs:3-17: any W x H is legal)."""
     for (scene, osc, path, sizes) in ((scene1993, oracle_scene1993, path1993, ((320, 200), (1280, 800), (132, 67), (64, 48), (1024, 768))),
                                       (scene1994, oracle_scene1994, path1994, ((320, 200), (2560, 1600)))):
         for (W, H) in sizes:
             idx = list(range(0, 1000, 125 if W * H > 70000 else 40))
             ctx = make_ctx(dg, scene, W, H, len(idx))
             out = ctx.render(dg.make_views(path[idx]))
-            assert ctx.timing(0)["strips_ms"] > 0.0 and ctx.fallbacks()["segments"] == 0
             for k, i in enumerate(idx):
                 assert np.array_equal(out[k], np.frombuffer(osc.render(W, H, path[i]), dtype=np.uint8).reshape(H, W, 3)), f"frame {i} at {W}x{H}"
             ctx.close()
 
 
-@pytest.mark.parametrize("strips", ["0", "1"], ids=["tiles", "strips"])
-def test_overlapped_slots_device_front_end(dg, scene1993, path1993, monkeypatch, strips):
+def test_overlapped_slots_device_front_end(dg, scene1993, path1993):
     """Four slots submitted back to back with no waits (the column scratch is shared between slots and ordered only by the
     event chain in enqueue_kernels), replayed in rotated order, then waited: every slot's frames must equal a quiet render."""
-    monkeypatch.setenv("DOOMGPU_STRIPS", strips)
     W, H, B, S = 320, 200, 40, 4
     batches = [path1993[s * 250:s * 250 + B] for s in range(S)]
     quiet = dg.Context(W, H, max_batch=B, slots=1, front_end=dg.DG_FE_DEVICE)
@@ -618,6 +586,35 @@ def test_async_readback_overlaps_and_matches(dg, scene1993, path1993):
         assert np.array_equal(got, ctx.readback(s, 0, B)), f"slot {s}"
     for b in bufs:
         dg.lib().dg_free_host(b)
+    ctx.close()
+
+
+def test_rerendering_a_slot_completes_its_pending_readback_first(dg, scene1993, path1993):
+    """A dg_readback_async still copying (300 MB here) when the slot is rendered into again — dg_replay_slot, dg_prepare_views with
+    OTHER views, dg_upload_scene — must be completed first: the host buffer holds the frames of the submission it was queued
+    behind, never a mix (include/doomgpu.h: dg_readback_async)."""
+    W, H, B = 1280, 800, 100
+    ctx = dg.Context(W, H, max_batch=B, slots=1)
+    ctx.upload_scene(scene1993)
+    va, vb = dg.make_views(path1993[0:B]), dg.make_views(path1993[500:500 + B])
+    want_a = ctx.render(va).copy()
+    buf = dg.lib().dg_alloc_host(B * ctx.frame_bytes)
+    assert buf
+    host = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctypes.c_uint8)), shape=(B, H, W, 3))
+    for how in ("prepare+replay", "replay", "upload_scene"):
+        ctx.submit(0, va)
+        host[:] = 0
+        ctx.readback_async(0, 0, B, buf)
+        if how == "prepare+replay":
+            ctx.prepare(0, vb)                            # different frames into the same framebuffer
+            ctx.replay(0)
+        elif how == "replay":
+            ctx.replay(0)
+        else:
+            ctx.upload_scene(scene1993)
+        ctx.wait(0)
+        assert np.array_equal(host, want_a), how
+    dg.lib().dg_free_host(buf)
     ctx.close()
 
 
