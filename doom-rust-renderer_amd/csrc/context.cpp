@@ -166,7 +166,7 @@ struct dg_ctx {
     const Scene *scene = nullptr;
     size_t uploaded_texels = 0;         // texel pool size at dg_upload_scene time (grows when new sprite bitmaps are decoded)
     // device scene
-    uint32_t *d_palette = nullptr;
+    uint32_t *d_palette = nullptr;      // 256 x u32 RGBX, followed by 256 x (r, g, b, 0) f32
     uint8_t *d_texel_idx = nullptr, *d_texel_opq = nullptr, *d_flats = nullptr;
     unsigned long long *d_checksums = nullptr;   // dg_frame_checksums scratch, max_batch entries
     uint4 *d_row_tab = nullptr;         // per-row constants of the flat / sky mappers (dg_row_table), rebuilt per scene upload
@@ -760,7 +760,9 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     uint32_t pal[256];
     for (int i = 0; i < 256; i++) pal[i] = (uint32_t)sc.palette[3 * i] | ((uint32_t)sc.palette[3 * i + 1] << 8) | ((uint32_t)sc.palette[3 * i + 2] << 16);
     const size_t nt = std::max<size_t>(sc.texel_idx.size(), 16), nf = std::max<size_t>(sc.flat_pool.size(), 16);
-    HIP_TRY(hipMalloc((void **)&c->d_palette, sizeof pal));
+    float palf[256 * 4];
+    for (int i = 0; i < 256; i++) { palf[4 * i] = (float)sc.palette[3 * i]; palf[4 * i + 1] = (float)sc.palette[3 * i + 1]; palf[4 * i + 2] = (float)sc.palette[3 * i + 2]; palf[4 * i + 3] = 0.0f; }
+    HIP_TRY(hipMalloc((void **)&c->d_palette, sizeof pal + sizeof palf));
     // [column-major texel index plane | flats] share one allocation: the tile rasteriser gathers every kind's texel with one
     // 32-bit offset from texel_idx (flats at flats - texel_idx)
     const size_t flats_at = (nt + 255) & ~(size_t)255;
@@ -768,13 +770,14 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     HIP_TRY(hipMalloc((void **)&c->d_texel_opq, nt));
     c->d_flats = c->d_texel_idx + flats_at;
     HIP_TRY(hipMemcpy(c->d_palette, pal, sizeof pal, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_palette + 256, palf, sizeof palf, hipMemcpyHostToDevice));
     if (!sc.texel_idx.empty()) {
         HIP_TRY(hipMemcpy(c->d_texel_idx, sc.texel_idx.data(), sc.texel_idx.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_texel_opq, sc.texel_opq.data(), sc.texel_opq.size(), hipMemcpyHostToDevice));
     }
     if (!sc.flat_pool.empty()) HIP_TRY(hipMemcpy(c->d_flats, sc.flat_pool.data(), sc.flat_pool.size(), hipMemcpyHostToDevice));
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
-    c->dscene = DevScene{c->d_palette, c->d_texel_idx, c->d_texel_opq, c->d_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
+    c->dscene = DevScene{c->d_palette, reinterpret_cast<const float *>(c->d_palette + 256), c->d_texel_idx, c->d_texel_opq, c->d_flats, sky.texel_off, sky.w, sky.h, sky.has_holes};
     if (!c->d_row_tab) HIP_TRY(hipMalloc((void **)&c->d_row_tab, (size_t)c->cfg.height * sizeof(uint4)));
     HIP_TRY(launch_row_table(c->dscene, c->dk, c->d_row_tab, nullptr));
     HIP_TRY(hipDeviceSynchronize());

@@ -108,7 +108,7 @@ DG_HD DevRSpan fe_resolve(const FeParams &P, const DevFrame &fr, const FeFrame &
     }
     if (kind == SPAN_FLAT) {
         const FePart &p = P.parts[ff.part_base + idx];
-        return resolve_flat_span(fe_span(ctop, cbot, 0, 0, SPAN_FLAT, x), (cs.w & FES_CEIL) ? p.ceil_plane : p.floor_plane, P.k);
+        return resolve_flat_span(fe_span(ctop, cbot, 0, 0, SPAN_FLAT, x), (cs.w & FES_CEIL) ? p.ceil_plane : p.floor_plane, P.k, (uint32_t)(P.scene.flats - P.scene.texel_idx));
     }
     return resolve_sky_span(fe_span(ctop, cbot, 0, 0, SPAN_SKY, x), P.scene, P.k, fr);
 }

@@ -7,7 +7,7 @@
 //                            self-contained 32-byte DevRSpan.
 // Kernel 2  dg_raster_tiles  one workgroup (8 wavefronts) per (frame, 64-column x 64-row tile), lane = row:
 //                              * the spans of the tile's 64 columns are ONE contiguous range of the column-major span array; they
-//                                are staged in LDS in their per-pixel form (stage_tile_span) with a single coalesced burst (16 KB),
+//                                are copied to LDS (they are in their per-pixel form already) with a single coalesced burst (16 KB),
 //                                together with the palette (as f32x4) and the tile's column offsets — one barrier;
 //                              * a wavefront owns eight of the tile's columns.  One pre-filter pass with lane = (column, span slot)
 //                                finds, for all eight at once, the spans that touch the tile's rows; then the wave takes one column
@@ -25,9 +25,12 @@
 // divide expansion keeps its own internal FMAs, which is what makes it correctly rounded).
 // Experiment builds (make variant VARIANT=x EXTRA="-D..."; never defined in the product build; results in profiles/r02_*.md):
 //   DG_EXP_T_LDSPAD=bytes   pad the tile kernel's LDS (occupancy experiment)      DG_EXP_T_TIMING   per-wave s_memtime phase probe (device printf)
+//   DG_EXP_ABL=n   ablations for instruction attribution with PMC (wrong pixels): 1 no column work, 2 no overlay passes, 3 no read-out,
+//                  4 owners only (no mapper / gather / shade), 5 = 1 + 3, 6 no mapper (owner + gather + shade of a fixed texel)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256) void dg_setup_spans(RasterParams P) {
     const DevSpan sp = P.spans[fr.span_base + i];
     DevRSpan o;
     if (sp.kind == SPAN_WALL) o = resolve_wall_span(sp, P.walls[fr.wall_base + sp.rec]);
-    else if (sp.kind == SPAN_FLAT) o = resolve_flat_span(sp, P.planes[fr.plane_base + sp.rec], P.k);
+    else if (sp.kind == SPAN_FLAT) o = resolve_flat_span(sp, P.planes[fr.plane_base + sp.rec], P.k, (uint32_t)(P.scene.flats - P.scene.texel_idx));
     else o = resolve_sky_span(sp, P.scene, P.k, fr);
     uint4 *dst = reinterpret_cast<uint4 *>(&P.rspans[fr.span_base + i]);
     dst[0] = make_uint4(o.w[0], o.w[1], o.w[2], o.w[3]);
@@ -104,8 +107,9 @@ __device__ __forceinline__ uint32_t shade_f(const float4 c, float factor) {
     return o;
 }
 
-// ---- spans as the tile kernel keeps them in LDS (stage_tile_span); record 0 of the staging area is the "nothing" record that an
-// unowned row points at (a sky span with factor 0 -> 0,0,0), records 1.. are the tile's spans ------------------------------------
+// ---- spans as the tile kernel keeps them in LDS: the DevRSpan words as dg_setup_spans / dg_fe_scatter wrote them (lists_dev.h) except
+// word 0, which is replaced (the row range lives in lw0); record 0 of the staging area is the "nothing" record that an unowned row
+// points at (a sky span with factor 0 -> 0,0,0), records 1.. are the tile's spans ----------------------------------------------
 //   WALL  a.x = hm (< 0x4000_0000): h - 1 for a power-of-two bitmap height, else 0x8000 | h;  a.y = d;  a.z = start of the texture
 //         column (column-major planes);  a.w = light factor;  b.x = uy1;  b.y = top_y | off_y << 16;  b.z = h as f32, NEGATED when h
 //         is not a power of two;  b.w = prepared reciprocal of d
@@ -113,7 +117,7 @@ __device__ __forceinline__ uint32_t shade_f(const float4 c, float factor) {
 //         b.x = gwz;  b.y = light_level / 255;  b.z = fast-divide-ok << 8
 //   SKY   a.x = 0x8000_0000 | .. (negative as i32);  a.z = offset of the sky texture column (0 when the reference would index outside
 //         the bitmap);  a.w = 1.0f (0.0f in that case)
-struct RowConsts {              // per screen row = per lane, fixed for the tile
+struct RowConsts {              // per screen row = per lane, fixed for the tile (dg_row_table)
     int y;
     float vy, r_vy;             // CFY - y (visplanes.rs:109) and its prepared reciprocal
     uint32_t row_fast;          // 0x100 unless vy == 0 (that row takes the plain divide: x / 0)
@@ -121,21 +125,11 @@ struct RowConsts {              // per screen row = per lane, fixed for the tile
     float sky_fac;              // 1.0f, 0.0f when outside the bitmap
 };
 
-__device__ __forceinline__ void stage_tile_span(uint4 &a, uint4 &b, uint32_t flats_rel) {
-    const uint32_t kind = w0_kind(a.x);
-    if (kind == SPAN_WALL) {
-        const uint32_t h = b.z & 0xffffu;
-        const bool pot = (h & (h - 1)) == 0;
-        stage_wall_span(a.y, a.z, b.z, b.w);
-        a.x = pot ? h - 1 : 0x8000u | h;
-        b.z = f32_bits(pot ? (float)h : -(float)h);
-    } else if (kind == SPAN_FLAT) {
-        a.z += flats_rel;
-    } else {
-        const bool valid = a.z != 0xffffffffu;
-        a.z = valid ? a.z : 0u;
-        a.w = f32_bits(valid ? 1.0f : 0.0f);
-    }
+// Word 0 of a staged span from the record's words 0 and 6: walls get their height mask, the other kinds keep their kind bits.
+__device__ __forceinline__ uint32_t staged_w0(uint32_t w0, uint32_t w6) {
+    const float hs = bits_f32(w6);
+    const uint32_t h = (uint32_t)__builtin_fabsf(hs);
+    return w0_kind(w0) == SPAN_WALL ? (hs > 0.0f ? h - 1u : 0x8000u | h) : w0;
 }
 
 // Texel offset of one wall pixel (bitmap_render.rs:256-263) from the staged words.  A wave in which some lane's bitmap height is not
@@ -295,7 +289,7 @@ constexpr int PACK_ROWS = 8;      // a tile with no more live rows than this is 
 
 struct TileLds {
     uint32_t tile[TILE_W * TILE_TS];        // [col][row]: conflict-free for lane = row writes
-    uint4 lspans[(SPAN_CAP + 1) * 2];       // record 0: "nothing"; records 1 ..: the staged spans (stage_tile_span)
+    uint4 lspans[(SPAN_CAP + 1) * 2];       // record 0: "nothing"; records 1 ..: the staged spans
     uint32_t lw0[SPAN_CAP];
     float4 pal[256];                        // r, g, b as f32
     uint32_t lcoff[TILE_W + 1];
@@ -304,8 +298,11 @@ struct TileLds {
 #endif
 };
 
-// One 64 x 64 tile of frame f: columns x0 .., rows y0 ..
-__device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int f, int x0, int y0) {
+// The tile rows [ty_begin, ty_end) of one 64-column strip of frame f (columns x0 ..): the strip's spans, the palette and the column
+// offsets are staged ONCE, then the 64 x 64 tiles are rendered one after another out of the same staging area.  What a tile costs
+// besides its pixels — the load -> LDS -> barrier chain in front, the workgroup launch and drain around it — is paid once per strip
+// segment instead of once per tile (profiles/r03_raster_tiles.md: that fixed part was two thirds of the kernel's time).
+__device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, int f, int x0, int ty_begin, int ty_end) {
 #ifdef DG_EXP_T_TIMING
     unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #define DG_PHASE(k) { const unsigned long long tnow = __builtin_readcyclecounter(); tm[k] += tnow - tprev; tprev = tnow; }
@@ -316,59 +313,62 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
     const int W = P.k.W, H = P.k.H;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int y = y0 + lane;
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
     const uint4 *gspans = reinterpret_cast<const uint4 *>(P.rspans + fr.span_base);
-    const uint32_t flats_rel = (uint32_t)(P.scene.flats - P.scene.texel_idx);   // one allocation: [texel index plane | flats]
 
     // The spans of adjacent columns are one contiguous range of the column-major span array: [col_off[x0], col_off[x0 + 64]).  The two
     // ends are wave-uniform (scalar loads); when the range fits in LDS — the normal case — every thread fetches its span straight
-    // away, together with the palette, the 65 column offsets and the row constants, and ONE barrier publishes all of it.  Wall
-    // spans are put into their per-pixel form on the way (stage_wall_tile: texture column start, prepared 1/d, height mask).
+    // away, together with its palette entry (already f32x4 in HBM) and the 65 column offsets, and ONE barrier publishes all of it.
+    // The records are in their per-pixel form already (raster_core.h resolve_*_span): staging is a copy.
     const uint32_t t_first = coff[x0 < W ? x0 : W], t_last = coff[x0 + TILE_W < W ? x0 + TILE_W : W];
     const bool fits = t_last - t_first <= (uint32_t)SPAN_CAP;
-    uint4 sa = make_uint4(0u, 0u, 0u, 0u), sb = sa;
-    const bool mine = fits && threadIdx.x < t_last - t_first;
-    if (mine) {
-        sa = gspans[2 * ((size_t)t_first + threadIdx.x)];
-        sb = gspans[2 * ((size_t)t_first + threadIdx.x) + 1];
+    {
+        uint4 sa = make_uint4(0u, 0u, 0u, 0u), sb = sa;
+        const bool mine = fits && threadIdx.x < t_last - t_first;
+        if (mine) {
+            sa = gspans[2 * ((size_t)t_first + threadIdx.x)];
+            sb = gspans[2 * ((size_t)t_first + threadIdx.x) + 1];
+        }
+        float4 pal_v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (threadIdx.x < 256) pal_v = reinterpret_cast<const float4 *>(P.scene.palette_f32)[threadIdx.x];
+        const int xc = x0 + (int)(threadIdx.x <= TILE_W ? threadIdx.x : 0);
+        const uint32_t coff_v = coff[xc < W ? xc : W];
+        if (threadIdx.x < 256) L.pal[threadIdx.x] = pal_v;
+        if (threadIdx.x <= TILE_W) L.lcoff[threadIdx.x] = coff_v;
+        if (mine) {
+            L.lw0[threadIdx.x] = sa.x;
+            sa.x = staged_w0(sa.x, sb.z);
+            L.lspans[2 * threadIdx.x + 2] = sa;
+            L.lspans[2 * threadIdx.x + 3] = sb;
+        }
+        if (threadIdx.x == THREADS - 1) {         // the "nothing" record: a sky span with factor 0
+            L.lspans[0] = make_uint4(0x80000000u, 0u, 0u, 0u);
+            L.lspans[1] = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
-    const uint4 rt = P.row_tab[y < H ? y : H - 1];                    // prepared reciprocal of vy and the sky row (dg_row_table)
-    // A tile with at most 8 live rows (the last tile row of a 200-row frame): a wave can take all eight of its columns in ONE pass,
-    // lane = (column, row) = (lane >> 3, lane & 7).  Its row constants:
-    const bool few_rows = H - y0 <= PACK_ROWS;
-    const int yp = y0 + (lane & (PACK_ROWS - 1));
-    uint4 rtp = make_uint4(0u, 0u, 0u, 0u);
-    if (few_rows) rtp = P.row_tab[yp < H ? yp : H - 1];
-    const uint32_t pal_v = P.scene.palette[threadIdx.x & 255];
-    const int xc = x0 + (int)(threadIdx.x <= TILE_W ? threadIdx.x : 0);
-    const uint32_t coff_v = coff[xc < W ? xc : W];
     auto row_consts = [&](int yy, const uint4 t) {
         RowConsts r;
         r.y = yy;
-        r.vy = P.k.CFY - (float)yy;
         r.r_vy = bits_f32(t.x);
-        r.row_fast = r.vy != 0.0f ? 0x100u : 0u;
-        r.sky_row = (int)t.y < 0 ? 0u : t.y;
-        r.sky_fac = (int)t.y < 0 ? 0.0f : 1.0f;
+        r.vy = bits_f32(t.y);
+        r.row_fast = t.z & 0x100u;
+        r.sky_row = t.z & 0xffu;
+        r.sky_fac = bits_f32(t.w);
         return r;
     };
-    const RowConsts R = row_consts(y, rt);
-    if (threadIdx.x < 256) L.pal[threadIdx.x] = make_float4((float)(pal_v & 255u), (float)((pal_v >> 8) & 255u), (float)((pal_v >> 16) & 255u), 0.0f);
-    if (threadIdx.x <= TILE_W) L.lcoff[threadIdx.x] = coff_v;
-    if (mine) {
-        L.lw0[threadIdx.x] = sa.x;
-        stage_tile_span(sa, sb, flats_rel);
-        L.lspans[2 * threadIdx.x + 2] = sa;
-        L.lspans[2 * threadIdx.x + 3] = sb;
-    }
-    if (threadIdx.x == THREADS - 1) {         // the "nothing" record: a sky span with factor 0
-        L.lspans[0] = make_uint4(0x80000000u, 0u, 0u, 0u);
-        L.lspans[1] = make_uint4(0u, 0u, 0u, 0u);
-    }
+    uint8_t *fb = P.fb + (size_t)f * (size_t)3 * (size_t)W * (size_t)H;
     DG_PHASE(0)
     __syncthreads();
     DG_PHASE(1)
+
+  for (int ty = ty_begin; ty < ty_end; ty++) {
+    const int y0 = ty * TILE_H;
+    const int y = y0 + lane;
+    const uint4 rt = P.row_tab[y < H ? y : H - 1];                    // dg_row_table
+    // A tile with at most 8 live rows (the last tile row of a 200-row frame): a wave can take all eight of its columns in ONE pass,
+    // lane = (column, row) = (lane >> 3, lane & 7).  Its row constants:
+    const bool few_rows = H - y0 <= PACK_ROWS;
+    const RowConsts R = row_consts(y, rt);
 
     int c_lo = 0;
     while (c_lo < TILE_W) {
@@ -383,7 +383,7 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
             for (uint32_t i = threadIdx.x; i < n_stage; i += THREADS) {
                 uint4 a = gspans[2 * ((size_t)t0 + i)], b = gspans[2 * ((size_t)t0 + i) + 1];
                 L.lw0[i] = a.x;
-                stage_tile_span(a, b, flats_rel);
+                a.x = staged_w0(a.x, b.z);
                 L.lspans[2 * i + 2] = a;
                 L.lspans[2 * i + 3] = b;
             }
@@ -414,7 +414,8 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
             // ---- eight columns x eight rows in one pass.  Lane (k, r) owns row r of the wave's column k; that column's spans sit in the
             // eight lanes of its own group (the pre-filter's layout), so the owner search is eight lane-permutes of one packed word
             // (first row | row count - 1 << 16; a span that does not count can never match).
-            const RowConsts Rp = row_consts(yp, rtp);
+            const int yp = y0 + (lane & (PACK_ROWS - 1));
+            const RowConsts Rp = row_consts(yp, P.row_tab[yp < H ? yp : H - 1]);
             const uint32_t mine_word = (f_hit && !w0_immediate(f_w0)) ? (v_lo | (v_rg << 16)) : 0x0000ffffu;
             const uint32_t off_first = v_off - 32u * (uint32_t)fslot;          // staging offset of the column's first span
             uint32_t winner = 0;
@@ -442,15 +443,30 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
             } else {
                 C.winner = owner_loop(hit_op & colmask, v_lo, v_rg, v_off, R, 0u);
             }
+#if defined(DG_EXP_ABL) && (DG_EXP_ABL == 4)
+            C.tex = C.winner; C.factor = 0.0f;
+#elif defined(DG_EXP_ABL) && (DG_EXP_ABL == 6)
+            C.factor = bits_f32(C.winner);
+            C.tex = P.scene.texel_idx[C.winner];
+#else
             const uint32_t o = owner_texel(fr, L.lspans, C.winner, R, C.factor);
             C.tex = P.scene.texel_idx[o];                    // in flight until stage 2
+#endif
             DG_PHASE(3)
         };
         auto stage2 = [&](int k, const Col &C) {
             const unsigned long long colmask = 0xffull << (8 * k);
+#if defined(DG_EXP_ABL) && (DG_EXP_ABL == 4)
+            uint32_t px = C.tex;
+#else
             uint32_t px = shade_f(L.pal[C.tex], C.factor);
+#endif
             DG_PHASE(4)
+#if defined(DG_EXP_ABL) && (DG_EXP_ABL == 2 || DG_EXP_ABL == 4 || DG_EXP_ABL == 6)
+            if (false) {
+#else
             if (big & colmask) {
+#endif
                 const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
                 px = big_column_overlays(P, L.pal, L.lw0 + n0, L.lspans, 32u * (n0 + 1u), n, lane, y0, R, C.winner, px);
             } else if (hit_ov & colmask) {
@@ -462,7 +478,12 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
             DG_PHASE(5)
         };
         Col A, B;
+#if defined(DG_EXP_ABL) && (DG_EXP_ABL == 1 || DG_EXP_ABL == 5)
+        for (int k = 0; k < nk; k++) L.tile[(c_lo + wave + WAVES * k) * TILE_TS + lane] = (uint32_t)(hit_op >> (8 * k)) ^ v_lo ^ (uint32_t)(hit_ov | hit_ovwall | big);
+        if (false) {
+#else
         if (nk == WAVES) {                                           // a whole tile's worth (the normal case): one loop shape, no conditionals
+#endif
             stage1(0, A);                                            // A and B alternate so that an in-flight texel never changes register
             for (int k = 1; k < WAVES - 1; k += 2) {
                 stage1(k, B);
@@ -489,13 +510,16 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
 
     // Read-out: groups of 4 pixels of a row (4 LDS words -> 12 B of RGB24), 16 groups per tile row; the 64 lanes of a wave take
     // 4 rows x 16 groups in an order that is conflict-free in LDS; 8 adjacent lanes write 96 contiguous bytes.
-    uint8_t *fb = P.fb + (size_t)f * (size_t)3 * (size_t)W * (size_t)H;
     const int gc = (lane & 7) | ((lane >> 5) << 3), rsub = (lane >> 3) & 3;
 #pragma unroll
     for (int pass = 0; pass < TILE_H / (4 * WAVES); pass++) {
         const int row = pass * 4 * WAVES + wave * 4 + rsub;
         const int yy = y0 + row, xx = x0 + 4 * gc;
+#if defined(DG_EXP_ABL) && (DG_EXP_ABL == 3 || DG_EXP_ABL == 5)
+        if (yy < H && xx < W && L.tile[row] == 0x12345678u) {
+#else
         if (yy < H && xx < W) {   // W % 4 == 0 (checked at dg_create), so a group never straddles the right edge
+#endif
             const uint32_t p0 = L.tile[(4 * gc + 0) * TILE_TS + row], p1 = L.tile[(4 * gc + 1) * TILE_TS + row];
             const uint32_t p2 = L.tile[(4 * gc + 2) * TILE_TS + row], p3 = L.tile[(4 * gc + 3) * TILE_TS + row];
             uint32_t *dst = reinterpret_cast<uint32_t *>(fb + ((size_t)yy * (size_t)W + (size_t)xx) * 3);
@@ -504,29 +528,35 @@ __device__ __forceinline__ void tile_body(const RasterParams &P, TileLds &L, int
             dst[2] = ((p2 >> 16) & 0xffu) | (p3 << 8);
         }
     }
+    if (ty + 1 < ty_end) __syncthreads();     // the LDS tile (and, when the spans did not fit, the staging area) is written again
+  }
 #ifdef DG_EXP_T_TIMING
     DG_PHASE(7)
-    if (lane == 0 && f == 100 && (x0 / TILE_W) % 5 == 2 && (y0 / TILE_H) % 4 == 1)
-        printf("[tile %d,%d wave %d] load+stage %llu barrier %llu between %llu stage1 %llu gather+shade %llu overlays+write %llu end-barrier %llu readout %llu\n", x0 / TILE_W,
-               y0 / TILE_H, wave, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7]);
+    if (lane == 0 && f == 100 && (x0 / TILE_W) % 5 == 2)
+        printf("[strip %d rows %d-%d wave %d] load+stage %llu barrier %llu between %llu stage1 %llu gather+shade %llu overlays+write %llu end-barrier %llu readout %llu\n", x0 / TILE_W,
+               ty_begin, ty_end, wave, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7]);
 #endif
 }
 
 // (launch bounds: 8 waves per SIMD = at most 64 VGPRs; one more register costs a fourth of the resident workgroups, 0.58 -> 0.67 ms)
-// Every tile of every frame.
+// One workgroup per (frame, 64-column strip, segment of P.tile_rows_per_wg tile rows).
 __global__ __launch_bounds__(THREADS, 8) void dg_raster_tiles(RasterParams P) {
     __shared__ __attribute__((aligned(16))) TileLds L;
-    tile_body(P, L, (int)blockIdx.z, (int)blockIdx.x * TILE_W, (int)blockIdx.y * TILE_H);
+    const int n_tile_rows = (P.k.H + TILE_H - 1) / TILE_H;
+    const int ty_begin = (int)blockIdx.y * P.tile_rows_per_wg;
+    strip_body(P, L, (int)blockIdx.z, (int)blockIdx.x * TILE_W, ty_begin, min(n_tile_rows, ty_begin + P.tile_rows_per_wg));
 }
 
-// Per-row constants of the flat and sky mappers for one frame size: the prepared reciprocal of vy = CFY - y (visplanes.rs:109)
-// and the sky texture row (visplanes.rs:68-72).  Same device code as the per-lane computation it replaces, run once per
-// scene upload instead of once per wavefront (~35 VALU instructions of every raster wave).
+// Per-row constants of the flat and sky mappers for one frame size: vy = CFY - y (visplanes.rs:109), its prepared reciprocal, the
+// "prepared divide allowed" bit (not on the vy == 0 row) and the sky texture row (visplanes.rs:68-72; row 0 with factor 0 when it is
+// outside the bitmap).  Same device code as the per-lane computation it replaces, run once per scene upload instead of once per tile.
+//   x = bits of prepare_rcp(vy)   y = bits of vy   z = sky row | 0x100 when vy != 0   w = bits of the sky factor (1.0f / 0.0f)
 __global__ void dg_row_table(DevScene scene, DevConsts k, uint4 *row_tab) {
     const int y = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (y >= k.H) return;
     const float vy = k.CFY - (float)y;
-    row_tab[y] = make_uint4(f32_bits(prepare_rcp(vy)), (uint32_t)sky_row(scene, k, y), f32_bits(vy), 0u);
+    const int32_t srow = sky_row(scene, k, y);
+    row_tab[y] = make_uint4(f32_bits(prepare_rcp(vy)), f32_bits(vy), (srow < 0 ? 0u : (uint32_t)srow) | (vy != 0.0f ? 0x100u : 0u), f32_bits(srow < 0 ? 0.0f : 1.0f));
 }
 
 // Order-independent per-frame checksum (dg_frame_checksums): every dword is mixed with its index, the mixes are summed.
@@ -562,9 +592,19 @@ hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hip
     return hipGetLastError();
 }
 
-hipError_t launch_raster(const RasterParams &P, hipStream_t stream) {
-    if (P.n_frames <= 0) return hipSuccess;
-    dim3 grid((unsigned)((P.k.W + TILE_W - 1) / TILE_W), (unsigned)((P.k.H + TILE_H - 1) / TILE_H), (unsigned)P.n_frames);
+int raster_tile_rows_per_wg(int H) {
+    const int n_tile_rows = (H + TILE_H - 1) / TILE_H;
+    int rows = 1;                                                     // TODO(tuning): chosen by measurement, profiles/r03_raster_tiles.md
+    if (const char *e = std::getenv("DOOMGPU_EXP_TILE_ROWS")) rows = std::max(1, std::atoi(e));
+    return std::min(rows, n_tile_rows);
+}
+
+hipError_t launch_raster(const RasterParams &P_in, hipStream_t stream) {
+    if (P_in.n_frames <= 0) return hipSuccess;
+    RasterParams P = P_in;
+    const int n_tile_rows = (P.k.H + TILE_H - 1) / TILE_H;
+    if (P.tile_rows_per_wg <= 0) P.tile_rows_per_wg = raster_tile_rows_per_wg(P.k.H);
+    dim3 grid((unsigned)((P.k.W + TILE_W - 1) / TILE_W), (unsigned)((n_tile_rows + P.tile_rows_per_wg - 1) / P.tile_rows_per_wg), (unsigned)P.n_frames);
     hipLaunchKernelGGL(dg_raster_tiles, grid, dim3(THREADS), 0, stream, P);
     return hipGetLastError();
 }

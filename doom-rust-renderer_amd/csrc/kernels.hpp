@@ -17,8 +17,9 @@ struct RasterParams {
     const DevWallRec *walls;
     const DevPlaneRec *planes;
     uint8_t *fb;                 // n_frames x 3*W*H, RGB24
-    const uint4 *row_tab;        // [H] per screen row: x = bits of prepare_rcp(CFY - y), y = sky texture row (or -1), z = bits of CFY - y; dg_row_table
+    const uint4 *row_tab;        // [H] per screen row: prepared 1 / vy, vy = CFY - y, sky row | fast-divide bit, sky factor (dg_row_table, kernels.hip)
     int32_t n_frames;
+    int32_t tile_rows_per_wg;    // tile rows one workgroup of dg_raster_tiles renders out of one staging pass; <= 0: launch_raster picks
 };
 
 hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hipStream_t stream);

@@ -26,23 +26,19 @@ struct DevSpan {              // one vertical run of one draw call in one screen
 };
 static_assert(sizeof(DevSpan) == 16, "DevSpan must be 16 bytes");
 
-struct DevSpanAux {           // setup-kernel output
-    uint32_t texcol;          // WALL/SKY: texel offset of the bitmap column (bitmap off + tx*h)
-    float factor;             // WALL: light_level/255 - z/4096 clamped at 0 (diminish_color, bitmap_render.rs:190-201)
-};
-static_assert(sizeof(DevSpanAux) == 8, "DevSpanAux must be 8 bytes");
-
 // The column-major, draw-ordered list the rasteriser starts from: one self-contained 32-byte record per span, written by
 // the setup kernel (host lists) or dg_fe_scatter (device column walk) from DevSpan + its wall/plane record.
 //   word   WALL (bitmap_render.rs:241-263)                    FLAT (visplanes.rs:103-126)           SKY (visplanes.rs:65-72)
 //   w0     ctop | imm << 15 | cbot << 16 | kind << 30          same                                   same      (imm: may be transparent)
 //   w1     d = (bottom_y - top_y) as f32                      wz * vx (f32)                          -
-//   w2     texel offset of the bitmap                         byte offset of the 64x64 flat          column-major texel offset of the sky column (or ~0)
-//   w3     light factor (f32, clamped >= 0)                   -                                      -
+//   w2     start of the texture column (texel_off + tx * h)   offset of the 64x64 flat from the      start of the sky texture column
+//                                                             texel index plane (flats follow it)     (0 when tx is outside the bitmap)
+//   w3     light factor (f32, clamped >= 0)                   -                                      1.0f (0.0f when tx is outside)
 //   w4     uy1 = top_height - bottom_height (NaN if d == 0)   gwz = GCFX * wz (f32)                  -
 //   w5     top_y | off_y << 16                                light_level / 255 (f32)                -
-//   w6     h | w << 16                                        fast-divide-ok << 8                    -
-//   w7     tx (texture column)                                -                                      tx (sky texture column, or ~0)
+//   w6     h as f32, NEGATED when h is not a power of two     fast-divide-ok << 8                    -
+//   w7     prepared reciprocal of d (raster_core.h)           -                                      -
+// This is the per-pixel form: a tile of dg_raster_tiles stages the record as it is (only the height mask of a wall is derived).
 struct DevRSpan { uint32_t w[8]; };
 static_assert(sizeof(DevRSpan) == 32, "DevRSpan must be 32 bytes");
 
@@ -80,6 +76,7 @@ static_assert(sizeof(DevFrame) == 48, "DevFrame must be 48 bytes");
 
 struct DevScene {             // immutable, uploaded once per map
     const uint32_t *palette;  // 256 x (r | g<<8 | b<<16)
+    const float *palette_f32; // 256 x (r, g, b, 0) as f32: what a tile of dg_raster_tiles copies to LDS
     const uint8_t *texel_idx; // column-major per bitmap (off + x*h + y): dg_raster_tiles, lane = row
     const uint8_t *texel_opq;
     const uint8_t *flats;

@@ -163,7 +163,8 @@ DG_HD int32_t floor_mod_fast(int32_t t, int32_t n, int32_t pow2_mask, float rcp_
     return r;
 }
 
-// ---- setup: DevSpan + record -> self-contained DevRSpan (one lane per span) ------------------------------------
+// ---- setup: DevSpan + record -> self-contained DevRSpan (one lane per span), already in the form the tile kernel evaluates
+// per pixel (lists_dev.h): nothing is re-derived when a tile stages the span ----------------------------------------------
 
 // Column-invariant part of render_vertical_bitmap_line (bitmap_render.rs:241-251): texture column + light factor.
 DG_HD DevRSpan resolve_wall_span(const DevSpan &sp, const DevWallRec &r) {
@@ -179,24 +180,26 @@ DG_HD DevRSpan resolve_wall_span(const DevSpan &sp, const DevWallRec &r) {
     // `h + (1.0 - ay) * 0.0 + ay * uy1` is NaN for every row (ay is +-Inf or NaN); a NaN uy1 reproduces exactly that,
     // and for a finite ay the middle term is +-0.0 and drops out (h >= 1), so the kernel evaluates h + ay * uy1.
     const float d = (float)((int32_t)sp.bot_y - (int32_t)sp.top_y);
+    const bool pot = (h & (h - 1)) == 0;
     DevRSpan o;
     o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_WALL, r.has_holes != 0);
     o.w[1] = f32_bits(d);
-    o.w[2] = r.texel_off;
+    o.w[2] = r.texel_off + (uint32_t)tx * (uint32_t)h;          // start of the texture column (column-major planes)
     o.w[3] = f32_bits(light_factor(r.lightf, z));
     o.w[4] = d == 0.0f ? 0x7fc00000u : f32_bits(r.uy1);
     o.w[5] = (uint32_t)(uint16_t)sp.top_y | ((uint32_t)(uint16_t)r.off_y << 16);
-    o.w[6] = (uint32_t)(uint16_t)h | ((uint32_t)(uint16_t)r.w << 16);
-    o.w[7] = (uint32_t)tx;
+    o.w[6] = f32_bits(pot ? (float)h : -(float)h);              // the sign says which modulus the pixel needs
+    o.w[7] = f32_bits(prepare_rcp(d));
     return o;
 }
-DG_HD DevRSpan resolve_flat_span(const DevSpan &sp, const DevPlaneRec &p, const DevConsts &k) {
+// flats_rel: offset of the flats from the texel index plane (one allocation, so that every kind gathers from one base).
+DG_HD DevRSpan resolve_flat_span(const DevSpan &sp, const DevPlaneRec &p, const DevConsts &k, uint32_t flats_rel) {
     const float vx = (k.CFX - (float)sp.x) / k.ARC;                      // visplanes.rs:108
     const float wzvx = p.wz * vx;                                        // numerator of wy = wz * vx / vy (visplanes.rs:114)
     DevRSpan o;
     o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_FLAT, false);
     o.w[1] = f32_bits(wzvx);
-    o.w[2] = p.flat_off;
+    o.w[2] = flats_rel + p.flat_off;
     o.w[3] = 0;
     o.w[4] = f32_bits(p.gwz);                                            // numerator of wx = GCFX * wz / vy (visplanes.rs:113)
     o.w[5] = f32_bits(p.lightf);
@@ -204,16 +207,17 @@ DG_HD DevRSpan resolve_flat_span(const DevSpan &sp, const DevPlaneRec &p, const 
     o.w[7] = 0;
     return o;
 }
-// draw_sky's texture column (visplanes.rs:65-66); ~0 when the reference would index outside the sky bitmap.
+// draw_sky's texture column (visplanes.rs:65-66); factor 0 (and column 0) when the reference would index outside the sky bitmap.
 DG_HD DevRSpan resolve_sky_span(const DevSpan &sp, const DevScene &sc, const DevConsts &k, const DevFrame &f) {
     int32_t tx = f32_as_i16((float)sp.x * 256.0f / (float)k.W);
     tx = wrap_i16(tx + f.sky_tx_offset) % 256;
+    const bool valid = tx >= 0 && tx < sc.sky_w;
     DevRSpan o;
     o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_SKY, sc.sky_has_holes != 0);   // a sky bitmap with holes is evaluated in draw order
     o.w[1] = 0;
-    o.w[2] = (tx < 0 || tx >= sc.sky_w) ? 0xffffffffu : sc.sky_texel_off + (uint32_t)tx * (uint32_t)sc.sky_h;
-    o.w[3] = o.w[4] = o.w[5] = o.w[6] = 0;
-    o.w[7] = (tx < 0 || tx >= sc.sky_w) ? 0xffffffffu : (uint32_t)tx;
+    o.w[2] = valid ? sc.sky_texel_off + (uint32_t)tx * (uint32_t)sc.sky_h : 0u;
+    o.w[3] = f32_bits(valid ? 1.0f : 0.0f);
+    o.w[4] = o.w[5] = o.w[6] = o.w[7] = 0;
     return o;
 }
 
@@ -228,20 +232,10 @@ DG_HD int32_t wall_texel_row(float d, float r_d, float uy1, uint32_t w5, int32_t
     const int32_t mask = (h & (h - 1)) == 0 ? h - 1 : 0;
     return floor_mod_fast(ty, h, mask, mask ? 0.0f : approx_rcp((float)h));
 }
-// dg_raster_tiles keeps a wall span in LDS in its per-pixel form: w2 = start of the texture column in the column-major planes,
-// w7 = prepared reciprocal of d (in HBM those words hold the bitmap's offset and tx, so that dg_resolve_columns can also
-// address the row-major pool).
-DG_HD void stage_wall_span(uint32_t w1, uint32_t &w2, uint32_t w6, uint32_t &w7) {
-    w2 += w7 * (w6 & 0xffffu);
-    w7 = f32_bits(prepare_rcp(bits_f32(w1)));
-}
-DG_HD uint32_t wall_texel_offset_staged(uint32_t w1, uint32_t w2, uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7, int32_t y) {
-    return w2 + (uint32_t)wall_texel_row(bits_f32(w1), bits_f32(w7), bits_f32(w4), w5, (int32_t)(w6 & 0xffffu), y);
-}
-// Texel offset of one wall pixel in the column-major planes from the DevRSpan words as they are in HBM.
+// Texel offset of one wall pixel in the column-major planes from the DevRSpan words.
 DG_HD uint32_t wall_texel_offset(uint32_t w1, uint32_t w2, uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7, int32_t y) {
-    const int32_t h = (int32_t)(w6 & 0xffffu);
-    return w2 + w7 * (uint32_t)h + (uint32_t)wall_texel_row(bits_f32(w1), prepare_rcp(bits_f32(w1)), bits_f32(w4), w5, h, y);
+    const int32_t h = (int32_t)__builtin_fabsf(bits_f32(w6));
+    return w2 + (uint32_t)wall_texel_row(bits_f32(w1), bits_f32(w7), bits_f32(w4), w5, h, y);
 }
 
 // Texture coordinates of one floor / ceiling pixel and its light factor (visplanes.rs:108-126).
@@ -261,7 +255,7 @@ DG_HD uint32_t flat_texel_offset(const DevFrame &f, uint32_t w1, uint32_t w2, ui
     int32_t tx = (f32_as_i16(rx) + f.pos_x_i16) & 63;       // wrapping i16 add, then & 63: the low 6 bits are unaffected by the wrap
     int32_t ty = (f32_as_i16(ry) + f.pos_y_i16) & 63;
     factor = light_factor(bits_f32(w5), f32_as_i16(wx));
-    return w2 + (uint32_t)(ty * 64 + tx);
+    return w2 + (uint32_t)(ty * 64 + tx);               // relative to the texel index plane (the flats follow it in one allocation)
 }
 
 // Texture row of a sky pixel (visplanes.rs:68-72): depends on the screen row only; -1 when outside the sky bitmap.
@@ -271,9 +265,9 @@ DG_HD int32_t sky_row(const DevScene &sc, const DevConsts &k, int32_t y) {
     ty %= 128;
     return (ty < 0 || ty >= sc.sky_h) ? -1 : ty;
 }
-// Texel offset of one sky pixel; ~0 when the reference would index outside the sky bitmap.
-DG_HD uint32_t sky_texel_offset(uint32_t w2, int32_t row) {
-    return (w2 == 0xffffffffu || row < 0) ? 0xffffffffu : w2 + (uint32_t)row;
+// Texel offset of one sky pixel; ~0 when the reference would index outside the sky bitmap (w3: the span's factor, 0 when its column is outside).
+DG_HD uint32_t sky_texel_offset(uint32_t w2, uint32_t w3, int32_t row) {
+    return (bits_f32(w3) == 0.0f || row < 0) ? 0xffffffffu : w2 + (uint32_t)row;
 }
 
 }  // namespace dg

@@ -38,9 +38,9 @@ static void raster_spans(const DevScene &ds, const DevConsts &k, const DevFrame 
                     float factor;
                     const float vy = k.CFY - (float)y;
                     uint32_t o = flat_texel_offset(hdr, w[1], w[2], w[4], w[5], w[6], vy, prepare_rcp(vy), factor);
-                    c = shade(pal[ds.flats[o]], factor); wr = true;
+                    c = shade(pal[ds.texel_idx[o]], factor); wr = true;
                 } else {
-                    uint32_t o = sky_texel_offset(w[2], sky_row(ds, k, y));
+                    uint32_t o = sky_texel_offset(w[2], w[3], sky_row(ds, k, y));
                     if (o != 0xffffffffu && ds.texel_opq[o]) { c = pal[ds.texel_idx[o]]; wr = true; }
                 }
                 if (wr) {
@@ -97,8 +97,12 @@ static int emul_render_impl(void *scene, int W, int H, const dg_view *view_in, c
 
     std::vector<uint32_t> pal(256);
     for (int i = 0; i < 256; i++) pal[i] = sc.palette[3 * i] | (sc.palette[3 * i + 1] << 8) | (sc.palette[3 * i + 2] << 16);
-    DevScene ds;
-    ds.palette = pal.data(); ds.texel_idx = sc.texel_idx.data(); ds.texel_opq = sc.texel_opq.data(); ds.flats = sc.flat_pool.data();
+    // [texel index plane | flats] in one buffer, like the device scene: a flat span's offset is relative to the texel plane
+    std::vector<uint8_t> texels(((sc.texel_idx.size() + 255) & ~(size_t)255) + sc.flat_pool.size());
+    std::copy(sc.texel_idx.begin(), sc.texel_idx.end(), texels.begin());
+    std::copy(sc.flat_pool.begin(), sc.flat_pool.end(), texels.begin() + (long)((sc.texel_idx.size() + 255) & ~(size_t)255));
+    DevScene ds{};
+    ds.palette = pal.data(); ds.texel_idx = texels.data(); ds.texel_opq = sc.texel_opq.data(); ds.flats = texels.data() + ((sc.texel_idx.size() + 255) & ~(size_t)255);
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
     ds.sky_texel_off = sky.texel_off; ds.sky_w = sky.w; ds.sky_h = sky.h; ds.sky_has_holes = sky.has_holes;
     DevConsts k{fk.ARC, fk.GCFX, fk.CFX, fk.CFY, W, H};
@@ -107,7 +111,7 @@ static int emul_render_impl(void *scene, int W, int H, const dg_view *view_in, c
     for (size_t i = 0; i < bf.spans.size(); i++) {                       // what dg_setup_spans does (one lane per span)
         const DevSpan &sp = bf.spans[i];
         rs[i] = sp.kind == SPAN_WALL ? resolve_wall_span(sp, bf.walls[sp.rec])
-              : sp.kind == SPAN_FLAT ? resolve_flat_span(sp, bf.planes[sp.rec], k)
+              : sp.kind == SPAN_FLAT ? resolve_flat_span(sp, bf.planes[sp.rec], k, (uint32_t)(ds.flats - ds.texel_idx))
                                      : resolve_sky_span(sp, ds, k, bf.hdr);
     }
     raster_spans(ds, k, bf.hdr, pal.data(), bf.col_off.data(), rs.data(), W, H, rgb);
@@ -136,8 +140,12 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
 
     std::vector<uint32_t> pal(256);
     for (int i = 0; i < 256; i++) pal[i] = sc.palette[3 * i] | (sc.palette[3 * i + 1] << 8) | (sc.palette[3 * i + 2] << 16);
-    DevScene ds;
-    ds.palette = pal.data(); ds.texel_idx = sc.texel_idx.data(); ds.texel_opq = sc.texel_opq.data(); ds.flats = sc.flat_pool.data();
+    // [texel index plane | flats] in one buffer, like the device scene: a flat span's offset is relative to the texel plane
+    std::vector<uint8_t> texels(((sc.texel_idx.size() + 255) & ~(size_t)255) + sc.flat_pool.size());
+    std::copy(sc.texel_idx.begin(), sc.texel_idx.end(), texels.begin());
+    std::copy(sc.flat_pool.begin(), sc.flat_pool.end(), texels.begin() + (long)((sc.texel_idx.size() + 255) & ~(size_t)255));
+    DevScene ds{};
+    ds.palette = pal.data(); ds.texel_idx = texels.data(); ds.texel_opq = sc.texel_opq.data(); ds.flats = texels.data() + ((sc.texel_idx.size() + 255) & ~(size_t)255);
     const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
     ds.sky_texel_off = sky.texel_off; ds.sky_w = sky.w; ds.sky_h = sky.h; ds.sky_has_holes = sky.has_holes;
     DevConsts k{fk.ARC, fk.GCFX, fk.CFX, fk.CFY, W, H};
@@ -228,7 +236,7 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
     for (size_t i = 0; same && i < bf.spans.size(); i++) {
         const DevSpan &sp = bf.spans[i];
         DevRSpan r = sp.kind == SPAN_WALL ? resolve_wall_span(sp, bf.walls[sp.rec])
-                   : sp.kind == SPAN_FLAT ? resolve_flat_span(sp, bf.planes[sp.rec], k)
+                   : sp.kind == SPAN_FLAT ? resolve_flat_span(sp, bf.planes[sp.rec], k, (uint32_t)(ds.flats - ds.texel_idx))
                                           : resolve_sky_span(sp, ds, k, bf.hdr);
         same = std::memcmp(&r, &rspans[i], sizeof r) == 0;
     }
@@ -254,5 +262,101 @@ double emul_time_front_end(void *scene, int W, int H, const dg_view *views, int 
             } else if (build_frame_parts(sc, W, H, v, arena, err)) return -1.0;
         }
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / ((double)iters * n);
+}
+
+// Workload statistics of dg_raster_tiles for one frame (tuning aid, tools/tile_stats.py): what the kernel's loops will meet.
+// out[0] chunks (column x 64-row tile)   [1] opaque span hits (owner-loop trips)   [2] overlay span hits (overlay-loop trips)
+// [3] overlay evaluations (some row covered and not owned by a later opaque span)   [4] chunks whose owners are of one kind only
+// [5] chunks with flat AND wall owners   [6] chunks with exactly one owner span for all live rows   [7] staged spans summed over tiles
+// [8] staged spans that touch their tile's rows   [9] pixels owned by flats   [10] by walls   [11] by sky   [12] by nothing
+// [13] tiles   [14] tiles with an overlay hit   [15] columns with more than 8 spans (summed over tiles)
+// [16] flat chunks (>= 1 flat-owned row)   [17] flat chunks whose flat rows all carry the (gwz, light) of the same rows 8 columns to the left
+int emul_tile_stats(void *scene, int W, int H, const dg_view *view_in, uint64_t *out) {
+    const Scene &sc = *(const Scene *)scene;
+    dg_view view = *view_in;
+    fill_view_trig(view);
+    static thread_local FrameArena arena;
+    static thread_local BinnedFrame bf;
+    dg_frame_lists fl;
+    int rc = build_frame_lists(sc, W, H, view, arena, fl, g_err, nullptr);
+    if (rc) return rc;
+    FrameConsts fk = make_consts(W, H);
+    rc = bin_frame(sc, fk, fl, bf, g_err);
+    if (rc) return rc;
+    for (int i = 0; i < 18; i++) out[i] = 0;
+    const int TH = 64, TW = 64;
+    std::vector<int32_t> owner((size_t)H), prev_key((size_t)W * (size_t)H * 2, 0);
+    std::vector<uint32_t> keyg((size_t)W * (size_t)H, 0), keyl((size_t)W * (size_t)H, 0);
+    std::vector<uint8_t> isflat((size_t)W * (size_t)H, 0);
+    for (int x = 0; x < W; x++) {
+        const uint32_t c0 = bf.col_off[(size_t)x], c1 = bf.col_off[(size_t)x + 1];
+        for (int y = 0; y < H; y++) owner[(size_t)y] = -1;
+        for (uint32_t i = c0; i < c1; i++) {
+            const DevSpan &sp = bf.spans[i];
+            const bool imm = sp.kind == SPAN_WALL ? bf.walls[sp.rec].has_holes != 0 : (sp.kind == SPAN_SKY && sc.bitmaps[(size_t)sc.sky_bitmap].has_holes);
+            if (!imm) for (int y = sp.ctop; y <= sp.cbot; y++) owner[(size_t)y] = (int32_t)i;
+        }
+        for (int y = 0; y < H; y++) {
+            const int32_t o = owner[(size_t)y];
+            if (o < 0) { out[12]++; continue; }
+            const DevSpan &sp = bf.spans[(size_t)o];
+            out[sp.kind == SPAN_FLAT ? 9 : sp.kind == SPAN_WALL ? 10 : 11]++;
+            if (sp.kind == SPAN_FLAT) {
+                isflat[(size_t)y * W + x] = 1;
+                const DevPlaneRec &pr = bf.planes[sp.rec];
+                std::memcpy(&keyg[(size_t)y * W + x], &pr.gwz, 4);
+                std::memcpy(&keyl[(size_t)y * W + x], &pr.lightf, 4);
+            }
+        }
+        for (int y0 = 0; y0 < H; y0 += TH) {
+            const int y1 = std::min(H, y0 + TH) - 1;
+            out[0]++;
+            bool kinds[4] = {false, false, false, false};
+            int32_t first_owner = owner[(size_t)y0];
+            bool single = true;
+            for (int y = y0; y <= y1; y++) {
+                const int32_t o = owner[(size_t)y];
+                single &= o == first_owner;
+                kinds[o < 0 ? 3 : bf.spans[(size_t)o].kind] = true;
+            }
+            const int nk = (int)kinds[0] + (int)kinds[1] + (int)kinds[2];
+            if (nk <= 1) out[4]++;
+            if (kinds[SPAN_FLAT] && kinds[SPAN_WALL]) out[5]++;
+            if (single && first_owner >= 0) out[6]++;
+            if (kinds[SPAN_FLAT]) {
+                out[16]++;
+                bool same = x >= 8;
+                for (int y = y0; same && y <= y1; y++)
+                    if (isflat[(size_t)y * W + x]) same = isflat[(size_t)y * W + x - 8] && keyg[(size_t)y * W + x] == keyg[(size_t)y * W + x - 8] && keyl[(size_t)y * W + x] == keyl[(size_t)y * W + x - 8];
+                if (same) out[17]++;
+            }
+            if (c1 - c0 > 8) out[15]++;
+            for (uint32_t i = c0; i < c1; i++) {
+                const DevSpan &sp = bf.spans[i];
+                if (sp.cbot < y0 || sp.ctop > y1) continue;
+                const bool imm = sp.kind == SPAN_WALL ? bf.walls[sp.rec].has_holes != 0 : (sp.kind == SPAN_SKY && sc.bitmaps[(size_t)sc.sky_bitmap].has_holes);
+                if (!imm) { out[1]++; continue; }
+                out[2]++;
+                bool any = false;
+                for (int y = std::max(y0, (int)sp.ctop); y <= std::min(y1, (int)sp.cbot); y++) any |= owner[(size_t)y] < (int32_t)i;
+                if (any) out[3]++;
+            }
+        }
+    }
+    for (int x0 = 0; x0 < W; x0 += TW)
+        for (int y0 = 0; y0 < H; y0 += TH) {
+            const int x1 = std::min(W, x0 + TW), y1 = std::min(H, y0 + TH) - 1;
+            out[13]++;
+            bool ov = false;
+            for (uint32_t i = bf.col_off[(size_t)x0]; i < bf.col_off[(size_t)x1]; i++) {
+                const DevSpan &sp = bf.spans[i];
+                out[7]++;
+                if (sp.cbot < y0 || sp.ctop > y1) continue;
+                out[8]++;
+                ov |= sp.kind == SPAN_WALL && bf.walls[sp.rec].has_holes != 0;
+            }
+            if (ov) out[14]++;
+        }
+    return 0;
 }
 }

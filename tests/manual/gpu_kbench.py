@@ -9,7 +9,8 @@ sw = importlib.import_module("doom-rust-renderer_amd.synth_wad")
 path = np.fromfile(os.path.join(ROOT, "tests/golden/campath_seed1993.f32"), dtype="<f4").reshape(1000, 8)
 wad = sw.build_synth_iwad(1993)
 osc = doomref.Scene(wad, "e1m1"); sc = dg.Scene(wad, "e1m1")
-for (W, H, B) in [(1280, 800, 250), (320, 200, 1000)]:
+SIZES = [tuple(int(v) for v in t.split("x")) for t in os.environ.get("KBENCH_SIZES", "1280x800x250,320x200x1000").split(",")]
+for (W, H, B) in SIZES:
     ctx = dg.Context(W, H, max_batch=B, slots=1); ctx.upload_scene(sc)
     idx = [0, 100, 297, 323, 623, 728]
     out = ctx.render(dg.make_views(path[idx]))

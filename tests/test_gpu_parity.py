@@ -658,7 +658,7 @@ def test_per_view_game_state_in_one_batch(dg, oracle, wad1993, path1993, front_e
 
 
 def test_the_eight_rank_paths_of_config_4_on_one_gpu(dg, synth, campath_mod, oracle):
-    """BASELINE config 4 as bench.py shards it: rank r of 8 renders camera path seed 1993 + r on map seed 1993 / 1994 alternating.
+    """BASELINE config 4 as bench.py --config 4 shards it: rank r of 8 renders camera path seed 1993 + r on map seed 1993 / 1994 (heavy) alternating.
     Here all eight (map, path) pairs on one GPU: 25 frames of each path at 320x200 through the device column walk against the
     oracle, and two of them at 1280x800 — the frames every rank of the scaling run will produce."""
     import sys
@@ -666,10 +666,10 @@ def test_the_eight_rank_paths_of_config_4_on_one_gpu(dg, synth, campath_mod, ora
     import bench
     scenes = {}
     for rank in range(8):
-        map_seed, path_seed = bench.rank_plan(rank, 8)
+        (map_seed, heavy), path_seed = bench.rank_plan(rank, 8, 4)
         if map_seed not in scenes:
-            wad = synth.build_synth_iwad(map_seed)
-            scenes[map_seed] = (dg.Scene(wad, "e1m1"), oracle.Scene(wad, "e1m1"), synth.synth_route(map_seed))
+            wad = synth.build_synth_iwad(map_seed, heavy=heavy)
+            scenes[map_seed] = (dg.Scene(wad, "e1m1"), oracle.Scene(wad, "e1m1"), synth.synth_route(map_seed, heavy=heavy))
         scene, osc, route = scenes[map_seed]
         path = campath_mod.make_camera_path(bench.seeded_route(route, path_seed), lambda x, y, d: scene.floor_height_at(x, y, d), bench.PATH_FRAMES)
         for (W, H, idx) in ((320, 200, list(range(0, 1000, 40))), (1280, 800, [137, 733])):
