@@ -25,8 +25,6 @@
 // divide expansion keeps its own internal FMAs, which is what makes it correctly rounded).
 // Experiment builds (make variant VARIANT=x EXTRA="-D..."; never defined in the product build; results in profiles/r02_*.md):
 //   DG_EXP_T_LDSPAD=bytes   pad the tile kernel's LDS (occupancy experiment)      DG_EXP_T_TIMING   per-wave s_memtime phase probe (device printf)
-//   DG_EXP_ABL=n   ablations for instruction attribution with PMC (wrong pixels): 1 no column work, 2 no overlay passes, 3 no read-out,
-//                  4 owners only (no mapper / gather / shade), 5 = 1 + 3, 6 no mapper (owner + gather + shade of a fixed texel)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -156,6 +154,24 @@ __device__ __forceinline__ uint32_t flat_offset_tile(const DevFrame &f, const ui
         wx = bits_f32(b.x) / R.vy;
         wy = bits_f32(a.y) / R.vy;
     }
+    const float rx = wx * f.cos_a - wy * f.sin_a;
+    const float ry = wy * f.cos_a + wx * f.sin_a;
+    const int32_t tx = (f32_as_i16(rx) + f.pos_x_i16) & 63;
+    const int32_t ty = (f32_as_i16(ry) + f.pos_y_i16) & 63;
+    factor = __builtin_fmaf(-(float)f32_as_i16(wx), 1.0f / 4096.0f, bits_f32(b.y));
+    return a.z + (uint32_t)(ty * 64 + tx);
+}
+
+// The same two mappers for a column whose 64 rows all belong to ONE plain span (w0_plain): a, b are that span's staged words, the same
+// in every lane, and nothing has to be voted on or selected — the arithmetic per row is exactly the general form's.
+__device__ __forceinline__ uint32_t wall_offset_plain(const uint4 a, const uint4 b, int y) {
+    const float ay = div_prepared_nofix((float)(y - lo_i16(b.y)), bits_f32(a.y), bits_f32(b.w));
+    const int32_t ty = f32_as_i16(bits_f32(b.z) + ay * bits_f32(b.x));
+    return a.z + ((uint32_t)(ty + hi_i16(b.y)) & a.x);
+}
+__device__ __forceinline__ uint32_t flat_offset_plain(const DevFrame &f, const uint4 a, const uint4 b, const RowConsts &R, float &factor) {
+    const float wx = div_prepared_nofix(bits_f32(b.x), R.vy, R.r_vy);
+    const float wy = div_prepared_nofix(bits_f32(a.y), R.vy, R.r_vy);
     const float rx = wx * f.cos_a - wy * f.sin_a;
     const float ry = wy * f.cos_a + wx * f.sin_a;
     const int32_t tx = (f32_as_i16(rx) + f.pos_x_i16) & 63;
@@ -369,6 +385,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
     // lane = (column, row) = (lane >> 3, lane & 7).  Its row constants:
     const bool few_rows = H - y0 <= PACK_ROWS;
     const RowConsts R = row_consts(y, rt);
+    const bool tile_vy0 = __builtin_amdgcn_ballot_w64(R.row_fast == 0u) != 0ull;   // the horizon row (vy == 0) is in this tile
 
     int c_lo = 0;
     while (c_lo < TILE_W) {
@@ -406,9 +423,21 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         }
         uint32_t v_lo, v_rg, v_off;
         unpack_span(f_w0, 32u * (f_n0 + 1u + (uint32_t)fslot), v_lo, v_rg, v_off);
-        const unsigned long long hit_op = __ballot(f_hit && !w0_immediate(f_w0)), hit_ov = __ballot(f_hit && w0_immediate(f_w0));
-        const unsigned long long hit_ovwall = __ballot(f_hit && w0_immediate(f_w0) && w0_kind(f_w0) == SPAN_WALL);
+        const bool f_op = f_hit && !w0_immediate(f_w0), f_ov = f_hit && w0_immediate(f_w0);
+        const unsigned long long hit_op = __ballot(f_op), hit_ov_all = __ballot(f_ov);
         const unsigned long long big = __ballot(f_n > 8u);         // all 8 lanes of a column with more than 8 spans
+        // Columns with ONE owner: the last span that touches the tile's rows is opaque, plain and covers all of the tile's live rows —
+        // whatever lies under it in draw order cannot show.  Such a column (two out of three in the benchmark scene) needs no owner
+        // search, no per-row parameter fetch and no kind vote: ucol_* carry one bit per column, at the owning span's lane.
+        const uint32_t my_group = (uint32_t)((hit_op | hit_ov_all) >> (lane & ~7)) & 0xffu;
+        const bool f_last = (my_group >> (fslot + 1)) == 0u;
+        const bool f_uni = f_op && f_last && w0_plain(f_w0) && w0_ctop(f_w0) <= y0 && w0_cbot(f_w0) >= (y0 + (TILE_H - 1) < H ? y0 + (TILE_H - 1) : H - 1);
+        const unsigned long long ucol_wall = __ballot(f_uni && w0_kind(f_w0) == SPAN_WALL);
+        const unsigned long long ucol_flat = tile_vy0 ? 0ull : __ballot(f_uni && w0_kind(f_w0) == SPAN_FLAT);   // the vy == 0 row takes the plain divide
+        const unsigned long long ucol = ucol_wall | ucol_flat;
+        const bool col_uni = ((uint32_t)(ucol >> (lane & ~7)) & 0xffu) != 0u;
+        const unsigned long long hit_ov = __ballot(f_ov && !col_uni);                                    // hidden under a sole owner: not evaluated
+        const unsigned long long hit_ovwall = __ballot(f_ov && !col_uni && w0_kind(f_w0) == SPAN_WALL);
         const int nk = (c_hi - c_lo - wave + WAVES - 1) / WAVES;     // columns of this chunk that are this wave's
         if (few_rows && nk == WAVES && (hit_ov | big) == 0ull) {
             // ---- eight columns x eight rows in one pass.  Lane (k, r) owns row r of the wave's column k; that column's spans sit in the
@@ -437,36 +466,33 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         auto stage1 = [&](int k, Col &C) {
             DG_PHASE(2)
             const unsigned long long colmask = 0xffull << (8 * k);
+            const unsigned long long mu = ucol & colmask;
+            if (mu) {                                                // one plain owner for all rows of this column
+                const uint32_t off = bcast(v_off, __builtin_ctzll(mu));
+                const uint4 a = span_at(L.lspans, off)[0], b = span_at(L.lspans, off)[1];   // same address in every lane: LDS broadcast
+                uint32_t o;
+                if (ucol_flat & mu) o = flat_offset_plain(fr, a, b, R, C.factor);
+                else { o = wall_offset_plain(a, b, R.y); C.factor = bits_f32(a.w); }
+                C.winner = 0u;
+                C.tex = P.scene.texel_idx[o];
+                DG_PHASE(3)
+                return;
+            }
             if (big & colmask) {
                 const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
                 C.winner = big_column_owner(L.lw0 + n0, 32u * (n0 + 1u), n, lane, y0, R);
             } else {
                 C.winner = owner_loop(hit_op & colmask, v_lo, v_rg, v_off, R, 0u);
             }
-#if defined(DG_EXP_ABL) && (DG_EXP_ABL == 4)
-            C.tex = C.winner; C.factor = 0.0f;
-#elif defined(DG_EXP_ABL) && (DG_EXP_ABL == 6)
-            C.factor = bits_f32(C.winner);
-            C.tex = P.scene.texel_idx[C.winner];
-#else
             const uint32_t o = owner_texel(fr, L.lspans, C.winner, R, C.factor);
             C.tex = P.scene.texel_idx[o];                    // in flight until stage 2
-#endif
             DG_PHASE(3)
         };
         auto stage2 = [&](int k, const Col &C) {
             const unsigned long long colmask = 0xffull << (8 * k);
-#if defined(DG_EXP_ABL) && (DG_EXP_ABL == 4)
-            uint32_t px = C.tex;
-#else
             uint32_t px = shade_f(L.pal[C.tex], C.factor);
-#endif
             DG_PHASE(4)
-#if defined(DG_EXP_ABL) && (DG_EXP_ABL == 2 || DG_EXP_ABL == 4 || DG_EXP_ABL == 6)
-            if (false) {
-#else
             if (big & colmask) {
-#endif
                 const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
                 px = big_column_overlays(P, L.pal, L.lw0 + n0, L.lspans, 32u * (n0 + 1u), n, lane, y0, R, C.winner, px);
             } else if (hit_ov & colmask) {
@@ -478,12 +504,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
             DG_PHASE(5)
         };
         Col A, B;
-#if defined(DG_EXP_ABL) && (DG_EXP_ABL == 1 || DG_EXP_ABL == 5)
-        for (int k = 0; k < nk; k++) L.tile[(c_lo + wave + WAVES * k) * TILE_TS + lane] = (uint32_t)(hit_op >> (8 * k)) ^ v_lo ^ (uint32_t)(hit_ov | hit_ovwall | big);
-        if (false) {
-#else
         if (nk == WAVES) {                                           // a whole tile's worth (the normal case): one loop shape, no conditionals
-#endif
             stage1(0, A);                                            // A and B alternate so that an in-flight texel never changes register
             for (int k = 1; k < WAVES - 1; k += 2) {
                 stage1(k, B);
@@ -515,11 +536,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
     for (int pass = 0; pass < TILE_H / (4 * WAVES); pass++) {
         const int row = pass * 4 * WAVES + wave * 4 + rsub;
         const int yy = y0 + row, xx = x0 + 4 * gc;
-#if defined(DG_EXP_ABL) && (DG_EXP_ABL == 3 || DG_EXP_ABL == 5)
-        if (yy < H && xx < W && L.tile[row] == 0x12345678u) {
-#else
         if (yy < H && xx < W) {   // W % 4 == 0 (checked at dg_create), so a group never straddles the right edge
-#endif
             const uint32_t p0 = L.tile[(4 * gc + 0) * TILE_TS + row], p1 = L.tile[(4 * gc + 1) * TILE_TS + row];
             const uint32_t p2 = L.tile[(4 * gc + 2) * TILE_TS + row], p3 = L.tile[(4 * gc + 3) * TILE_TS + row];
             uint32_t *dst = reinterpret_cast<uint32_t *>(fb + ((size_t)yy * (size_t)W + (size_t)xx) * 3);
@@ -594,7 +611,7 @@ hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hip
 
 int raster_tile_rows_per_wg(int H) {
     const int n_tile_rows = (H + TILE_H - 1) / TILE_H;
-    int rows = 1;                                                     // TODO(tuning): chosen by measurement, profiles/r03_raster_tiles.md
+    int rows = n_tile_rows >= 8 ? 3 : 2;                              // measured: profiles/r03_raster_tiles.md (1280x800: 1 / 2 / 3 / 4 / 13 rows = 0.561 / 0.540 / 0.536 / 0.59 / 0.67 ms)
     if (const char *e = std::getenv("DOOMGPU_EXP_TILE_ROWS")) rows = std::max(1, std::atoi(e));
     return std::min(rows, n_tile_rows);
 }

@@ -29,7 +29,7 @@ static_assert(sizeof(DevSpan) == 16, "DevSpan must be 16 bytes");
 // The column-major, draw-ordered list the rasteriser starts from: one self-contained 32-byte record per span, written by
 // the setup kernel (host lists) or dg_fe_scatter (device column walk) from DevSpan + its wall/plane record.
 //   word   WALL (bitmap_render.rs:241-263)                    FLAT (visplanes.rs:103-126)           SKY (visplanes.rs:65-72)
-//   w0     ctop | imm << 15 | cbot << 16 | kind << 30          same                                   same      (imm: may be transparent)
+//   w0     ctop | plain << 14 | imm << 15 | cbot << 16 | kind << 30   same                            same      (imm: may be transparent; plain: raster_core.h pack_w0)
 //   w1     d = (bottom_y - top_y) as f32                      wz * vx (f32)                          -
 //   w2     start of the texture column (texel_off + tx * h)   offset of the 64x64 flat from the      start of the sky texture column
 //                                                             texel index plane (flats follow it)     (0 when tx is outside the bitmap)

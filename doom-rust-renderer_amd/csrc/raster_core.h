@@ -29,10 +29,13 @@ DG_HD float bits_f32(uint32_t u) {
 #endif
 }
 DG_HD int32_t lo_i16(uint32_t w) { return (int32_t)(int16_t)(w & 0xffffu); }
-// DevRSpan word 0: ctop (bits 0-13) | immediate-flag (bit 15) | cbot (bits 16-29) | kind (bits 30-31); rows are < 16384.
-DG_HD uint32_t pack_w0(int32_t ctop, int32_t cbot, uint32_t kind, bool immediate) {
-    return (uint32_t)(ctop & 0x3fff) | (immediate ? 0x8000u : 0u) | ((uint32_t)(cbot & 0x3fff) << 16) | (kind << 30);
+// DevRSpan word 0: ctop (bits 0-13) | plain-flag (bit 14) | immediate-flag (bit 15) | cbot (bits 16-29) | kind (bits 30-31); rows are
+// < 16384.  plain: the span's pixels take the short form of their mapper — a wall whose bitmap height is a power of two (mask instead
+// of modulus), a floor / ceiling whose numerators are inside the prepared divide's verified domain (div_guard_ok).
+DG_HD uint32_t pack_w0(int32_t ctop, int32_t cbot, uint32_t kind, bool immediate, bool plain) {
+    return (uint32_t)(ctop & 0x3fff) | (plain ? 0x4000u : 0u) | (immediate ? 0x8000u : 0u) | ((uint32_t)(cbot & 0x3fff) << 16) | (kind << 30);
 }
+DG_HD bool w0_plain(uint32_t w0) { return (w0 & 0x4000u) != 0; }
 DG_HD int32_t w0_ctop(uint32_t w0) { return (int32_t)(w0 & 0x3fffu); }
 DG_HD int32_t w0_cbot(uint32_t w0) { return (int32_t)((w0 >> 16) & 0x3fffu); }
 DG_HD uint32_t w0_kind(uint32_t w0) { return w0 >> 30; }
@@ -182,7 +185,7 @@ DG_HD DevRSpan resolve_wall_span(const DevSpan &sp, const DevWallRec &r) {
     const float d = (float)((int32_t)sp.bot_y - (int32_t)sp.top_y);
     const bool pot = (h & (h - 1)) == 0;
     DevRSpan o;
-    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_WALL, r.has_holes != 0);
+    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_WALL, r.has_holes != 0, pot);
     o.w[1] = f32_bits(d);
     o.w[2] = r.texel_off + (uint32_t)tx * (uint32_t)h;          // start of the texture column (column-major planes)
     o.w[3] = f32_bits(light_factor(r.lightf, z));
@@ -196,14 +199,15 @@ DG_HD DevRSpan resolve_wall_span(const DevSpan &sp, const DevWallRec &r) {
 DG_HD DevRSpan resolve_flat_span(const DevSpan &sp, const DevPlaneRec &p, const DevConsts &k, uint32_t flats_rel) {
     const float vx = (k.CFX - (float)sp.x) / k.ARC;                      // visplanes.rs:108
     const float wzvx = p.wz * vx;                                        // numerator of wy = wz * vx / vy (visplanes.rs:114)
+    const bool guard_ok = div_guard_ok(wzvx) && div_guard_ok(p.gwz);
     DevRSpan o;
-    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_FLAT, false);
+    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_FLAT, false, guard_ok);
     o.w[1] = f32_bits(wzvx);
     o.w[2] = flats_rel + p.flat_off;
     o.w[3] = 0;
     o.w[4] = f32_bits(p.gwz);                                            // numerator of wx = GCFX * wz / vy (visplanes.rs:113)
     o.w[5] = f32_bits(p.lightf);
-    o.w[6] = (div_guard_ok(wzvx) && div_guard_ok(p.gwz)) ? 0x100u : 0u;
+    o.w[6] = guard_ok ? 0x100u : 0u;
     o.w[7] = 0;
     return o;
 }
@@ -213,7 +217,7 @@ DG_HD DevRSpan resolve_sky_span(const DevSpan &sp, const DevScene &sc, const Dev
     tx = wrap_i16(tx + f.sky_tx_offset) % 256;
     const bool valid = tx >= 0 && tx < sc.sky_w;
     DevRSpan o;
-    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_SKY, sc.sky_has_holes != 0);   // a sky bitmap with holes is evaluated in draw order
+    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_SKY, sc.sky_has_holes != 0, false);   // a sky bitmap with holes is evaluated in draw order
     o.w[1] = 0;
     o.w[2] = valid ? sc.sky_texel_off + (uint32_t)tx * (uint32_t)sc.sky_h : 0u;
     o.w[3] = f32_bits(valid ? 1.0f : 0.0f);

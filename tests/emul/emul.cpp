@@ -52,6 +52,79 @@ static void raster_spans(const DevScene &ds, const DevConsts &k, const DevFrame 
     }
 }
 
+// ---- statistics only (tools/tile_stats.py): which (screen column, 64-row tile) chunks have ONE owner — what the sole-owner fast path of
+// dg_raster_tiles finds with its wave ballots (kernels.hip, ucol_*) ---------------------------------------------------------------
+//   CH_EMPTY    no span touches the chunk's rows: the pixels are the frame's clear colour
+//   CH_WALL /   the last span (in draw order) that touches the rows is opaque, plain (pack_w0) and covers every live row of the chunk:
+//   CH_FLAT /   it owns all of them whatever lies underneath — no owner search, no per-row parameters, no kind vote; the low bits are
+//   CH_SKY      that span's index in the frame's span array
+//   CH_GENERIC  anything else (several owners, possibly-transparent spans on top, long modulus, the horizon row of a floor, a tile
+//               with at most `pack_rows` live rows): the draw-ordered walk
+enum : uint32_t { CH_EMPTY = 0, CH_WALL = 1, CH_FLAT = 2, CH_SKY = 3, CH_GENERIC = 4, CH_CLASS_SHIFT = 28, CH_INDEX_MASK = (1u << 28) - 1u };
+
+// spans [c0, c1) of the column (w0_at(i) = word 0 of span i), rows y0 .. y_last of a frame of height H; vy0_row: the row with
+// CFY - y == 0 (or -1), which a floor / ceiling may only cross with the plain divide (visplanes.rs:113-114).
+template <typename W0At>
+static uint32_t classify_chunk(W0At w0_at, uint32_t c0, uint32_t c1, int32_t y0, int32_t y_last, int32_t H, int32_t vy0_row, int32_t pack_rows) {
+    uint32_t last = 0xffffffffu, last_w0 = 0;
+    for (uint32_t i = c0; i < c1; i++) {
+        const uint32_t w0 = w0_at(i);
+        if (w0_cbot(w0) >= y0 && w0_ctop(w0) <= y_last) { last = i; last_w0 = w0; }
+    }
+    if (last == 0xffffffffu) return CH_EMPTY << CH_CLASS_SHIFT;
+    const uint32_t kind = w0_kind(last_w0);
+    const bool covers = w0_ctop(last_w0) <= y0 && w0_cbot(last_w0) >= y_last && !w0_immediate(last_w0);
+    const bool horizon = vy0_row >= y0 && vy0_row <= y_last;
+    uint32_t cls = CH_GENERIC;
+    if (covers && kind == SPAN_WALL && w0_plain(last_w0)) cls = CH_WALL;
+    else if (covers && kind == SPAN_FLAT && w0_plain(last_w0) && !horizon) cls = CH_FLAT;
+    else if (covers && kind == SPAN_SKY) cls = CH_SKY;
+    if (H - y0 <= pack_rows || last >= (1u << 27)) cls = CH_GENERIC;      // (few live rows: the packed pass is cheaper; the raster kernel shifts the index left by 5 in 32 bits)
+    return (cls << CH_CLASS_SHIFT) | (last & CH_INDEX_MASK);
+}
+
+// What the sole-owner fast path of dg_raster_tiles does: every (column, 64-row tile) chunk that is not CH_GENERIC is
+// rendered from its ONE owner span (or left black), and must equal the draw-order replay.  Returns false (and says why) otherwise;
+// counts[class] += chunks.
+static bool check_chunk_descriptors(const DevScene &ds, const DevConsts &k, const DevFrame &hdr, const uint32_t *pal, const uint32_t *col_off,
+                                    const DevRSpan *rs, int W, int H, const uint8_t *rgb, uint64_t *counts) {
+    const int vy0_row = H % 2 == 0 ? H / 2 : -1;
+    for (int x = 0; x < W; x++)
+        for (int y0 = 0; y0 < H; y0 += 64) {
+            const int y_last = std::min(H, y0 + 64) - 1;
+            const uint32_t d = classify_chunk([&](uint32_t i) { return rs[i].w[0]; }, col_off[x], col_off[x + 1], y0, y_last, H, vy0_row, 8);
+            const uint32_t cls = d >> CH_CLASS_SHIFT;
+            if (counts) counts[cls]++;
+            if (cls == CH_GENERIC) continue;
+            const uint32_t *w = rs[d & CH_INDEX_MASK].w;
+            for (int y = y0; y <= y_last; y++) {
+                uint32_t c = 0;
+                if (cls == CH_WALL) {
+                    const uint32_t h = (uint32_t)bits_f32(w[6]);
+                    const int32_t top_y = lo_i16(w[5]), off_y = hi_i16(w[5]);
+                    const float ay = (float)(y - top_y) / bits_f32(w[1]);
+                    const int32_t ty = f32_as_i16(bits_f32(w[6]) + ay * bits_f32(w[4]));
+                    c = shade(pal[ds.texel_idx[w[2] + ((uint32_t)(ty + off_y) & (h - 1u))]], bits_f32(w[3]));
+                } else if (cls == CH_FLAT) {
+                    float factor;
+                    const float vy = k.CFY - (float)y;
+                    const uint32_t o = flat_texel_offset(hdr, w[1], w[2], w[4], w[5], 0x100u, vy, 0.0f, factor);
+                    c = shade(pal[ds.texel_idx[o]], factor);
+                } else if (cls == CH_SKY) {
+                    const int32_t row = sky_row(ds, k, y);
+                    const float fac = bits_f32(w[3]) * (row < 0 ? 0.0f : 1.0f);
+                    c = shade(pal[ds.texel_idx[w[2] + (row < 0 ? 0u : (uint32_t)row)]], fac);
+                }
+                const uint8_t *p = rgb + 3 * ((size_t)y * W + x);
+                if (p[0] != (c & 255) || p[1] != ((c >> 8) & 255) || p[2] != ((c >> 16) & 255)) {
+                    g_err = "chunk descriptor class " + std::to_string(cls) + " at column " + std::to_string(x) + " row " + std::to_string(y) + " differs from the draw-order replay";
+                    return false;
+                }
+            }
+        }
+    return true;
+}
+
 extern "C" {
 
 const char *emul_last_error() { return g_err.c_str(); }
@@ -115,6 +188,7 @@ static int emul_render_impl(void *scene, int W, int H, const dg_view *view_in, c
                                      : resolve_sky_span(sp, ds, k, bf.hdr);
     }
     raster_spans(ds, k, bf.hdr, pal.data(), bf.col_off.data(), rs.data(), W, H, rgb);
+    if (!check_chunk_descriptors(ds, k, bf.hdr, pal.data(), bf.col_off.data(), rs.data(), W, H, rgb, nullptr)) return DG_ERR_INVALID;
     if (stats) { stats[0] = bf.spans.size(); stats[1] = bf.walls.size(); stats[2] = bf.planes.size(); stats[3] = bf.covered_pixels; }
     return 0;
 }
@@ -241,6 +315,7 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
         same = std::memcmp(&r, &rspans[i], sizeof r) == 0;
     }
     raster_spans(ds, k, fr, pal.data(), col_off.data(), rspans.data(), W, H, rgb);
+    if (!check_chunk_descriptors(ds, k, fr, pal.data(), col_off.data(), rspans.data(), W, H, rgb, nullptr)) return DG_ERR_INVALID;
     if (stats) { stats[0] = off; stats[1] = ff.n_parts; stats[2] = ff.n_sprites; stats[3] = flags[0]; stats[4] = same ? 1 : 0; stats[5] = n_gaps; }
     return 0;
 }
@@ -283,7 +358,7 @@ int emul_tile_stats(void *scene, int W, int H, const dg_view *view_in, uint64_t 
     FrameConsts fk = make_consts(W, H);
     rc = bin_frame(sc, fk, fl, bf, g_err);
     if (rc) return rc;
-    for (int i = 0; i < 18; i++) out[i] = 0;
+    for (int i = 0; i < 24; i++) out[i] = 0;
     const int TH = 64, TW = 64;
     std::vector<int32_t> owner((size_t)H), prev_key((size_t)W * (size_t)H * 2, 0);
     std::vector<uint32_t> keyg((size_t)W * (size_t)H, 0), keyl((size_t)W * (size_t)H, 0);
@@ -343,6 +418,22 @@ int emul_tile_stats(void *scene, int W, int H, const dg_view *view_in, uint64_t 
             }
         }
     }
+    {   // [18 + class] chunks per descriptor class; [23] tiles without a CH_GENERIC chunk
+        std::vector<DevRSpan> rs(bf.spans.size());
+        for (size_t i = 0; i < bf.spans.size(); i++) rs[i].w[0] = pack_w0(bf.spans[i].ctop, bf.spans[i].cbot, bf.spans[i].kind,
+            bf.spans[i].kind == SPAN_WALL ? bf.walls[bf.spans[i].rec].has_holes != 0 : (bf.spans[i].kind == SPAN_SKY && sc.bitmaps[(size_t)sc.sky_bitmap].has_holes),
+            bf.spans[i].kind == SPAN_WALL ? (bf.walls[bf.spans[i].rec].h & (bf.walls[bf.spans[i].rec].h - 1)) == 0 : bf.spans[i].kind == SPAN_FLAT);
+        for (int x0 = 0; x0 < W; x0 += TW)
+            for (int y0 = 0; y0 < H; y0 += TH) {
+                bool any_gen = false;
+                for (int x = x0; x < std::min(W, x0 + TW); x++) {
+                    const uint32_t d = classify_chunk([&](uint32_t i) { return rs[i].w[0]; }, bf.col_off[(size_t)x], bf.col_off[(size_t)x + 1], y0, std::min(H, y0 + TH) - 1, H, H % 2 == 0 ? H / 2 : -1, 8);
+                    out[18 + (d >> CH_CLASS_SHIFT)]++;
+                    any_gen |= (d >> CH_CLASS_SHIFT) == CH_GENERIC;
+                }
+                if (!any_gen) out[23]++;
+            }
+    }
     for (int x0 = 0; x0 < W; x0 += TW)
         for (int y0 = 0; y0 < H; y0 += TH) {
             const int x1 = std::min(W, x0 + TW), y1 = std::min(H, y0 + TH) - 1;
@@ -358,5 +449,29 @@ int emul_tile_stats(void *scene, int W, int H, const dg_view *view_in, uint64_t 
             if (ov) out[14]++;
         }
     return 0;
+}
+
+// Debug aid: the resolved spans of one screen column (8 words each) and their count.
+int emul_column_spans(void *scene, int W, int H, const dg_view *view_in, int x, uint32_t *out, int cap) {
+    const Scene &sc = *(const Scene *)scene;
+    dg_view view = *view_in;
+    fill_view_trig(view);
+    static thread_local FrameArena arena;
+    static thread_local BinnedFrame bf;
+    dg_frame_lists fl;
+    if (build_frame_lists(sc, W, H, view, arena, fl, g_err, nullptr)) return -1;
+    FrameConsts fk = make_consts(W, H);
+    if (bin_frame(sc, fk, fl, bf, g_err)) return -1;
+    DevConsts k{fk.ARC, fk.GCFX, fk.CFX, fk.CFY, W, H};
+    DevScene ds{};
+    const BitmapInfo &sky = sc.bitmaps[(size_t)sc.sky_bitmap];
+    ds.sky_texel_off = sky.texel_off; ds.sky_w = sky.w; ds.sky_h = sky.h; ds.sky_has_holes = sky.has_holes;
+    int n = 0;
+    for (uint32_t i = bf.col_off[(size_t)x]; i < bf.col_off[(size_t)x + 1] && n < cap; i++, n++) {
+        const DevSpan &sp = bf.spans[i];
+        DevRSpan r = sp.kind == SPAN_WALL ? resolve_wall_span(sp, bf.walls[sp.rec]) : sp.kind == SPAN_FLAT ? resolve_flat_span(sp, bf.planes[sp.rec], k, 0u) : resolve_sky_span(sp, ds, k, bf.hdr);
+        std::memcpy(out + 8 * n, r.w, 32);
+    }
+    return n;
 }
 }
