@@ -179,7 +179,6 @@ __device__ __forceinline__ uint32_t flat_offset_plain(const DevFrame &f, const u
     factor = __builtin_fmaf(-(float)f32_as_i16(wx), 1.0f / 4096.0f, bits_f32(b.y));
     return a.z + (uint32_t)(ty * 64 + tx);
 }
-
 // Spans are addressed by their BYTE offset in the staging area (32 x record number): the owner of a row is the largest offset
 // among the opaque spans that cover it, 0 = the "nothing" record.
 //
@@ -431,15 +430,19 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         // search, no per-row parameter fetch and no kind vote: ucol_* carry one bit per column, at the owning span's lane.
         const uint32_t my_group = (uint32_t)((hit_op | hit_ov_all) >> (lane & ~7)) & 0xffu;
         const bool f_last = (my_group >> (fslot + 1)) == 0u;
-        const bool f_uni = f_op && f_last && w0_plain(f_w0) && w0_ctop(f_w0) <= y0 && w0_cbot(f_w0) >= (y0 + (TILE_H - 1) < H ? y0 + (TILE_H - 1) : H - 1);
-        const unsigned long long ucol_wall = __ballot(f_uni && w0_kind(f_w0) == SPAN_WALL);
-        const unsigned long long ucol_flat = tile_vy0 ? 0ull : __ballot(f_uni && w0_kind(f_w0) == SPAN_FLAT);   // the vy == 0 row takes the plain divide
+        const bool f_sole = f_op && f_last && w0_ctop(f_w0) <= y0 && w0_cbot(f_w0) >= (y0 + (TILE_H - 1) < H ? y0 + (TILE_H - 1) : H - 1);
+        const bool f_flat_short = w0_plain(f_w0) && !tile_vy0;                // the vy == 0 row takes the plain divide, and so does its whole wave
+        const unsigned long long ucol_wall = __ballot(f_sole && w0_kind(f_w0) == SPAN_WALL && w0_plain(f_w0));   // (a bitmap height that is not a power of two: the general path)
+        const unsigned long long ucol_flat = __ballot(f_sole && w0_kind(f_w0) == SPAN_FLAT && f_flat_short);
+        // (more classes — floors with the plain divide, sky — were measured: the code they add to every copy of stage 1 costs more than
+        // the few per cent of chunks they take off the general path, profiles/r03_raster_tiles.md)
         const unsigned long long ucol = ucol_wall | ucol_flat;
         const bool col_uni = ((uint32_t)(ucol >> (lane & ~7)) & 0xffu) != 0u;
         const unsigned long long hit_ov = __ballot(f_ov && !col_uni);                                    // hidden under a sole owner: not evaluated
         const unsigned long long hit_ovwall = __ballot(f_ov && !col_uni && w0_kind(f_w0) == SPAN_WALL);
+        const unsigned long long walk2 = big | hit_ov;                        // columns whose stage 2 has more to do than shading
         const int nk = (c_hi - c_lo - wave + WAVES - 1) / WAVES;     // columns of this chunk that are this wave's
-        if (few_rows && nk == WAVES && (hit_ov | big) == 0ull) {
+        if (few_rows && nk == WAVES && walk2 == 0ull) {
             // ---- eight columns x eight rows in one pass.  Lane (k, r) owns row r of the wave's column k; that column's spans sit in the
             // eight lanes of its own group (the pre-filter's layout), so the owner search is eight lane-permutes of one packed word
             // (first row | row count - 1 << 16; a span that does not count can never match).
@@ -467,12 +470,12 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
             DG_PHASE(2)
             const unsigned long long colmask = 0xffull << (8 * k);
             const unsigned long long mu = ucol & colmask;
-            if (mu) {                                                // one plain owner for all rows of this column
+            if (mu) {                                                // one owner for all rows of this column
                 const uint32_t off = bcast(v_off, __builtin_ctzll(mu));
                 const uint4 a = span_at(L.lspans, off)[0], b = span_at(L.lspans, off)[1];   // same address in every lane: LDS broadcast
                 uint32_t o;
-                if (ucol_flat & mu) o = flat_offset_plain(fr, a, b, R, C.factor);
-                else { o = wall_offset_plain(a, b, R.y); C.factor = bits_f32(a.w); }
+                if (ucol_wall & mu) { o = wall_offset_plain(a, b, R.y); C.factor = bits_f32(a.w); }
+                else o = flat_offset_plain(fr, a, b, R, C.factor);
                 C.winner = 0u;
                 C.tex = P.scene.texel_idx[o];
                 DG_PHASE(3)
@@ -492,13 +495,15 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
             const unsigned long long colmask = 0xffull << (8 * k);
             uint32_t px = shade_f(L.pal[C.tex], C.factor);
             DG_PHASE(4)
-            if (big & colmask) {
-                const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
-                px = big_column_overlays(P, L.pal, L.lw0 + n0, L.lspans, 32u * (n0 + 1u), n, lane, y0, R, C.winner, px);
-            } else if (hit_ov & colmask) {
-                // (issuing the first such span's texel fetch in stage 1, unmasked, was measured: slower — 0.60 against 0.57 ms)
-                const uint32_t color = overlay_loop(P, L.pal, L.lspans, hit_ov & colmask, hit_ovwall, v_lo, v_rg, v_off, R, C.winner, 0u);
-                px = (int32_t)color < 0 ? color : px;
+            if (walk2 & colmask) {                                   // possibly-transparent spans on top, in draw order
+                if (big & colmask) {
+                    const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
+                    px = big_column_overlays(P, L.pal, L.lw0 + n0, L.lspans, 32u * (n0 + 1u), n, lane, y0, R, C.winner, px);
+                } else {
+                    // (issuing the first such span's texel fetch in stage 1, unmasked, was measured: slower — 0.60 against 0.57 ms)
+                    const uint32_t color = overlay_loop(P, L.pal, L.lspans, hit_ov & colmask, hit_ovwall, v_lo, v_rg, v_off, R, C.winner, 0u);
+                    px = (int32_t)color < 0 ? color : px;
+                }
             }
             L.tile[(c_lo + wave + WAVES * k) * TILE_TS + lane] = px;
             DG_PHASE(5)
