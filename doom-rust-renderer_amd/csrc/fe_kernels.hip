@@ -189,7 +189,8 @@ __global__ __launch_bounds__(FE_SCAN_THREADS) void dg_fe_scan(FeParams P) {
 // column-major list.  64 adjacent columns x FE_SCATTER_GROUPS slot groups per workgroup: the lanes of a wave read the
 // same slot of 64 adjacent columns (coalesced in the [slot][column] scratch layout); the keys are staged in LDS once.
 __global__ __launch_bounds__(64 * FE_SCATTER_GROUPS) void dg_fe_scatter(FeParams P) {
-    __shared__ uint32_t lkeys[FE_MAX_COL_SLOTS * 64];
+    extern __shared__ uint32_t lkeys[];       // [col_slots][64]: sized by the ctx's slot count at launch (12 KB at the default 48 slots), so that
+                                              // LDS does not cap the resident workgroups of this latency-bound kernel
     const int f = blockIdx.y;
     const int W = P.k.W;
     const int lx = (int)(threadIdx.x & 63);
@@ -225,7 +226,7 @@ hipError_t launch_fe(const FeParams &P, hipStream_t stream) {
     hipLaunchKernelGGL(dg_fe_columns, grid, dim3(FE_COL_THREADS), 0, stream, P);
     if (P.max_sky_slots) hipLaunchKernelGGL(dg_fe_gaps, dim3(P.max_sky_slots, (unsigned)P.n_frames), dim3(64), 0, stream, P);
     hipLaunchKernelGGL(dg_fe_scan, dim3((unsigned)P.n_frames), dim3(FE_SCAN_THREADS), 0, stream, P);
-    hipLaunchKernelGGL(dg_fe_scatter, dim3((unsigned)((P.k.W + 63) / 64), (unsigned)P.n_frames), dim3(64 * FE_SCATTER_GROUPS), 0, stream, P);
+    hipLaunchKernelGGL(dg_fe_scatter, dim3((unsigned)((P.k.W + 63) / 64), (unsigned)P.n_frames), dim3(64 * FE_SCATTER_GROUPS), (size_t)P.col_slots * 64 * 4, stream, P);
     return hipGetLastError();
 }
 
