@@ -433,22 +433,25 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         uint32_t v_lo, v_rg, v_off;
         unpack_span(f_w0, 32u * (f_n0 + 1u + (uint32_t)fslot), v_lo, v_rg, v_off);
         const bool f_op = f_hit && !w0_immediate(f_w0), f_ov = f_hit && w0_immediate(f_w0);
-        const unsigned long long hit_op = __ballot(f_op), hit_ov_all = __ballot(f_ov);
+        const unsigned long long hit_op = __ballot(f_op);
         const unsigned long long big = __ballot(f_n > 8u);         // all 8 lanes of a column with more than 8 spans
-        // Columns with ONE owner: the last span that touches the tile's rows is opaque, plain and covers all of the tile's live rows —
-        // whatever lies under it in draw order cannot show.  Such a column (two out of three in the benchmark scene) needs no owner
-        // search, no per-row parameter fetch and no kind vote: ucol_* carry one bit per column, at the owning span's lane.
-        const uint32_t my_group = (uint32_t)((hit_op | hit_ov_all) >> (lane & ~7)) & 0xffu;
-        const bool f_last = (my_group >> (fslot + 1)) == 0u;
-        const bool f_sole = f_op && f_last && w0_ctop(f_w0) <= y0 && w0_cbot(f_w0) >= (y0 + (TILE_H - 1) < H ? y0 + (TILE_H - 1) : H - 1);
-        const unsigned long long ucol_wall = __ballot(f_sole && w0_kind(f_w0) == SPAN_WALL && w0_plain(f_w0));   // (a bitmap height that is not a power of two: the general path)
-        const unsigned long long ucol_flat = __ballot(f_sole && w0_kind(f_w0) == SPAN_FLAT && w0_plain(f_w0));   // (numerators outside the prepared divide's domain: the general path)
+        // Columns with ONE opaque owner: the last OPAQUE span that touches the tile's rows is plain and covers all of the tile's live
+        // rows — whatever lies under it in draw order cannot show.  Such a column (two out of three in the benchmark scene) needs no
+        // owner search, no per-row parameter fetch and no kind vote: ucol_* carry one bit per column, at the owning span's lane.
+        // Possibly-transparent spans drawn after it (a sprite in front of a wall) are laid on top in stage 2 as usual; those drawn
+        // before it are dropped here.
+        const uint32_t my_ops = (uint32_t)(hit_op >> (lane & ~7)) & 0xffu;
+        const bool f_last = (my_ops >> (fslot + 1)) == 0u;
+        const bool f_sole = f_op && f_last && w0_plain(f_w0) && w0_ctop(f_w0) <= y0 && w0_cbot(f_w0) >= (y0 + (TILE_H - 1) < H ? y0 + (TILE_H - 1) : H - 1);
+        const unsigned long long ucol_wall = __ballot(f_sole && w0_kind(f_w0) == SPAN_WALL);   // (a bitmap height that is not a power of two: the general path)
+        const unsigned long long ucol_flat = __ballot(f_sole && w0_kind(f_w0) == SPAN_FLAT);   // (numerators outside the prepared divide's domain: the general path)
         // (more classes — floors with the plain divide, sky — were measured: the code they add to every copy of stage 1 costs more than
         // the few per cent of chunks they take off the general path, profiles/r03_raster_tiles.md)
         const unsigned long long ucol = ucol_wall | ucol_flat;
-        const bool col_uni = ((uint32_t)(ucol >> (lane & ~7)) & 0xffu) != 0u;
-        const unsigned long long hit_ov = __ballot(f_ov && !col_uni);                                    // hidden under a sole owner: not evaluated
-        const unsigned long long hit_ovwall = __ballot(f_ov && !col_uni && w0_kind(f_w0) == SPAN_WALL);
+        const uint32_t my_ucol = (uint32_t)(ucol >> (lane & ~7)) & 0xffu;                      // the sole owner of my column, if it has one
+        const bool under = my_ucol != 0u && (1u << fslot) < my_ucol;                           // drawn before it: cannot show
+        const unsigned long long hit_ov = __ballot(f_ov && !under);
+        const unsigned long long hit_ovwall = __ballot(f_ov && !under && w0_kind(f_w0) == SPAN_WALL);
         const unsigned long long walk2 = big | hit_ov;                        // columns whose stage 2 has more to do than shading
         const int nk = (c_hi - c_lo - wave + WAVES - 1) / WAVES;     // columns of this chunk that are this wave's
         if (few_rows && nk == WAVES && walk2 == 0ull) {
@@ -485,7 +488,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
                 uint32_t o;
                 if (ucol_wall & mu) { o = wall_offset_plain(a, b, R.y); C.factor = bits_f32(a.w); }
                 else o = flat_offset_plain(fr, a, b, R, tile_vy0, C.factor);
-                C.winner = 0u;
+                C.winner = off;                                     // (stage 2 lays later possibly-transparent spans on top)
                 C.tex = P.scene.texel_idx[o];
                 DG_PHASE(3)
                 return;

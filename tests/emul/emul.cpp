@@ -74,11 +74,10 @@ static uint32_t classify_chunk(W0At w0_at, uint32_t c0, uint32_t c1, int32_t y0,
     if (last == 0xffffffffu) return CH_EMPTY << CH_CLASS_SHIFT;
     const uint32_t kind = w0_kind(last_w0);
     const bool covers = w0_ctop(last_w0) <= y0 && w0_cbot(last_w0) >= y_last && !w0_immediate(last_w0);
-    const bool horizon = vy0_row >= y0 && vy0_row <= y_last;
+    (void)vy0_row;
     uint32_t cls = CH_GENERIC;
     if (covers && kind == SPAN_WALL && w0_plain(last_w0)) cls = CH_WALL;
-    else if (covers && kind == SPAN_FLAT && w0_plain(last_w0) && !horizon) cls = CH_FLAT;
-    else if (covers && kind == SPAN_SKY) cls = CH_SKY;
+    else if (covers && kind == SPAN_FLAT && w0_plain(last_w0)) cls = CH_FLAT;         // (the horizon row is handled in place: x * +inf)
     if (H - y0 <= pack_rows || last >= (1u << 27)) cls = CH_GENERIC;      // (few live rows: the packed pass is cheaper; the raster kernel shifts the index left by 5 in 32 bits)
     return (cls << CH_CLASS_SHIFT) | (last & CH_INDEX_MASK);
 }
@@ -358,7 +357,7 @@ int emul_tile_stats(void *scene, int W, int H, const dg_view *view_in, uint64_t 
     FrameConsts fk = make_consts(W, H);
     rc = bin_frame(sc, fk, fl, bf, g_err);
     if (rc) return rc;
-    for (int i = 0; i < 24; i++) out[i] = 0;
+    for (int i = 0; i < 32; i++) out[i] = 0;
     const int TH = 64, TW = 64;
     std::vector<int32_t> owner((size_t)H), prev_key((size_t)W * (size_t)H * 2, 0);
     std::vector<uint32_t> keyg((size_t)W * (size_t)H, 0), keyl((size_t)W * (size_t)H, 0);
@@ -406,6 +405,30 @@ int emul_tile_stats(void *scene, int W, int H, const dg_view *view_in, uint64_t 
                 if (same) out[17]++;
             }
             if (c1 - c0 > 8) out[15]++;
+            {   // [24] chunks with exactly 2 distinct opaque owners over the live rows, no uncovered row, no overlay hit, both plain;
+                // [25] the same with a visible overlay; [26] >= 3 owners; [27] single owner but an overlay on top; [28] some row uncovered
+                int owners[64]; int no = 0; bool uncovered = false;
+                for (int y = y0; y <= y1; y++) {
+                    const int32_t o = owner[(size_t)y];
+                    if (o < 0) { uncovered = true; continue; }
+                    bool seen = false;
+                    for (int q = 0; q < no; q++) seen |= owners[q] == o;
+                    if (!seen && no < 64) owners[no++] = o;
+                }
+                bool ov = false;
+                for (uint32_t i = c0; i < c1; i++) {
+                    const DevSpan &sp = bf.spans[i];
+                    if (sp.cbot < y0 || sp.ctop > y1) continue;
+                    const bool imm = sp.kind == SPAN_WALL ? bf.walls[sp.rec].has_holes != 0 : (sp.kind == SPAN_SKY && sc.bitmaps[(size_t)sc.sky_bitmap].has_holes);
+                    if (!imm) continue;
+                    for (int y = std::max(y0, (int)sp.ctop); y <= std::min(y1, (int)sp.cbot); y++) ov |= owner[(size_t)y] < (int32_t)i;
+                }
+                if (uncovered) out[28]++;
+                else if (no == 2 && !ov) out[24]++;
+                else if (no == 2 && ov) out[25]++;
+                else if (no >= 3) out[26]++;
+                else if (no == 1 && ov) out[27]++;
+            }
             for (uint32_t i = c0; i < c1; i++) {
                 const DevSpan &sp = bf.spans[i];
                 if (sp.cbot < y0 || sp.ctop > y1) continue;

@@ -13,7 +13,8 @@ import emul_bind
 NAMES = ["chunks", "opaque span hits", "overlay span hits", "overlay evaluations", "single-kind chunks", "flat+wall chunks", "single-owner chunks",
          "staged spans (sum over tiles)", "staged spans touching their tile", "flat px", "wall px", "sky px", "uncovered px", "tiles", "tiles with overlays",
          "columns > 8 spans (per tile)", "flat chunks", "flat chunks = same planes as 8 columns left",
-         "CH_EMPTY chunks", "CH_WALL chunks", "CH_FLAT chunks", "CH_SKY chunks", "CH_GENERIC chunks", "tiles without a CH_GENERIC chunk"]
+         "no-span chunks", "sole-owner wall chunks", "sole-owner flat chunks", "(unused)", "general-path chunks", "tiles without a general-path chunk",
+         "2 owners, no overlay", "2 owners + overlay", ">= 3 owners", "1 owner + overlay", "some row uncovered", "", "", ""]
 
 def main():
     ap = argparse.ArgumentParser()
@@ -31,11 +32,11 @@ def main():
     import doomref
     osc = doomref.Scene(wad, "e1m1")
     path = cp.make_camera_path(sw.synth_route(a.seed, heavy=a.heavy), osc.floor_height_at, 1000)
-    tot = np.zeros(24, dtype=np.float64); n = 0
+    tot = np.zeros(32, dtype=np.float64); n = 0
     for i in range(0, 1000, a.stride):
         r = path[i]
         v = emul_bind.DgView(float(r[0]), float(r[1]), float(r[2]), float(r[7]), float(r[3]), float(r[4]), float(r[5]), float(r[6]), 0.0, 1)
-        st = (ctypes.c_uint64 * 24)()
+        st = (ctypes.c_uint64 * 32)()
         assert L.emul_tile_stats(sc._h, W, H, ctypes.byref(v), st) == 0
         tot += np.array(list(st), dtype=np.float64); n += 1
     tot /= n
