@@ -497,4 +497,45 @@ int emul_column_spans(void *scene, int W, int H, const dg_view *view_in, int x, 
     }
     return n;
 }
+
+// What the host ships to the device column walk for one frame (FePart records, fe_dev.h), for tests/np_front_end.py: 12 dwords per
+// part = sx, ex, bits of bsy, bsx, bdelta, tsy, tsx, tdelta, flags, seq, has-columns hint (unused), reserved.  Returns the part count.
+int emul_frame_parts(void *scene, int W, int H, const dg_view *view_in, uint32_t *out, int cap) {
+    const Scene &sc = *(const Scene *)scene;
+    dg_view view = *view_in;
+    fill_view_trig(view);
+    static thread_local FrameArena arena;
+    if (build_frame_parts(sc, W, H, view, arena, g_err)) return -1;
+    int n = 0;
+    for (const FePart &p : arena.parts) {
+        if (n >= cap) return -2;
+        uint32_t *o = out + 12 * n++;
+        o[0] = (uint32_t)p.sx; o[1] = (uint32_t)p.ex;
+        o[2] = f32_bits(p.bsy); o[3] = f32_bits(p.bsx); o[4] = f32_bits(p.bdelta);
+        o[5] = f32_bits(p.tsy); o[6] = f32_bits(p.tsx); o[7] = f32_bits(p.tdelta);
+        o[8] = p.flags; o[9] = p.seq; o[10] = 0; o[11] = 0;
+    }
+    return n;
+}
+
+// The host list builder's output for one frame, flattened for Python (the layout of include/doomgpu.h dg_frame_lists):
+//   renders: 4 ints each = start_x, end_x, first_column, n_columns;  columns: 5 int16 each;  visplanes: 4 ints = left, right, first_entry, flat;
+//   plane_tb: int16 pairs;  order: 2 uints.  counts[5] = how many of each.  Returns 0, or -2 when a buffer is too small.
+int emul_frame_lists(void *scene, int W, int H, const dg_view *view_in, int32_t *renders, int16_t *columns, int32_t *visplanes, int16_t *plane_tb, uint32_t *order,
+                     uint32_t *counts, uint32_t cap) {
+    const Scene &sc = *(const Scene *)scene;
+    dg_view view = *view_in;
+    fill_view_trig(view);
+    static thread_local FrameArena arena;
+    dg_frame_lists fl;
+    if (build_frame_lists(sc, W, H, view, arena, fl, g_err)) return -1;
+    if (fl.n_renders > cap || fl.n_columns > cap || fl.n_visplanes > cap || fl.n_plane_tb > 2 * cap || fl.n_order > cap) return -2;
+    for (uint32_t i = 0; i < fl.n_renders; i++) { renders[4 * i] = fl.renders[i].start_x; renders[4 * i + 1] = fl.renders[i].end_x; renders[4 * i + 2] = (int32_t)fl.renders[i].first_column; renders[4 * i + 3] = (int32_t)fl.renders[i].n_columns; }
+    for (uint32_t i = 0; i < fl.n_columns; i++) { const dg_bitmap_column &c = fl.columns[i]; columns[5 * i] = c.x; columns[5 * i + 1] = c.clipped_top_y; columns[5 * i + 2] = c.clipped_bottom_y; columns[5 * i + 3] = c.bottom_y; columns[5 * i + 4] = c.top_y; }
+    for (uint32_t i = 0; i < fl.n_visplanes; i++) { visplanes[4 * i] = fl.visplanes[i].left; visplanes[4 * i + 1] = fl.visplanes[i].right; visplanes[4 * i + 2] = (int32_t)fl.visplanes[i].first_entry; visplanes[4 * i + 3] = fl.visplanes[i].flat; }
+    for (uint32_t i = 0; i < fl.n_plane_tb; i++) plane_tb[i] = fl.plane_tb[i];
+    for (uint32_t i = 0; i < fl.n_order; i++) { order[2 * i] = fl.order[i].kind; order[2 * i + 1] = fl.order[i].index; }
+    counts[0] = fl.n_renders; counts[1] = fl.n_columns; counts[2] = fl.n_visplanes; counts[3] = fl.n_plane_tb; counts[4] = fl.n_order;
+    return 0;
+}
 }
