@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — frames/sec of the MI355X rasteriser on the fixed e1m1 camera path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3,4,5}] [--width W --height H] [--batch 500]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3,4,5}] [--width W --height H] [--batch 1000]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
 Workload (config.workload): by default BASELINE config 3 — the 1 000-frame scripted camera path through the e1m1-like
@@ -10,7 +10,7 @@ WAD can be shipped, so the maps are the committed synthetic IWADs and `data` say
 command runs a real IWAD).  --config selects the other BASELINE.json configurations (CONFIGS below): 1 = the Player-1 start
 frame at 320x200, 2 = the path at 320x200, 4 = eight paths over two maps at 1280x800, 5 = the heavy map at 2560x1600.
 
-A *step* is ONE PASS OVER THE WHOLE 1 000-FRAME PATH: 1000 / `--batch` batches (default: two of 500) of consecutive frames, each going through
+A *step* is ONE PASS OVER THE WHOLE 1 000-FRAME PATH: 1000 / `--batch` batches (default at 1280x800: one of 1000) of consecutive frames, each going through
 the complete hot path of SURVEY.md §8(d) — host BSP walk / clip / projection / record generation on the ctx's host
 threads, pinned staging, H2D, the device column walk (dg_fe_*) and the tile rasteriser dg_raster_tiles — leaving 1 000 RGB24
 frames in HBM.  The batches are
@@ -52,9 +52,9 @@ LIGHT_MAP, HEAVY_MAP = (1993, False), (1994, True)
 CONFIGS = {
     1: ("config 1: e1m1 stand-in at 320x200, the single Player-1 start viewpoint", 320, 200, 1000, (LIGHT_MAP,), "start"),
     2: ("config 2: e1m1 stand-in at 320x200, 1000-frame scripted camera path", 320, 200, 1000, (LIGHT_MAP,), "path"),
-    3: ("config 3: e1m1 stand-in at 1280x800, 1000-frame scripted camera path", 1280, 800, 500, (LIGHT_MAP,), "path"),
-    4: ("config 4: two maps (map01 + map07 stand-ins) at 1280x800, eight independent camera paths, one per GPU", 1280, 800, 500, (LIGHT_MAP, HEAVY_MAP), "path"),
-    5: ("config 5: heavy map (e2m1 stand-in: more visplanes + sprites) at 2560x1600", 2560, 1600, 125, (HEAVY_MAP,), "path"),
+    3: ("config 3: e1m1 stand-in at 1280x800, 1000-frame scripted camera path", 1280, 800, 1000, (LIGHT_MAP,), "path"),
+    4: ("config 4: two maps (map01 + map07 stand-ins) at 1280x800, eight independent camera paths, one per GPU", 1280, 800, 1000, (LIGHT_MAP, HEAVY_MAP), "path"),
+    5: ("config 5: heavy map (e2m1 stand-in: more visplanes + sprites) at 2560x1600", 2560, 1600, 250, (HEAVY_MAP,), "path"),
 }
 
 
@@ -483,6 +483,7 @@ def cpu_baseline(args, be, ctx, n_slots, np):
 def host_frames_rate(args, be, ctx, n_slots, views, B, batches_per_step, barrier, dist, world):
     """Every frame to page-locked host memory, D2H of batch i overlapped with the kernels of batch i + 1."""
     dg = be.dg
+    n_slots = min(n_slots, 2)                         # two slots are enough to overlap copy and kernels; each needs B frames of page-locked memory
     nb = max(2 * n_slots, min(4 * batches_per_step, 16))
     bufs = [dg.lib().dg_alloc_host(B * ctx.frame_bytes) for _ in range(n_slots)]
     try:
