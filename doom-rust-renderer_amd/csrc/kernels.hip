@@ -64,24 +64,11 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int lane) { return (uint32
 //   A  opaque spans (no immediate flag): a wave-uniform loop over the spans that touch these rows, three VALU instructions each
 //      (row - ctop, unsigned compare with cbot - ctop, select) — `winner` = index of the last opaque span covering the row;
 //   B  possibly-transparent spans (masked walls, sprites, a sky bitmap with holes: the immediate flag), in draw order, for the
-//      rows they cover and that no LATER opaque span owns (index > winner): texel fetched, written only where it is opaque;
+//      rows they cover and that no LATER opaque span owns (index > winner): texel fetched, taken only where it is opaque;
 //   C  every row evaluates its winner once: each kind present computes its (texel offset, light factor), then ONE byte gather,
 //      palette lookup and shade for all kinds (flats and bitmap texels live in one allocation; sky = factor 1.0, uncovered =
 //      factor 0.0 -> exactly 0,0,0).
 // No pixel is evaluated twice except under step B's overlays; nothing depends on the order of evaluation but B.
-
-// shade_f with bit 31 of the result set: "an overlay wrote this pixel" (the tile read-out ignores the top byte).
-__device__ __forceinline__ uint32_t shade_f_marked(const float4 c, float factor) {
-    const float r = c.x * factor, g = c.y * factor, b = c.z * factor;
-    uint32_t o;
-    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-                 "v_cvt_pk_u8_f32 %0, %1, 0, %4\n\t"
-                 "v_cvt_pk_u8_f32 %0, %2, 1, %0\n\t"
-                 "v_cvt_pk_u8_f32 %0, %3, 2, %0\n\t"
-                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-                 : "=&v"(o) : "v"(r), "v"(g), "v"(b), "s"(0x80000000u));
-    return o;
-}
 
 // Both planes of one texel (palette index, opacity) with one round trip: address = scalar base + 32-bit lane offset, waited for here.
 __device__ __forceinline__ void gather_u8x2(const uint8_t *base0, const uint8_t *base1, uint32_t o, uint32_t &v0, uint32_t &v1) {
@@ -212,11 +199,12 @@ __device__ __forceinline__ const uint4 *span_at(const uint4 *staged, uint32_t of
     return reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(staged) + off);
 }
 
-// Possibly-transparent spans in draw order (m_wall: which of them are bitmap columns; the others are sky-with-holes spans).  A
-// written pixel carries bit 31 (shade_f_marked); returns the colour so far.  (Fetching two spans' texels per trip without exec
-// masking was measured: slower at 1280x800 — most columns meet one such span — and no faster at 320x200.)
-__device__ __forceinline__ uint32_t overlay_loop(const RasterParams &P, const float4 *palf, const uint4 *staged, unsigned long long m, unsigned long long m_wall,
-                                                 uint32_t v_lo, uint32_t v_rg, uint32_t v_off, const RowConsts &R, uint32_t winner, uint32_t color) {
+// Possibly-transparent spans in draw order (m_wall: which of them are bitmap columns; the others are sky-with-holes spans): where such a
+// span shows — its texel is opaque and no later opaque span owns the row — its (texel, light factor) replace the row's; the pixel is
+// shaded once, afterwards.  (Fetching two spans' texels per trip without exec masking was measured: slower at 1280x800 — most columns
+// meet one such span — and no faster at 320x200.)
+__device__ __forceinline__ void overlay_loop(const RasterParams &P, const uint4 *staged, unsigned long long m, unsigned long long m_wall,
+                                             uint32_t v_lo, uint32_t v_rg, uint32_t v_off, const RowConsts &R, uint32_t winner, uint32_t &tex_io, float &factor_io) {
     while (m) {
         const int j = take_lowest(m);
         const uint32_t off = bcast(v_off, j);
@@ -234,11 +222,11 @@ __device__ __forceinline__ uint32_t overlay_loop(const RasterParams &P, const fl
             }
             uint32_t tex, opq;
             gather_u8x2(P.scene.texel_idx, P.scene.texel_opq, o, tex, opq);
-            const uint32_t c = shade_f_marked(palf[tex], factor);
-            color = (opq != 0u && (wall || factor != 0.0f)) ? c : color;
+            const bool shows = opq != 0u && (wall || factor != 0.0f);
+            tex_io = shows ? tex : tex_io;
+            factor_io = shows ? factor : factor_io;
         }
     }
-    return color;
 }
 
 // Every row evaluates its owner.  The scalar instruction stream is what this kernel is short of (profiles/r02_raster_tiles.md), so
@@ -293,9 +281,8 @@ __device__ __forceinline__ uint32_t big_column_owner(const uint32_t *lw0, uint32
     return winner;
 }
 // Stage 2 for such a column.
-__device__ __forceinline__ uint32_t big_column_overlays(const RasterParams &P, const float4 *pal, const uint32_t *lw0, const uint4 *staged, uint32_t off0,
-                                                        uint32_t n, int lane, int y0, const RowConsts &R, uint32_t winner, uint32_t base_color) {
-    uint32_t color = 0;
+__device__ __forceinline__ void big_column_overlays(const RasterParams &P, const uint32_t *lw0, const uint4 *staged, uint32_t off0, uint32_t n, int lane, int y0,
+                                                    const RowConsts &R, uint32_t winner, uint32_t &tex_io, float &factor_io) {
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + (uint32_t)lane;
         const uint32_t w0v = i < n ? lw0[i] : 0u;
@@ -304,9 +291,8 @@ __device__ __forceinline__ uint32_t big_column_overlays(const RasterParams &P, c
         if (!m) continue;
         uint32_t v_lo, v_rg, v_off;
         unpack_span(w0v, off0 + 32u * i, v_lo, v_rg, v_off);
-        color = overlay_loop(P, pal, staged, m, __ballot(hit && w0_kind(w0v) == SPAN_WALL), v_lo, v_rg, v_off, R, winner, color);
+        overlay_loop(P, staged, m, __ballot(hit && w0_kind(w0v) == SPAN_WALL), v_lo, v_rg, v_off, R, winner, tex_io, factor_io);
     }
-    return (int32_t)color < 0 ? color : base_color;
 }
 
 constexpr int TILE_TS = 65;       // dwords per tile COLUMN in LDS
@@ -505,18 +491,19 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         };
         auto stage2 = [&](int k, const Col &C) {
             const unsigned long long colmask = 0xffull << (8 * k);
-            uint32_t px = shade_f(L.pal[C.tex], C.factor);
+            uint32_t tex = C.tex;
+            float factor = C.factor;
             DG_PHASE(4)
             if (walk2 & colmask) {                                   // possibly-transparent spans on top, in draw order
                 if (big & colmask) {
                     const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
-                    px = big_column_overlays(P, L.pal, L.lw0 + n0, L.lspans, 32u * (n0 + 1u), n, lane, y0, R, C.winner, px);
+                    big_column_overlays(P, L.lw0 + n0, L.lspans, 32u * (n0 + 1u), n, lane, y0, R, C.winner, tex, factor);
                 } else {
                     // (issuing the first such span's texel fetch in stage 1, unmasked, was measured: slower — 0.60 against 0.57 ms)
-                    const uint32_t color = overlay_loop(P, L.pal, L.lspans, hit_ov & colmask, hit_ovwall, v_lo, v_rg, v_off, R, C.winner, 0u);
-                    px = (int32_t)color < 0 ? color : px;
+                    overlay_loop(P, L.lspans, hit_ov & colmask, hit_ovwall, v_lo, v_rg, v_off, R, C.winner, tex, factor);
                 }
             }
+            const uint32_t px = shade_f(L.pal[tex], factor);         // palette x light, `as u8` (bitmap_render.rs:202-207), once per pixel
             L.tile[(c_lo + wave + WAVES * k) * TILE_TS + lane] = px;
             DG_PHASE(5)
         };
