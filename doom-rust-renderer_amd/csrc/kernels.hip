@@ -132,17 +132,12 @@ __device__ __forceinline__ uint32_t wall_offset_tile(const uint4 a, const uint4 
 // Texel offset and light factor of one floor / ceiling pixel (visplanes.rs:108-126); see flat_texel_offset (raster_core.h) for the
 // scalar form.  The factor is left unclamped: `as u8` of (colour x negative) is 0, the same as with the reference's
 // `if factor < 0.0 { factor = 0.0 }`, and lightf - z / 4096 as one fma is exact because z / 4096 is.
-__device__ __forceinline__ uint32_t flat_offset_tile(const DevFrame &f, const uint4 a, const uint4 b, const RowConsts &R, unsigned long long lanes, bool tile_vy0, float &factor) {
+__device__ __forceinline__ uint32_t flat_offset_tile(const DevFrame &f, const uint4 a, const uint4 b, const RowConsts &R, unsigned long long lanes, float &factor) {
     float wx, wy;
-    if ((__builtin_amdgcn_ballot_w64((b.z & 0x100u) == 0u) & lanes) == 0ull) {
+    if ((__builtin_amdgcn_ballot_w64((b.z & R.row_fast) == 0u) & lanes) == 0ull) {
         wx = div_prepared_nofix(bits_f32(b.x), R.vy, R.r_vy);
         wy = div_prepared_nofix(bits_f32(a.y), R.vy, R.r_vy);
-        if (tile_vy0) {                           // the horizon row is in this tile: x / +0.0 = x * +inf (+-inf by the sign of x, NaN for 0; tests/gpu_numerics E)
-            const bool horizon = R.row_fast == 0u;
-            wx = horizon ? bits_f32(b.x) * bits_f32(0x7f800000u) : wx;
-            wy = horizon ? bits_f32(a.y) * bits_f32(0x7f800000u) : wy;
-        }
-    } else {                                      // a numerator outside the prepared divide's verified domain somewhere in the wave: plain divides
+    } else {                                      // a numerator outside the verified domain or the vy == 0 row somewhere in the wave: plain divides
         wx = bits_f32(b.x) / R.vy;
         wy = bits_f32(a.y) / R.vy;
     }
@@ -161,14 +156,9 @@ __device__ __forceinline__ uint32_t wall_offset_plain(const uint4 a, const uint4
     const int32_t ty = f32_as_i16(bits_f32(b.z) + ay * bits_f32(b.x));
     return a.z + ((uint32_t)(ty + hi_i16(b.y)) & a.x);
 }
-__device__ __forceinline__ uint32_t flat_offset_plain(const DevFrame &f, const uint4 a, const uint4 b, const RowConsts &R, bool tile_vy0, float &factor) {
-    float wx = div_prepared_nofix(bits_f32(b.x), R.vy, R.r_vy);
-    float wy = div_prepared_nofix(bits_f32(a.y), R.vy, R.r_vy);
-    if (tile_vy0) {                               // (see flat_offset_tile)
-        const bool horizon = R.row_fast == 0u;
-        wx = horizon ? bits_f32(b.x) * bits_f32(0x7f800000u) : wx;
-        wy = horizon ? bits_f32(a.y) * bits_f32(0x7f800000u) : wy;
-    }
+__device__ __forceinline__ uint32_t flat_offset_plain(const DevFrame &f, const uint4 a, const uint4 b, const RowConsts &R, float &factor) {
+    const float wx = div_prepared_nofix(bits_f32(b.x), R.vy, R.r_vy);
+    const float wy = div_prepared_nofix(bits_f32(a.y), R.vy, R.r_vy);
     const float rx = wx * f.cos_a - wy * f.sin_a;
     const float ry = wy * f.cos_a + wx * f.sin_a;
     const int32_t tx = (f32_as_i16(rx) + f.pos_x_i16) & 63;
@@ -233,7 +223,7 @@ __device__ __forceinline__ void overlay_loop(const RasterParams &P, const uint4 
 // there is no divergent control flow here: a kind that some row of the wave needs is computed by ALL 64 lanes (on words of another
 // kind the arithmetic is garbage but harmless) and each lane then selects — two uniform branches and a few selects instead of
 // nested exec-mask regions.  The gather comes after the select, so every address is that of the lane's real owner.
-__device__ __forceinline__ uint32_t owner_texel(const DevFrame &fr, const uint4 *staged, uint32_t winner, const RowConsts &R, bool tile_vy0, float &factor_out) {
+__device__ __forceinline__ uint32_t owner_texel(const DevFrame &fr, const uint4 *staged, uint32_t winner, const RowConsts &R, float &factor_out) {
     const uint4 a = span_at(staged, winner)[0], b = span_at(staged, winner)[1];
     const bool is_wall = a.x < 0x40000000u, is_sky = (int32_t)a.x < 0;
     const unsigned long long m_wall = __builtin_amdgcn_ballot_w64(is_wall), m_sky = __builtin_amdgcn_ballot_w64(is_sky);
@@ -241,7 +231,7 @@ __device__ __forceinline__ uint32_t owner_texel(const DevFrame &fr, const uint4 
     float factor = bits_f32(a.w) * R.sky_fac;
     if (~(m_wall | m_sky) != 0ull) {              // some row is owned by a floor / ceiling
         float ff;
-        const uint32_t fo = flat_offset_tile(fr, a, b, R, ~(m_wall | m_sky), tile_vy0, ff);
+        const uint32_t fo = flat_offset_tile(fr, a, b, R, ~(m_wall | m_sky), ff);
         const bool is_flat = !is_wall && !is_sky;
         o = is_flat ? fo : o;
         factor = is_flat ? ff : factor;
@@ -430,7 +420,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         const bool f_last = (my_ops >> (fslot + 1)) == 0u;
         const bool f_sole = f_op && f_last && w0_plain(f_w0) && w0_ctop(f_w0) <= y0 && w0_cbot(f_w0) >= (y0 + (TILE_H - 1) < H ? y0 + (TILE_H - 1) : H - 1);
         const unsigned long long ucol_wall = __ballot(f_sole && w0_kind(f_w0) == SPAN_WALL);   // (a bitmap height that is not a power of two: the general path)
-        const unsigned long long ucol_flat = __ballot(f_sole && w0_kind(f_w0) == SPAN_FLAT);   // (numerators outside the prepared divide's domain: the general path)
+        const unsigned long long ucol_flat = tile_vy0 ? 0ull : __ballot(f_sole && w0_kind(f_w0) == SPAN_FLAT);   // (the vy == 0 row, like numerators outside the prepared divide's domain: the general path)
         // (more classes — floors with the plain divide, sky — were measured: the code they add to every copy of stage 1 costs more than
         // the few per cent of chunks they take off the general path, profiles/r03_raster_tiles.md)
         const unsigned long long ucol = ucol_wall | ucol_flat;
@@ -455,7 +445,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
                 winner = ((uint32_t)Rp.y - (w & 0xffffu)) <= (w >> 16) ? off_first + 32u * (uint32_t)j : winner;
             }
             float factor;
-            const uint32_t o = owner_texel(fr, L.lspans, winner, Rp, tile_vy0, factor);
+            const uint32_t o = owner_texel(fr, L.lspans, winner, Rp, factor);
             const uint32_t px = shade_f(L.pal[P.scene.texel_idx[o]], factor);
             L.tile[(c_lo + wave + WAVES * fk) * TILE_TS + fslot] = px;
             c_lo = c_hi;
@@ -473,7 +463,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
                 const uint4 a = span_at(L.lspans, off)[0], b = span_at(L.lspans, off)[1];   // same address in every lane: LDS broadcast
                 uint32_t o;
                 if (ucol_wall & mu) { o = wall_offset_plain(a, b, R.y); C.factor = bits_f32(a.w); }
-                else o = flat_offset_plain(fr, a, b, R, tile_vy0, C.factor);
+                else o = flat_offset_plain(fr, a, b, R, C.factor);
                 C.winner = off;                                     // (stage 2 lays later possibly-transparent spans on top)
                 C.tex = P.scene.texel_idx[o];
                 DG_PHASE(3)
@@ -485,7 +475,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
             } else {
                 C.winner = owner_loop(hit_op & colmask, v_lo, v_rg, v_off, R, 0u);
             }
-            const uint32_t o = owner_texel(fr, L.lspans, C.winner, R, tile_vy0, C.factor);
+            const uint32_t o = owner_texel(fr, L.lspans, C.winner, R, C.factor);
             C.tex = P.scene.texel_idx[o];                    // in flight until stage 2
             DG_PHASE(3)
         };
@@ -510,6 +500,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         Col A, B;
         if (nk == WAVES) {                                           // a whole tile's worth (the normal case): one loop shape, no conditionals
             stage1(0, A);                                            // A and B alternate so that an in-flight texel never changes register
+#pragma unroll                                                       // k a literal in every copy: the column masks and lane numbers fold (measured: -2.6 %)
             for (int k = 1; k < WAVES - 1; k += 2) {
                 stage1(k, B);
                 stage2(k - 1, A);
