@@ -28,7 +28,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -604,11 +603,11 @@ hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hip
     return hipGetLastError();
 }
 
+// Tile rows one workgroup renders out of one staging pass.  Measured at 1280x800 (13 tile rows): 1 / 2 / 3 / 4 / 13 rows = 0.586 / 0.577 /
+// 0.562 / 0.593 / 0.669 ms per 250 frames; at 320x200 (4 tile rows) 2 rows win (profiles/r03_raster_tiles.md).
 int raster_tile_rows_per_wg(int H) {
     const int n_tile_rows = (H + TILE_H - 1) / TILE_H;
-    int rows = n_tile_rows >= 8 ? 3 : 2;                              // measured: profiles/r03_raster_tiles.md (1280x800: 1 / 2 / 3 / 4 / 13 rows = 0.561 / 0.540 / 0.536 / 0.59 / 0.67 ms)
-    if (const char *e = std::getenv("DOOMGPU_EXP_TILE_ROWS")) rows = std::max(1, std::atoi(e));
-    return std::min(rows, n_tile_rows);
+    return std::min(n_tile_rows >= 8 ? 3 : 2, n_tile_rows);
 }
 
 hipError_t launch_raster(const RasterParams &P_in, hipStream_t stream) {

@@ -7,8 +7,8 @@ dg = importlib.import_module("doom-rust-renderer_amd")
 sw = importlib.import_module("doom-rust-renderer_amd.synth_wad")
 print("| config | map | size | frames/launch | front end | front-end kernels ms | raster ms | frames/s (resident) | GB/s alg | frac | spans/frame | records/frame |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|")
-for (name, seed, W, H, B) in [("1", 1993, 320, 200, 1000), ("2", 1993, 1280, 800, 250), ("native", 1993, 1024, 768, 250), ("3/4-like", 1994, 1280, 800, 250),
-                              ("5-like", 1994, 2560, 1600, 64), ("2 @ 2560x1600", 1993, 2560, 1600, 64), ("vanilla-shaped", 1995, 1280, 800, 250)]:
+for (name, seed, W, H, B) in [("1 / 2", 1993, 320, 200, 1000), ("3", 1993, 1280, 800, 250), ("native", 1993, 1024, 768, 250), ("4 (second map)", 1994, 1280, 800, 250),
+                              ("5", 1994, 2560, 1600, 64), ("3 @ 2560x1600", 1993, 2560, 1600, 64), ("vanilla-shaped", 1995, 1280, 800, 250)]:
     path = np.fromfile(os.path.join(ROOT, f"tests/golden/campath_seed{seed}.f32"), dtype="<f4").reshape(1000, 8)
     sc = dg.Scene(sw.build_synth_iwad(seed, heavy=(seed == 1994), vanilla=(seed == 1995)), "e1m1")
     for fe in (dg.DG_FE_DEVICE, dg.DG_FE_HOST):
