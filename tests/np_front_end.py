@@ -135,3 +135,295 @@ def column_loops(W: int, H: int, calls):
         sv.flush()                                                                         # :347
         all_columns.append(cols)
     return all_columns, visplanes
+
+
+# ====================================================================================================================================
+# The PER-SEG half: BSP visit order, seg transform, frustum clip, projection, the three parts of a wall / portal.
+#
+#     Renderer::render_node / process_subsector            src/renderer/mod.rs:61-104
+#     Segs::process_seg                                     src/renderer/segs.rs:353-590
+#     Segs::process_sidedef up to its column loop           src/renderer/segs.rs:121-200
+#     clip_to_viewport, perspective_transform,
+#     make_sidedef_non_vertical_line                        src/renderer/misc.rs:13-161
+#     Line::intersection, Vertex::{rotate, is_left_of_line, distance_to}     src/geometry.rs:56-82, src/map/vertexes.rs:20-38
+#     the map lumps                                         src/map/*.rs (record layouts), src/wad.rs:175-183 (first marker of the name)
+#
+# Again written from those lines with numpy float32 scalars and Python ints, sharing nothing with the oracle or the product.  Together
+# with column_loops above this is a complete second front end for walls and visplanes (sprites are not restated).
+# ====================================================================================================================================
+import struct
+
+TWOSIDED, DONTPEGTOP, DONTPEGBOTTOM = 4, 8, 16            # src/map/linedefs.rs:10-18
+
+
+def _as_i32(v) -> int:
+    v = float(v)
+    if v != v:
+        return 0
+    if v >= 2147483647.0:
+        return 2147483647
+    if v <= -2147483648.0:
+        return -2147483648
+    return int(v)
+
+
+def _i32_as_i16(v: int) -> int:
+    return ((v + 32768) & 0xffff) - 32768                 # `as i16` of an i32 wraps
+
+
+class Map:
+    """The lumps process_seg reads, as plain tuples."""
+
+    def __init__(self, wad: bytes, map_name: str):
+        n, off = struct.unpack_from("<II", wad, 4)
+        lumps = []
+        for i in range(n):
+            o, s = struct.unpack_from("<II", wad, off + 16 * i)
+            lumps.append((wad[off + 16 * i + 8: off + 16 * i + 16].split(b"\0")[0].decode("ascii").upper(), o, s))
+        m = next(i for i, l in enumerate(lumps) if l[0] == map_name.upper())     # wad.rs:175-183: the first marker of that name
+
+        def lump(k):
+            _, o, s = lumps[m + k]
+            return wad[o:o + s]
+
+        def name(b):
+            return b.split(b"\0")[0].decode("ascii")                          # wad.rs:112-126 (no case folding)
+        linedefs, sidedefs, vertexes, segs, ssectors, nodes, sectors = (lump(k) for k in (2, 3, 4, 5, 6, 7, 8))
+        self.vertexes = [tuple(F32(t) for t in struct.unpack_from("<hh", vertexes, 4 * i)) for i in range(len(vertexes) // 4)]
+        self.sectors = []
+        for i in range(len(sectors) // 26):
+            fh, ch = struct.unpack_from("<hh", sectors, 26 * i)
+            self.sectors.append({"floor_height": fh, "ceiling_height": ch, "floor_texture": name(sectors[26 * i + 4: 26 * i + 12]),
+                                 "ceiling_texture": name(sectors[26 * i + 12: 26 * i + 20]), "light_level": struct.unpack_from("<h", sectors, 26 * i + 20)[0]})
+        self.sidedefs = []
+        for i in range(len(sidedefs) // 30):
+            b = sidedefs[30 * i: 30 * i + 30]
+            self.sidedefs.append({"x_offset": struct.unpack_from("<h", b, 0)[0], "y_offset": struct.unpack_from("<h", b, 2)[0],
+                                  "upper": name(b[4:12]), "lower": name(b[12:20]), "middle": name(b[20:28]), "sector": self.sectors[struct.unpack_from("<h", b, 28)[0]]})
+        self.linedefs = []
+        for i in range(len(linedefs) // 14):
+            v1, v2, flags, _sp, _tag, fs, bs = struct.unpack_from("<hhhhhhh", linedefs, 14 * i)
+            self.linedefs.append({"flags": flags, "front": None if fs == -1 else self.sidedefs[fs], "back": None if bs == -1 else self.sidedefs[bs]})
+        self.segs = []
+        for i in range(len(segs) // 12):
+            v1, v2, _ang, ld, direction, seg_off = struct.unpack_from("<hhhhhh", segs, 12 * i)
+            self.segs.append({"start": self.vertexes[v1], "end": self.vertexes[v2], "linedef": self.linedefs[ld], "direction": direction != 0, "offset": seg_off})
+        self.subsectors = [struct.unpack_from("<hh", ssectors, 4 * i) for i in range(len(ssectors) // 4)]        # (seg_count, first_seg)
+        self.nodes = []
+        for i in range(len(nodes) // 28):
+            x, y, dx, dy = struct.unpack_from("<hhhh", nodes, 28 * i)
+            rc, lc = struct.unpack_from("<HH", nodes, 28 * i + 24)
+            self.nodes.append((F32(x), F32(y), F32(dx), F32(dy), rc, lc))
+
+
+def _sub(a, b):
+    return (a[0] - b[0], a[1] - b[1])
+
+
+def _is_left_of_line(p, l0, l1):                           # vertexes.rs:32-34
+    a, b = _sub(p, l0), _sub(l1, l0)
+    return a[0] * b[1] - a[1] * b[0] <= F32(0.0)
+
+
+def _intersection(s, e, o0, o1):                          # geometry.rs:56-82; None = "Lines are parallel"
+    x1, y1, x2, y2 = s[0], s[1], e[0], e[1]
+    x3, y3, x4, y4 = o0[0], o0[1], o1[0], o1[1]
+    quot = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4)
+    if abs(quot) < F32(0.001):
+        return None
+    invquot = F32(1.0) / quot
+    px = invquot * ((x1 * y2 - y1 * x2) * (x3 - x4) - (x1 - x2) * (x3 * y4 - y3 * x4))
+    py = invquot * ((x1 * y2 - y1 * x2) * (y3 - y4) - (y1 - y2) * (x3 * y4 - y3 * x4))
+    return (px, py)
+
+
+def clip_to_viewport(start, end):                         # misc.rs:13-115; -> (start, end, start_offset) or None
+    Z, ONE = F32(0.0), F32(1.0)
+    left, right = ((Z, Z), (ONE, ONE)), ((Z, Z), (ONE, -ONE))
+    start_outside_left, end_outside_left = _is_left_of_line(start, *left), _is_left_of_line(end, *left)
+    start_outside_right, end_outside_right = not _is_left_of_line(start, *right), not _is_left_of_line(end, *right)
+    start_in = start[0] > Z and not start_outside_left and not start_outside_right
+    end_in = end[0] > Z and not end_outside_left and not end_outside_right
+    if start_in and end_in:
+        return start, end, Z
+    li, ri = _intersection(start, end, *left), _intersection(start, end, *right)
+    left_x = li is not None and li[0] >= Z
+    right_x = ri is not None and ri[0] >= Z
+    if not start_in and not end_in and not left_x and not right_x:
+        return None
+    if not start_in and not end_in and left_x != right_x:
+        return None
+    if (right_x and start_outside_right and end_outside_right) or (left_x and start_outside_left and end_outside_left):
+        return None
+    s, e, start_offset = start, end, Z
+    if left_x:
+        if start_outside_left:
+            dx, dy = li[0] - s[0], li[1] - s[1]
+            start_offset = np.sqrt(dx * dx + dy * dy)       # new_start.distance_to(&start), vertexes.rs:36-38
+            s = li
+        if end_outside_left:
+            e = li
+    if right_x:
+        if start_outside_right:
+            s = ri
+        if end_outside_right:
+            e = ri
+    return s, e, start_offset
+
+
+def per_seg_calls(m: Map, W: int, H: int, view):
+    """view: x, y, cos(-angle), sin(-angle), floor_height as np.float32 (the trig values the reference's libm returned are an input, as for
+    the product).  -> the process_sidedef calls that reach their column loop, in visit order, as column_loops() takes them."""
+    arc = F32(200.0) / F32(240.0)                          # constants.rs:3-17
+    gcfx = (F32(W) / arc) / F32(2.0)
+    cfx, cfy = F32(W) / F32(2.0), F32(H) / F32(2.0)
+    pos = (view["x"], view["y"])
+    cn, sn = view["cos_neg"], view["sin_neg"]
+    calls = []
+
+    def non_vertical_line(s, e, height):                  # misc.rs:130-161
+        out = []
+        for v in (s, e):
+            tx = gcfx * v[1] / v[0]                        # perspective_transform: x = v.y, z = v.x
+            ty = gcfx * height / v[0]
+            tx = tx * arc
+            out.append((min(_as_i32(cfx - tx), W - 1), _as_i32(cfy - ty)))
+        return out
+
+    def process_sidedef(s, e, bottom_height, top_height, texture_name, only, lower, upper, draw_ceiling, two, rec=None, offset_y=0):   # segs.rs:121-200
+        bottom, top = non_vertical_line(s, e, bottom_height), non_vertical_line(s, e, top_height)
+        assert bottom[0][0] == top[0][0] and bottom[1][0] == top[1][0], "Wall start not vertical"
+        if _i32_as_i16(bottom[0][0]) == _i32_as_i16(bottom[1][0]) or _i32_as_i16(top[0][0]) == _i32_as_i16(top[1][0]):
+            return
+        for (x, _) in bottom + top:
+            assert 0 <= x < W, "Invalid line x (the reference panics)"
+        bdelta = (F32(bottom[0][1]) - F32(bottom[1][1])) / (F32(bottom[0][0]) - F32(bottom[1][0]))
+        tdelta = (F32(top[0][1]) - F32(top[1][1])) / (F32(top[0][0]) - F32(top[1][0]))
+        flags = (ONLY_OCCLUSIONS if only else 0) | (IS_LOWER_WALL if lower else 0) | (IS_UPPER_WALL if upper else 0) | (DRAW_CEILING if draw_ceiling else 0) | \
+                (IS_TWO_SIDED_MIDDLE_WALL if two else 0) | (HAS_TEXTURE if texture_name != "-" else 0)
+        c = {"sx": bottom[0][0], "ex": bottom[1][0], "bsy": F32(bottom[0][1]), "bsx": F32(bottom[0][0]), "bdelta": bdelta,
+             "tsy": F32(top[0][1]), "tsx": F32(top[0][0]), "tdelta": tdelta, "flags": flags}
+        if rec is not None:                                # what BitmapRender::new (segs.rs:186-199) and SidedefVisPlanes::new (:163-169) are given
+            c.update(rec)
+            c.update({"texture": texture_name, "line": (s[0], s[1], e[0], e[1]), "start_x": bottom[0][0], "end_x": bottom[1][0],
+                      "bottom_height": bottom_height, "top_height": top_height,
+                      "offset_y": _i32_as_i16(rec["sidedef_y_offset"] + _i32_as_i16(offset_y))})
+        calls.append(c)
+
+    def process_seg(seg):                                 # segs.rs:353-590
+        ld = seg["linedef"]
+        front, back = (ld["back"], ld["front"]) if seg["direction"] else (ld["front"], ld["back"])
+        if front is None:
+            return
+        fs = front["sector"]
+        floor_height, ceiling_height = F32(fs["floor_height"]), F32(fs["ceiling_height"])
+        portal_bottom = portal_top = None
+        if back is not None:
+            bsec = back["sector"]
+            if bsec["floor_height"] > fs["floor_height"]:
+                portal_bottom = F32(bsec["floor_height"])
+            if bsec["ceiling_height"] < fs["ceiling_height"]:
+                portal_top = F32(bsec["ceiling_height"])
+        two_sided = (ld["flags"] & TWOSIDED) != 0
+        rot = []
+        for v in (seg["start"], seg["end"]):
+            mx, my = v[0] - pos[0], v[1] - pos[1]
+            rot.append((mx * cn - my * sn, my * cn + mx * sn))            # rotate(-angle), vertexes.rs:20-25
+        clipped = clip_to_viewport(rot[0], rot[1])
+        if clipped is None:
+            return
+        s, e, start_offset = clipped
+        assert not (s[0] < F32(-0.01)), "Clipped line x < -0.01 (the reference panics)"
+        top_unpegged, bottom_unpegged = (ld["flags"] & DONTPEGTOP) != 0, (ld["flags"] & DONTPEGBOTTOM) != 0
+        player_height = view["floor_height"] + F32(41.0)
+        floor = non_vertical_line(s, e, floor_height - player_height)
+        if floor[0][0] > floor[1][0]:
+            return
+        draw_ceiling = True
+        if back is not None and "SKY" in fs["ceiling_texture"] and "SKY" in back["sector"]["ceiling_texture"]:   # the sky hack
+            portal_top = None
+            ceiling_height = min(F32(back["sector"]["ceiling_height"]), ceiling_height)
+            draw_ceiling = False
+        rec = {"light_level": fs["light_level"], "start_offset": start_offset, "sidedef_y_offset": front["y_offset"],
+               "offset_x": _i32_as_i16(front["x_offset"] + seg["offset"]),                          # sidedef.x_offset as i16 + sds.offset_x (wrapping)
+               "floor_flat": fs["floor_texture"], "ceiling_flat": fs["ceiling_texture"],            # (get_animated at timestamp 0 = the first frame: draw side)
+               "floor_height_i16": fs["floor_height"], "ceiling_height_i16": fs["ceiling_height"]}
+        if not two_sided:
+            oy = _as_i32(floor_height - ceiling_height) if bottom_unpegged else 0                     # segs.rs:496-502
+            process_sidedef(s, e, floor_height - player_height, ceiling_height - player_height, front["middle"], False, False, False, draw_ceiling, False, rec, oy)
+        else:
+            process_sidedef(s, e, floor_height - player_height, ceiling_height - player_height, front["middle"], True, False, False, draw_ceiling, False, rec, 0)
+            mid_floor = portal_bottom if portal_bottom is not None else floor_height
+            mid_ceiling = portal_top if portal_top is not None else ceiling_height
+            process_sidedef(s, e, mid_floor - player_height, mid_ceiling - player_height, front["middle"], False, False, False, draw_ceiling, True, rec, 0)
+            if portal_bottom is not None:
+                oy = _as_i32(ceiling_height - portal_bottom) if bottom_unpegged else 0                # segs.rs:552-558
+                process_sidedef(s, e, floor_height - player_height, portal_bottom - player_height, front["lower"], False, True, False, draw_ceiling, False, rec, oy)
+            if portal_top is not None:
+                oy = 0 if top_unpegged else _as_i32(portal_top - ceiling_height)                      # segs.rs:572-578
+                process_sidedef(s, e, portal_top - player_height, ceiling_height - player_height, front["upper"], False, False, True, draw_ceiling, False, rec, oy)
+
+    def subsector(i):                                     # mod.rs:61-66
+        count, first = m.subsectors[i]
+        for k in range(first, first + count):
+            process_seg(m.segs[k])
+
+    # mod.rs:69-104, iteratively: front child first, then the back child — always both
+    def render_node(ni):
+        x, y, dx, dy, rc, lc = m.nodes[ni]
+        v1 = (x, y)
+        v2 = (x + dx, y + dy)
+        is_left = _is_left_of_line(pos, v1, v2)
+        front_c, back_c = (lc, rc) if is_left else (rc, lc)
+        for c in (front_c, back_c):
+            if c & 0x8000:
+                subsector(c & 0x7fff)
+            else:
+                render_node(c)
+
+    import sys
+    sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+    render_node(len(m.nodes) - 1)
+    return calls
+
+
+# The flats that cycle (flats.rs:30-77): get_animated(name, timestamp) picks list[(timestamp * 3.0) as usize % len]
+_ANIMATED = [["NUKAGE1", "NUKAGE2", "NUKAGE3"], ["FWATER1", "FWATER2", "FWATER3", "FWATER4"], ["SWATER1", "SWATER2", "SWATER3", "SWATER4"],
+             ["LAVA1", "LAVA2", "LAVA3", "LAVA4"], ["BLOOD1", "BLOOD2", "BLOOD3"], ["RROCK05", "RROCK06", "RROCK07", "RROCK08"],
+             ["SLIME01", "SLIME02", "SLIME03", "SLIME04"], ["SLIME05", "SLIME06", "SLIME07", "SLIME08"], ["SLIME09", "SLIME10", "SLIME11", "SLIME12"]]
+
+
+def get_animated(name: str, timestamp: float) -> str:
+    for lst in _ANIMATED:
+        if name in lst:
+            return lst[int(F32(timestamp) * F32(3.0)) % len(lst)]
+    return name
+
+
+def frame_lists(m: Map, W: int, H: int, view, timestamp: float = 0.0):
+    """The whole front end for a frame WITHOUT map objects, as the list dict tests/np_mappers.draw_lists replays: inline walls in visit
+    order (segs.rs:231-258), the visplanes in push order (mod.rs:106-116), then — no sprite being there to interleave them —
+    the masked middle textures in reversed visit order (mod.rs:124, segs.rs:593-597, bitmap_render.rs:101-135)."""
+    calls = per_seg_calls(m, W, H, view)
+    columns, visplanes = column_loops(W, H, calls)
+    lists = {"renders": [], "columns": [], "visplanes": [], "order": []}
+    masked = []
+    for c, cols in zip(calls, columns):
+        if not (c["flags"] & HAS_TEXTURE) or not cols:
+            continue
+        two, only = bool(c["flags"] & IS_TWO_SIDED_MIDDLE_WALL), bool(c["flags"] & ONLY_OCCLUSIONS)
+        if only:
+            continue
+        r = {k: c[k] for k in ("texture", "light_level", "offset_x", "offset_y", "line", "start_offset", "start_x", "end_x", "bottom_height", "top_height")}
+        r["first_column"], r["n_columns"] = len(lists["columns"]), len(cols)
+        lists["columns"] += cols
+        lists["renders"].append(r)
+        (masked if two else lists["order"]).append((0, len(lists["renders"]) - 1))
+    for (ci, which, left, right, tb) in visplanes:
+        c = calls[ci]
+        flat = get_animated(c["floor_flat"] if which == "floor" else c["ceiling_flat"], timestamp)
+        lists["visplanes"].append({"flat": flat, "height": c["floor_height_i16"] if which == "floor" else c["ceiling_height_i16"],
+                                   "light_level": c["light_level"], "left": left, "right": right, "tb": tb})
+        lists["order"].append((1, len(lists["visplanes"]) - 1))
+    lists["order"] += masked[::-1]
+    return lists

@@ -1,9 +1,13 @@
-"""The per-column half of the front end against a code-disjoint restatement (tests/np_front_end.py, written from
-src/renderer/segs.rs:202-345 and sidedef_visplanes.rs): the process_sidedef calls the product's host walk hands to the device column
-walk (FePart records) are run through the numpy column loop, and what it leaves behind — wall columns and visplanes — must be what
-the product's list builder (dg_build_lists: BitmapRender columns, Visplane entries, draw order) produced for the same view.
-Together with tests/np_mappers.py (the three texture mappers) the reference's per-column and per-pixel work now has a second
-opinion that shares no code with oracle/doomref.c or the product; the per-seg half (BSP order, clip, projection) has not."""
+"""The front end against a code-disjoint restatement (tests/np_front_end.py, written from the reference's src/renderer/{mod,segs,misc,
+sidedef_visplanes,visplanes}.rs, geometry.rs and the map loaders):
+  * the numpy column loop on the process_sidedef calls the product's host walk hands to the device column walk (FePart records), and
+  * the same column loop on calls produced by the numpy per-seg half (BSP visit order, seg transform, clip_to_viewport, projection, the
+    parts of a wall / portal) — a complete second front end for walls and visplanes —
+must leave behind what the product's list builder (dg_build_lists: BitmapRender columns, Visplane entries, draw order) produced for the
+same view; and the numpy front end feeding the numpy mappers (tests/np_mappers.py) must render WHOLE FRAMES byte-identical to
+oracle/doomref.c when the map objects are switched off.  Nothing in the numpy code is shared with the oracle or the product; what
+still has no second restatement is draw_map_objects (sprite projection, clipping against the recorded wall columns, the sprite /
+masked-wall interleave)."""
 import ctypes
 
 import numpy as np
@@ -51,16 +55,25 @@ def frame_lists(sc, W, H, rec):
     return renders, planes, [(int(k), int(i)) for k, i in order]
 
 
+@pytest.mark.parametrize("per_seg", ["product-records", "numpy-per-seg-half"])
 @pytest.mark.parametrize("seed,vanilla,size", [(1993, False, (320, 200)), (1993, False, (132, 67)), (1995, True, (320, 200)), (1994, False, (256, 160))])
-def test_column_loop_restatement_agrees_with_the_list_builder(synth, campath_mod, oracle, seed, vanilla, size):
+def test_column_loop_restatement_agrees_with_the_list_builder(synth, campath_mod, oracle, seed, vanilla, size, per_seg):
+    """product-records: the numpy column loop on the process_sidedef calls the product ships to the GPU (FePart).
+    numpy-per-seg-half: the same column loop on calls produced by the numpy BSP walk / process_seg / clip / projection — a complete second
+    front end (walls and visplanes) that never touches product or oracle code; it walks every seg like the reference, the product culls."""
     W, H = size
     wad = synth.build_synth_iwad(seed, heavy=(seed == 1994), vanilla=vanilla)
     sc = emul_bind.EmulScene(wad)
     osc = oracle.Scene(wad, "e1m1")
     path = campath_mod.make_camera_path(synth.synth_route(seed, heavy=(seed == 1994), vanilla=vanilla), osc.floor_height_at, 1000)
+    np_map = nf.Map(wad, "e1m1") if per_seg == "numpy-per-seg-half" else None
     checked_cols = checked_planes = masked = 0
     for i in range(0, 1000, 83):
-        calls = frame_parts(sc, W, H, path[i])
+        if np_map is None:
+            calls = frame_parts(sc, W, H, path[i])
+        else:
+            r = path[i]
+            calls = nf.per_seg_calls(np_map, W, H, {"x": r[0], "y": r[1], "cos_neg": r[5], "sin_neg": r[6], "floor_height": r[7]})
         columns, visplanes = nf.column_loops(W, H, calls)
         renders, planes, order = frame_lists(sc, W, H, path[i])
         # phase 1 of the draw order = the inline wall draws (segs.rs:231-258), in visit order: textured, not two-sided, not occlusion-only
@@ -80,3 +93,26 @@ def test_column_loop_restatement_agrees_with_the_list_builder(synth, campath_mod
                 assert cols in late, f"frame {i}: a masked wall's recorded columns are not among the late draws"
                 masked += 1
     assert checked_cols > 1000 and checked_planes > 50 and masked > 0
+
+
+@pytest.mark.parametrize("seed,vanilla", [(1993, False), (1995, True), (1994, False)])
+def test_numpy_renderer_equals_the_oracle_without_map_objects(synth, campath_mod, oracle, seed, vanilla):
+    """Whole frames from code that shares nothing with the oracle or the product: the numpy front end (per-seg half + column loop,
+    np_front_end.py) feeding the numpy mappers (np_mappers.py), against oracle/doomref.c with every map object switched off (sprites are
+    the one part of the frame that has no second restatement).  160x100, a handful of path frames: pure-Python pixel loops."""
+    import np_mappers as nm
+    W, H = 160, 100
+    wad = synth.build_synth_iwad(seed, heavy=(seed == 1994), vanilla=vanilla)
+    osc = oracle.Scene(wad, "e1m1")
+    for mo in range(osc.mobj_count()):
+        osc.set_mobj_state(mo, None)                                          # S_NULL: draw_map_objects skips it (renderer/map_objects.rs:37)
+    path = campath_mod.make_camera_path(synth.synth_route(seed, heavy=(seed == 1994), vanilla=vanilla), osc.floor_height_at, 1000)
+    np_map, np_wad = nf.Map(wad, "e1m1"), nm.Wad(wad)
+    for i in (0, 217, 431, 640, 858):
+        r = path[i]
+        lists = nf.frame_lists(np_map, W, H, {"x": r[0], "y": r[1], "cos_neg": r[5], "sin_neg": r[6], "floor_height": r[7]})
+        got = nm.draw_lists(np_wad, "SKY1", W, H, {"x": r[0], "y": r[1], "angle": r[2], "cos": r[3], "sin": r[4], "floor_height": r[7]}, lists)
+        want = np.frombuffer(osc.render(W, H, r), dtype=np.uint8).reshape(H, W, 3)
+        bad = np.argwhere(np.any(got != want, axis=2))
+        assert len(bad) == 0, f"frame {i}: {len(bad)} pixels differ, first at (x={bad[0][1]}, y={bad[0][0]}): numpy {got[bad[0][0], bad[0][1]]} oracle {want[bad[0][0], bad[0][1]]}"
+        assert want.any()
