@@ -427,3 +427,255 @@ def frame_lists(m: Map, W: int, H: int, view, timestamp: float = 0.0):
         lists["order"].append((1, len(lists["visplanes"]) - 1))
     lists["order"] += masked[::-1]
     return lists
+
+
+# ====================================================================================================================================
+# Map objects: draw_map_objects (src/renderer/map_objects.rs:19-241), BitmapRender::is_behind_vertex / Ord (bitmap_render.rs:137-188),
+# get_sector_from_vertex (bsp.rs:9-44), the sprite lump table (graphics/sprites.rs:26-117, pictures.rs:66-147), MapObjects::new
+# (src/map_objects.rs:25-50; the thing type -> spawn state table is DATA taken from data/mobj_spawn.tsv, extracted from src/info.rs).
+# With it the numpy code renders complete frames.
+# ====================================================================================================================================
+import math
+import os
+
+_PI = F32(math.pi)
+
+
+def _as_u8(v) -> int:
+    v = float(v)
+    if v != v or v <= 0.0:
+        return 0
+    return 255 if v >= 255.0 else int(v)
+
+
+def load_things(wad: bytes, map_name: str):
+    """MapObjects::new: (x, y, angle in radians as f32::to_radians gives it, sprite, frame, full_bright) per thing that is not a start spot
+    and whose spawn state is not S_NULL."""
+    n, off = struct.unpack_from("<II", wad, 4)
+    lumps = [(wad[off + 16 * i + 8: off + 16 * i + 16].split(b"\0")[0].decode("ascii").upper(),) + struct.unpack_from("<II", wad, off + 16 * i) for i in range(n)]
+    mi = next(i for i, l in enumerate(lumps) if l[0] == map_name.upper())
+    _, o, s = lumps[mi + 1]
+    table = {}
+    for line in open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "mobj_spawn.tsv")):
+        if line.startswith("#") or not line.strip():
+            continue
+        t = line.split("\t")
+        table[int(t[0])] = (t[1], int(t[2]), int(t[3]) != 0, int(t[4]) != 0)
+    out = []
+    for i in range(s // 10):
+        x, y, ang, typ, _flags = struct.unpack_from("<hhhhh", wad, o + 10 * i)
+        if 1 <= typ <= 4 or typ == 11:
+            continue
+        sprite, frame, full_bright, is_null = table[typ]                        # (an unknown type is a panic in the reference)
+        if is_null:
+            continue
+        out.append({"x": F32(x), "y": F32(y), "angle": F32(ang) * (_PI / F32(180.0)), "sprite": sprite, "frame": frame, "full_bright": full_bright})
+    return out
+
+
+class SpriteTable:
+    """sprites.rs:26-117 for the sprites that are asked for."""
+
+    def __init__(self, wad: bytes):
+        self.wad = wad
+        n, off = struct.unpack_from("<II", wad, 4)
+        self.lumps = [(wad[off + 16 * i + 8: off + 16 * i + 16].split(b"\0")[0].decode("ascii").upper(),) + struct.unpack_from("<II", wad, off + 16 * i) for i in range(n)]
+        last = {nm: i for i, (nm, _, _) in enumerate(self.lumps)}            # get_dir_entry: the last lump of a name (wad.rs:128-157)
+        self.first, self.last_idx, self.by_name = last["S_START"], last["S_END"], last
+        self.cache = {}
+
+    def _picture(self, name):                                                 # pictures.rs:66-126: (w, h, top_offset, rows[y][x])
+        _, o, _ = self.lumps[self.by_name[name]]
+        d = self.wad
+        w, h, _left, top = struct.unpack_from("<hhhh", d, o)
+        px = [[None] * w for _ in range(h)]
+        for x in range(w):
+            p = o + struct.unpack_from("<I", d, o + 8 + 4 * x)[0]
+            while d[p] != 0xFF:
+                ytop, cnt = d[p], d[p + 1]
+                for k in range(cnt):
+                    if ytop + k < h:
+                        px[ytop + k][x] = d[p + 3 + k]
+                p += cnt + 4
+        return w, h, top, px
+
+    def get_picture(self, sprite: str, frame: int, rotation: int):
+        key = (sprite, frame)
+        if key not in self.cache:
+            rots = {}
+            for i in range(self.first, self.last_idx):
+                nm = self.lumps[i][0]
+                if not nm.startswith(sprite):
+                    continue
+                pic = self._picture(nm)
+                if ord(nm[4]) - 65 == frame:
+                    rots[ord(nm[5]) - 48] = pic
+                if len(nm) > 6 and ord(nm[6]) - 65 == frame:
+                    w, h, top, px = pic
+                    rots[ord(nm[7]) - 48] = (w, h, top, [row[::-1] for row in px])          # Picture::mirror, pictures.rs:129-147
+            if len(rots) != 1:
+                assert len(rots) == 8, "Got something other than 8 rotations"
+                self.cache[key] = [rots[r] for r in range(1, 9)]
+            else:
+                self.cache[key] = [rots[0]]
+        pics = self.cache[key]
+        assert rotation <= 7
+        return pics[rotation] if len(pics) == 8 else pics[0]
+
+
+def get_sector_from_vertex(m: Map, v):                    # bsp.rs:9-44
+    ni = len(m.nodes) - 1
+    while True:
+        x, y, dx, dy, rc, lc = m.nodes[ni]
+        c = lc if _is_left_of_line(v, (x, y), (x + dx, y + dy)) else rc
+        if c & 0x8000:
+            count, first = m.subsectors[c & 0x7fff]
+            for k in range(first, first + count):
+                seg = m.segs[k]
+                sd = seg["linedef"]["back"] if seg["direction"] else seg["linedef"]["front"]
+                if sd is not None:
+                    return sd["sector"]
+            return None
+        ni = c
+
+
+def render_frame(m: Map, things, sprites: SpriteTable, np_wad, nm, W: int, H: int, view, sky_name: str = "SKY1"):
+    """Renderer::render (mod.rs:118-136) in full: walls inline, visplanes, map objects with the masked walls behind them, the remaining
+    masked walls.  np_wad / nm: tests/np_mappers.py's Wad and module (the three texture mappers).  -> H x W x 3 uint8."""
+    calls = per_seg_calls(m, W, H, view)
+    columns, visplanes = column_loops(W, H, calls)
+    fr = nm.Frame(W, H)
+    pal = np_wad.palette()
+    tex_cache, flat_cache = {}, {}
+    mview = {"x": view["x"], "y": view["y"], "angle": view["angle"], "cos": view["cos"], "sin": view["sin"], "floor_height": view["floor_height"]}
+
+    def texture(name):
+        if name not in tex_cache:
+            tex_cache[name] = np_wad.texture(name)
+        return tex_cache[name]
+
+    def replay(rec, cols, bitmap):
+        for col in cols:
+            nm.render_vertical_bitmap_line(fr, bitmap, pal, rec, col)
+
+    # the records Segs.segs holds after the BSP walk (one per process_sidedef call, segs.rs:186-199, 349)
+    segs = []
+    for c, cols in zip(calls, columns):
+        fl = c["flags"]
+        two, only = bool(fl & IS_TWO_SIDED_MIDDLE_WALL), bool(fl & ONLY_OCCLUSIONS)
+        lower, upper = bool(fl & IS_LOWER_WALL), bool(fl & IS_UPPER_WALL)
+        full = not lower and not upper and not only
+        rec = {k: c[k] for k in ("light_level", "offset_x", "offset_y", "line", "start_offset", "start_x", "end_x", "bottom_height", "top_height")}
+        bitmap = texture(c["texture"]) if (fl & HAS_TEXTURE) else None
+        if bitmap is not None and not two and not only:
+            replay(rec, cols, bitmap)                                         # drawn inline, in visit order (segs.rs:231-258)
+        segs.append({"state": "two" if two else "solid", "bitmap": bitmap, "rec": rec, "cols": cols, "line": c["line"],
+                     "extends_to_bottom": lower or (not two and full), "extends_to_top": upper or (not two and full), "draw_ceiling": bool(fl & DRAW_CEILING)})
+    for (ci, which, left, right, tb) in visplanes:                            # mod.rs:106-116
+        c = calls[ci]
+        p = {"flat": get_animated(c["floor_flat"] if which == "floor" else c["ceiling_flat"], 0.0), "height": c["floor_height_i16"] if which == "floor" else c["ceiling_height_i16"],
+             "light_level": c["light_level"], "left": left, "right": right, "tb": tb}
+        if "SKY" in p["flat"]:
+            nm.draw_sky(fr, texture(sky_name), pal, mview, p)
+        else:
+            if p["flat"] not in flat_cache:
+                flat_cache[p["flat"]] = np_wad.flat(p["flat"])
+            nm.draw_visplane(fr, flat_cache[p["flat"]], pal, mview, p)
+    segs.reverse()                                                            # mod.rs:124
+
+    def is_behind_vertex(seg, v):                                             # bitmap_render.rs:137-165
+        sx, sy, ex, ey = seg["line"]
+        if min(sx, ex) > v[0]:
+            return True
+        return max(sx, ex) > v[0] and not _is_left_of_line(v, (sx, sy), (ex, ey))
+
+    def render_seg(seg):                                                      # bitmap_render.rs:101-135
+        if seg["state"] != "two":
+            return
+        if seg["bitmap"] is not None:
+            replay(seg["rec"], seg["cols"], seg["bitmap"])
+        seg["state"] = "drawn"
+
+    # draw_map_objects, renderer/map_objects.rs:19-241
+    cn, sn = view["cos_neg"], view["sin_neg"]
+    arc = F32(200.0) / F32(240.0)
+    gcfx = (F32(W) / arc) / F32(2.0)
+    cfx, cfy = F32(W) / F32(2.0), F32(H) / F32(2.0)
+
+    def non_vertical_line(s, e, height):                                      # misc.rs:138-161
+        out = []
+        for v in (s, e):
+            tx = gcfx * v[1] / v[0] * arc
+            ty = gcfx * height / v[0]
+            out.append((min(_as_i32(cfx - tx), W - 1), _as_i32(cfy - ty)))
+        return out
+    objects = []
+    two_pi = F32(2.0) * _PI
+    for t in things:
+        angle = view["angle"] - t["angle"] - _PI                              # :55-67
+        angle = angle + _PI / F32(16.0)
+        angle = F32(math.fmod(float(angle), float(two_pi)))
+        if angle < F32(0.0):
+            angle = angle + two_pi
+        angle = F32(math.fmod(float(angle), float(two_pi)))
+        rotation = _as_u8(angle * F32(8.0) / two_pi)
+        w, h, top_offset, px = sprites.get_picture(t["sprite"], t["frame"], rotation)
+        mx, my = t["x"] - view["x"], t["y"] - view["y"]
+        vp = (mx * cn - my * sn, my * cn + mx * sn)
+        start = (vp[0] - F32(0.0), vp[1] - (-F32(w) / F32(2.0)))              # :81-82
+        end = (vp[0] - F32(0.0), vp[1] - (F32(w) / F32(2.0)))
+        clipped = clip_to_viewport(start, end)
+        if clipped is None:
+            continue
+        s, e, start_offset = clipped
+        assert not (s[0] < F32(-0.01))
+        sector = get_sector_from_vertex(m, (t["x"], t["y"]))
+        if sector is None:
+            continue
+        light_level = 255 if t["full_bright"] else sector["light_level"]
+        player_height = view["floor_height"] + F32(41.0)
+        z = sector["floor_height"]
+        bottom_height = F32(z) - player_height
+        top_height = F32(z) + F32(h) - F32(1.0) - player_height
+        bottom_height = bottom_height + (F32(top_offset) - F32(h))
+        top_height = top_height + (F32(top_offset) - F32(h))
+        bottom, top = non_vertical_line(s, e, bottom_height), non_vertical_line(s, e, top_height)
+        top_clip, bottom_clip = [-1] * W, [H] * W
+        for seg in segs:                                                      # :130-166
+            if is_behind_vertex(seg, vp):
+                continue
+            for (x, ct, cb, by, ty) in seg["cols"]:
+                if seg["state"] == "solid":
+                    if seg["extends_to_bottom"]:
+                        bottom_clip[x] = min(bottom_clip[x], ct)
+                    if seg["extends_to_top"]:
+                        top_clip[x] = max(top_clip[x], cb)
+                elif seg["state"] == "two":
+                    if seg["draw_ceiling"]:
+                        top_clip[x] = max(top_clip[x], ty)
+                    bottom_clip[x] = min(bottom_clip[x], by)
+        with np.errstate(all="ignore"):
+            bdelta = (F32(bottom[0][1]) - F32(bottom[1][1])) / (F32(bottom[0][0]) - F32(bottom[1][0]))
+            tdelta = (F32(top[0][1]) - F32(top[1][1])) / (F32(top[0][0]) - F32(top[1][0]))
+            cols = []
+            for x in range(_i32_as_i16(bottom[0][0]), _i32_as_i16(bottom[1][0])):      # :194: the end is exclusive
+                by = as_i16(F32(bottom[0][1]) + (F32(x) - F32(bottom[0][0])) * bdelta)
+                ty = as_i16(F32(top[0][1]) + (F32(x) - F32(top[0][0])) * tdelta)
+                ct = max(0, max(ty, top_clip[x]))
+                cb = min(H - 1, min(by, bottom_clip[x]))
+                cols.append((x, ct, cb, by, ty))
+        rec = {"light_level": light_level, "offset_x": 0, "offset_y": 0, "line": (s[0], s[1], e[0], e[1]), "start_offset": start_offset,
+               "start_x": bottom[0][0], "end_x": bottom[1][0], "bottom_height": bottom_height, "top_height": top_height}
+        objects.append({"rec": rec, "cols": cols, "bitmap": (w, h, px), "key": as_i16(s[0])})
+    objects.sort(key=lambda o: o["key"])                                      # :216-217: stable sort on `start.x as i16`, then reversed
+    objects.reverse()
+    for o in objects:                                                         # :220-240
+        sx, sy, ex, ey = o["rec"]["line"]
+        mid = ((sx + ex) / F32(2.0), (sy + ey) / F32(2.0))
+        for seg in segs:
+            if is_behind_vertex(seg, mid):
+                render_seg(seg)
+        replay(o["rec"], o["cols"], o["bitmap"])
+    for seg in segs:                                                          # draw_remaining_segs, segs.rs:593-597
+        render_seg(seg)
+    return fr.px
