@@ -7,4 +7,4 @@ cd /tmp && export TMPDIR=/tmp
 env "$@" rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tests/manual/gpu_kbench.py > $OUT/log.txt 2>&1
 echo "== $TAG $@"
 grep "mismatches" $OUT/log.txt
-python3 $GRAFT_REPO_ROOT/tools/trace_summary.py $OUT | grep -v "fe_"
+python3 $GRAFT_REPO_ROOT/tools/trace_summary.py $OUT
