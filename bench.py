@@ -139,10 +139,10 @@ def _parse_cpulist(txt: str):
     return cpus
 
 
-def gpu_numa_nodes():
+def gpu_numa_nodes(sysfs: str = "/sys"):
     """NUMA node of every GPU in KFD enumeration order (= HIP ordinal order on a default box), read from sysfs without
-    touching HIP; [] when the topology cannot be read."""
-    base = "/sys/class/kfd/kfd/topology/nodes"
+    touching HIP; [] when the topology cannot be read.  (`sysfs`: the tree to read — tests point it at a made-up 8-GPU box.)"""
+    base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
     nodes = []
     try:
         for d in sorted(os.listdir(base), key=int):
@@ -152,7 +152,7 @@ def gpu_numa_nodes():
             loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
             bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
             try:
-                nodes.append(int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read()))
+                nodes.append(int(open(os.path.join(sysfs, f"bus/pci/devices/{bdf}/numa_node")).read()))
             except OSError:
                 nodes.append(-1)
     except (OSError, ValueError):
@@ -160,18 +160,18 @@ def gpu_numa_nodes():
     return nodes
 
 
-def bind_rank_cpus(local_rank: int, local_world: int):
-    """Pin this process (and the threads it will create) to its share of the host CPUs BEFORE any HIP call: the CPUs of the
-    GPU's NUMA node split among the ranks whose GPUs sit on that node, else an even split of the allowed CPUs."""
-    allowed = sorted(os.sched_getaffinity(0))
+def rank_cpu_share(local_rank: int, local_world: int, allowed, sysfs: str = "/sys"):
+    """-> (CPUs of this rank, how they were chosen): the CPUs of the GPU's NUMA node split among the ranks whose GPUs sit on that
+    node, else an even split of the allowed CPUs."""
+    allowed = sorted(allowed)
     if local_world <= 1 or len(allowed) < local_world:
         return allowed, "all allowed CPUs"
     share, how = None, ""
-    numa = gpu_numa_nodes()
+    numa = gpu_numa_nodes(sysfs)
     if len(numa) >= local_world and numa[local_rank] >= 0:
         node = numa[local_rank]
         try:
-            node_cpus = [c for c in _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) if c in set(allowed)]
+            node_cpus = [c for c in _parse_cpulist(open(os.path.join(sysfs, f"devices/system/node/node{node}/cpulist")).read()) if c in set(allowed)]
             peers = [r for r in range(local_world) if numa[r] == node]
             if len(node_cpus) >= len(peers):
                 i, n = peers.index(local_rank), len(peers)
@@ -182,7 +182,14 @@ def bind_rank_cpus(local_rank: int, local_world: int):
     if not share:
         share = allowed[local_rank * len(allowed) // local_world:(local_rank + 1) * len(allowed) // local_world]
         how = "even split of the allowed CPUs"
-    os.sched_setaffinity(0, share)
+    return share, how
+
+
+def bind_rank_cpus(local_rank: int, local_world: int):
+    """Pin this process (and the threads it will create) to its share of the host CPUs (rank_cpu_share) BEFORE any HIP call."""
+    share, how = rank_cpu_share(local_rank, local_world, os.sched_getaffinity(0))
+    if local_world > 1 and len(share) >= 1:
+        os.sched_setaffinity(0, share)
     return share, how
 
 

@@ -163,6 +163,68 @@ def test_device_ordinal_survives_masked_visibility():
     assert bench.pick_device(3, 0) == 3                 # no GPU visible (CPU rehearsal): unchanged, dg_create reports it
 
 
+def _fake_eight_gpu_sysfs(root, numa_of_gpu, cpulists, gpu_first=False):
+    """A KFD topology + PCI + NUMA tree shaped like an 8-GPU MI300-class host: two CPU nodes (simd_count 0) and eight GPU nodes whose
+    `properties` carry location_id / domain among other two-token lines (and a line that is not two tokens), the PCI device of each
+    with its numa_node, the NUMA nodes' cpulists."""
+    nodes = os.path.join(root, "class/kfd/kfd/topology/nodes")
+    kinds = ["cpu", "cpu"] + ["gpu"] * 8
+    if gpu_first:
+        kinds = ["gpu"] * 8 + ["cpu", "cpu"]
+    g = 0
+    for i, kind in enumerate(kinds):
+        os.makedirs(os.path.join(nodes, str(i)))
+        if kind == "cpu":
+            props = "cpu_cores_count 128\nsimd_count 0\nmem_banks_count 1\nlocation_id 0\ndomain 0\n"
+        else:
+            bus, dom = 0x05 + 0x10 * g, g // 4                       # two PCI domains, four GPUs each
+            loc = (bus << 8) | (0 << 3) | 0
+            props = f"cpu_cores_count 0\nsimd_count 1024\nmem_banks_count 1\nname\nsimd_arrays_per_engine 1\nlocation_id {loc}\ndomain {dom}\ngfx_target_version 90500\n"
+            dev = os.path.join(root, f"bus/pci/devices/{dom:04x}:{bus:02x}:00.0")
+            os.makedirs(dev)
+            open(os.path.join(dev, "numa_node"), "w").write(f"{numa_of_gpu[g]}\n")
+            g += 1
+        open(os.path.join(nodes, str(i), "properties"), "w").write(props)
+    for n, cl in enumerate(cpulists):
+        d = os.path.join(root, f"devices/system/node/node{n}")
+        os.makedirs(d)
+        open(os.path.join(d, "cpulist"), "w").write(cl + "\n")
+
+
+def test_cpu_binding_on_a_made_up_eight_gpu_topology(tmp_path):
+    """bench.py pins each rank to CPUs of its GPU's NUMA node before HIP starts.  No multi-GPU box is available to the builder, so the
+    sysfs parsing and the split are exercised on a made-up tree with the KFD layout (CPU nodes before or after the GPU nodes, two PCI
+    domains, hyper-thread sibling ranges in the cpulists, a GPU without NUMA information, a restricted affinity mask)."""
+    import bench
+    root = str(tmp_path / "a")
+    _fake_eight_gpu_sysfs(root, [0, 0, 0, 0, 1, 1, 1, 1], ["0-63,128-191", "64-127,192-255"])
+    assert bench.gpu_numa_nodes(root) == [0, 0, 0, 0, 1, 1, 1, 1]
+    allowed = range(256)
+    shares = [bench.rank_cpu_share(r, 8, allowed, root) for r in range(8)]
+    assert all(len(s) == 32 for s, _ in shares) and all("NUMA node" in how and "4 rank(s)" in how for _, how in shares)
+    flat = [c for s, _ in shares for c in s]
+    assert sorted(flat) == list(range(256))                          # disjoint, everything used
+    assert set(shares[0][0]) <= set(range(0, 64)) | set(range(128, 192)) and set(shares[5][0]) <= set(range(64, 128)) | set(range(192, 256))
+    # GPU nodes enumerated before the CPU nodes, GPUs interleaved over the NUMA nodes
+    root = str(tmp_path / "b")
+    _fake_eight_gpu_sysfs(root, [0, 1, 0, 1, 0, 1, 0, 1], ["0-127", "128-255"], gpu_first=True)
+    assert bench.gpu_numa_nodes(root) == [0, 1, 0, 1, 0, 1, 0, 1]
+    s1, how = bench.rank_cpu_share(1, 8, allowed, root)
+    assert s1 == list(range(128, 160)) and "node 1" in how
+    # a launcher that left this rank 16 CPUs in all: fewer CPUs on the node than ranks sharing it -> even split of what is allowed
+    s, how = bench.rank_cpu_share(3, 8, range(0, 16), root)
+    assert s == [6, 7] and how == "even split of the allowed CPUs"
+    # a GPU whose PCI device reports no NUMA node
+    root = str(tmp_path / "c")
+    _fake_eight_gpu_sysfs(root, [-1] * 8, ["0-255"])
+    s, how = bench.rank_cpu_share(2, 8, allowed, root)
+    assert s == list(range(64, 96)) and how == "even split of the allowed CPUs"
+    # no topology at all (this container): even split; one rank: everything
+    assert bench.gpu_numa_nodes(str(tmp_path / "none")) == []
+    assert bench.rank_cpu_share(0, 2, range(8), str(tmp_path / "none")) == ([0, 1, 2, 3], "even split of the allowed CPUs")
+    assert bench.rank_cpu_share(0, 1, range(8), root)[1] == "all allowed CPUs"
+
+
 def test_route_from_wad_gives_a_closed_walk(synth, campath_mod):
     """bench.py --wad: any map yields a route (midpoints of its two-sided lines around their centroid, from the FIRST marker)."""
     for quirks in (False, True):
