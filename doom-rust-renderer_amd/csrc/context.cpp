@@ -106,7 +106,8 @@ private:
 
 struct Slot {
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_raster = nullptr, ev_rstart = nullptr;
+    hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_raster = nullptr, ev_rstart = nullptr, ev_h2d = nullptr;
+    bool raster_recorded = false;
     hipStream_t copy_stream = nullptr;   // dg_readback_async: D2H of this slot's frames while another slot's kernels run
     uint8_t *copy_out = nullptr;         // pending asynchronous readback (re-issued if the batch has to be redone)
     int copy_first = 0, copy_count = 0;
@@ -126,8 +127,8 @@ struct Slot {
     // device column walk (DG_FE_DEVICE)
     uint8_t *h_fe = nullptr, *d_fe = nullptr;   // record slab: pinned staging / HBM
     uint32_t *d_fe_coloff = nullptr;
-    uint32_t *d_status = nullptr, *h_status = nullptr;   // [F] overflow flags, [F] spans per frame; on the device followed by the
-                                                         // sky event bits (fe_event_words) so that one fill clears both
+    uint32_t *h_status = nullptr;               // pinned host memory the walk's kernels write: [F] overflow flags, [F] spans per frame
+    uint64_t *d_events = nullptr;               // sky event bits (fe_event_words), zeroed before every walk
     FeParams FP{};
     bool fe_mode = false;         // the last submission went through the device column walk
     bool fe_check = false;        // ... and its overflow flags have not been looked at yet
@@ -172,8 +173,7 @@ struct dg_ctx {
     uint4 *d_row_tab = nullptr;         // per-row constants of the flat / sky mappers (dg_row_table), rebuilt per scene upload
     DevScene dscene{};
     std::vector<Slot> slots;
-    hipEvent_t last_front = nullptr;    // end of the last column walk: the shared column scratch is free again
-    hipEvent_t last_raster = nullptr;   // raster kernels of different slots run back to back; list uploads overlap them
+    hipStream_t kstream = nullptr;      // every kernel of every slot, in submission order (enqueue_kernels)
     std::unique_ptr<Pool> pool;
     std::vector<std::unique_ptr<FrameArena>> arenas;   // one per worker (+ caller)
     std::vector<BinnedFrame> binned;                   // one per frame of a batch
@@ -198,6 +198,12 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Everything queued for the slot so far has finished (its kernels run on the ctx's kernel stream, the rest on its own).
+hipError_t slot_sync(Slot &s) {
+    if (s.raster_recorded) { const hipError_t e = hipEventSynchronize(s.ev_raster); if (e != hipSuccess) return e; }
+    return hipStreamSynchronize(s.stream);
+}
+
 void free_ctx(dg_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
@@ -210,15 +216,17 @@ void free_ctx(dg_ctx *c) {
         if (s.h_fe) (void)hipHostFree(s.h_fe);
         if (s.d_fe) (void)hipFree(s.d_fe);
         if (s.d_fe_coloff) (void)hipFree(s.d_fe_coloff);
-        if (s.d_status) (void)hipFree(s.d_status);
+        if (s.d_events) (void)hipFree(s.d_events);
         if (s.h_status) (void)hipHostFree(s.h_status);
         if (s.ev_start) (void)hipEventDestroy(s.ev_start);
         if (s.ev_setup) (void)hipEventDestroy(s.ev_setup);
         if (s.ev_raster) (void)hipEventDestroy(s.ev_raster);
         if (s.ev_rstart) (void)hipEventDestroy(s.ev_rstart);
+        if (s.ev_h2d) (void)hipEventDestroy(s.ev_h2d);
         if (s.copy_stream) { (void)hipStreamSynchronize(s.copy_stream); (void)hipStreamDestroy(s.copy_stream); }
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
+    if (c->kstream) { (void)hipStreamSynchronize(c->kstream); (void)hipStreamDestroy(c->kstream); }
     if (c->d_palette) (void)hipFree(c->d_palette);
     if (c->d_texel_idx) (void)hipFree(c->d_texel_idx);
     if (c->d_texel_opq) (void)hipFree(c->d_texel_opq);
@@ -389,8 +397,8 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_vie
     F.bin_parts = reinterpret_cast<const uint16_t *>(s.d_fe + off_bins);
     F.sbin_sprites = reinterpret_cast<const uint16_t *>(s.d_fe + off_sbins);
     F.cspans = c->d_fe_cspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt;
-    F.events = reinterpret_cast<uint64_t *>(s.d_status + 2 * (size_t)c->cfg.max_batch);
-    F.flags = s.d_status; F.totals = s.d_status + c->cfg.max_batch;
+    F.events = s.d_events;
+    F.flags = s.h_status; F.totals = s.h_status + c->cfg.max_batch;      // pinned host memory, written by the kernels directly
     F.col_off = s.d_fe_coloff; F.rspans = s.d_rspans;
     F.n_frames = n; F.span_stride = span_stride; F.w64 = (uint32_t)((W + 63) / 64); F.col_slots = c->fe_col_slots;
     RasterParams &P = s.P;
@@ -422,33 +430,31 @@ int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *
 }
 
 int enqueue_kernels(dg_ctx *c, Slot &s) {
-    // The slot's H2D copy is already queued on its stream and may overlap the previous slot's kernels.  Raster kernels run
-    // back to back (each fills the chip on its own).  The column walk of this submission only needs the shared column
-    // scratch, which is free once the previous submission's scatter kernel has finished, so it overlaps that submission's
-    // raster kernel (the walk is latency bound, the raster issue bound).
+    // All kernels of all slots run on ONE in-order stream (highest priority, so that it gets a hardware queue of its own): column walk
+    // i, rasteriser i, column walk i + 1, ...  The slot's own stream carries its H2D copy (queued already; it overlaps the previous
+    // slots' kernels), tied in with an event.  Letting the walk of batch i + 1 overlap the raster launch of batch i was measured to buy
+    // nothing: its waves take slots a raster workgroup needs as a whole, the launch stretches by what the walk costs alone
+    // (profiles/r03_column_walk.md).  The walk's per-frame status words (overflow flags, span totals) live in pinned host memory and are
+    // written by the kernels directly: nothing is queued behind the raster launch, so no stream ever holds a barrier that another
+    // slot's upload could get stuck behind (streams share hardware queues).
+    hipStream_t ks = c->kstream;
+    HIP_TRY(hipEventRecord(s.ev_h2d, s.stream));
+    HIP_TRY(hipStreamWaitEvent(ks, s.ev_h2d, 0));
+    HIP_TRY(hipEventRecord(s.ev_start, ks));
     if (s.fe_mode) {
-        if (c->last_front && c->last_front != s.ev_setup) HIP_TRY(hipStreamWaitEvent(s.stream, c->last_front, 0));
-        HIP_TRY(hipEventRecord(s.ev_start, s.stream));
+        std::memset(s.h_status, 0, (size_t)2 * (size_t)c->cfg.max_batch * 4);
         const size_t ev_bytes = (size_t)3 * (size_t)s.FP.n_frames * s.FP.max_sky_slots * s.FP.w64 * 8;   // all three event kinds (fe_event_words)
-        HIP_TRY(hipMemsetAsync(s.d_status, 0, (size_t)2 * (size_t)c->cfg.max_batch * 4 + ev_bytes, s.stream));
-        HIP_TRY(launch_fe(s.FP, s.stream));
-        HIP_TRY(hipEventRecord(s.ev_setup, s.stream));
-        c->last_front = s.ev_setup;
-        if (c->last_raster && c->last_raster != s.ev_raster) HIP_TRY(hipStreamWaitEvent(s.stream, c->last_raster, 0));
-    } else {
-        if (c->last_raster && c->last_raster != s.ev_raster) HIP_TRY(hipStreamWaitEvent(s.stream, c->last_raster, 0));
-        HIP_TRY(hipEventRecord(s.ev_start, s.stream));
-        HIP_TRY(launch_setup(s.P, s.max_spans, s.stream));
-        HIP_TRY(hipEventRecord(s.ev_setup, s.stream));
-    }
-    HIP_TRY(hipEventRecord(s.ev_rstart, s.stream));
-    HIP_TRY(launch_raster(s.P, s.stream));
-    HIP_TRY(hipEventRecord(s.ev_raster, s.stream));
-    c->last_raster = s.ev_raster;
-    if (s.fe_mode) {
-        HIP_TRY(hipMemcpyAsync(s.h_status, s.d_status, (size_t)2 * (size_t)c->cfg.max_batch * 4, hipMemcpyDeviceToHost, s.stream));
+        if (ev_bytes) HIP_TRY(hipMemsetAsync(s.d_events, 0, ev_bytes, ks));
+        HIP_TRY(launch_fe(s.FP, ks));
         s.fe_check = true;
+    } else {
+        HIP_TRY(launch_setup(s.P, s.max_spans, ks));
     }
+    HIP_TRY(hipEventRecord(s.ev_setup, ks));
+    HIP_TRY(hipEventRecord(s.ev_rstart, ks));
+    HIP_TRY(launch_raster(s.P, ks));
+    HIP_TRY(hipEventRecord(s.ev_raster, ks));
+    s.raster_recorded = true;
     s.busy = true; s.timed = true;
     return DG_OK;
 }
@@ -497,7 +503,7 @@ int redo_frame_host(dg_ctx *c, Slot &s, int i) {
     Q.n_frames = 1;
     HIP_TRY(launch_setup(Q, (uint32_t)bf.spans.size(), s.stream));
     HIP_TRY(launch_raster(Q, s.stream));
-    HIP_TRY(hipStreamSynchronize(s.stream));                                 // the host slab is reused by the next frame
+    HIP_TRY(slot_sync(s));                                 // the host slab is reused by the next frame
     return DG_OK;
 }
 
@@ -533,7 +539,7 @@ int settle_slot(dg_ctx *c, Slot &s) {
             if (rc) return rc;
             rc = enqueue_kernels(c, s);
             if (rc) return rc;
-            HIP_TRY(hipStreamSynchronize(s.stream));
+            HIP_TRY(slot_sync(s));
         }
     }
     return DG_OK;
@@ -549,7 +555,7 @@ int enqueue_copy(dg_ctx *c, Slot &s) {
 // Everything queued for the slot has finished: kernels, capacity checks (a batch that overflowed is redone here) and a
 // pending asynchronous readback (re-issued after a redo: its first copy took frames of the overflowed run).
 int finish_slot(dg_ctx *c, Slot &s) {
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    HIP_TRY(slot_sync(s));
     s.busy = false;
     const uint64_t redone = c->fallbacks_fe;
     int rc = settle_slot(c, s);
@@ -714,12 +720,18 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         CTX_TRY(hipMalloc((void **)&c->d_fe_recs, F * c->fe_col_slots * W * sizeof(FeColRec)));
         CTX_TRY(hipMalloc((void **)&c->d_fe_cnt, F * W * 4));
     }
+    {
+        int lo = 0, hi = 0;
+        CTX_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        CTX_TRY(hipStreamCreateWithPriority(&c->kstream, hipStreamNonBlocking, hi));
+    }
     for (Slot &s : c->slots) {
         CTX_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         CTX_TRY(hipEventCreate(&s.ev_start));
         CTX_TRY(hipEventCreate(&s.ev_setup));
         CTX_TRY(hipEventCreate(&s.ev_raster));
         CTX_TRY(hipEventCreate(&s.ev_rstart));
+        CTX_TRY(hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming));
         CTX_TRY(hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking));
         CTX_TRY(hipHostMalloc((void **)&s.h_lists, lists_cap, hipHostMallocDefault));
         CTX_TRY(hipMalloc((void **)&s.d_lists, lists_cap));
@@ -729,7 +741,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
             CTX_TRY(hipHostMalloc((void **)&s.h_fe, c->fe_slab_cap, hipHostMallocDefault));
             CTX_TRY(hipMalloc((void **)&s.d_fe, c->fe_slab_cap));
             CTX_TRY(hipMalloc((void **)&s.d_fe_coloff, F * (W + 1) * 4));
-            CTX_TRY(hipMalloc((void **)&s.d_status, 2 * F * 4 + F * FE_MAX_SKY_SLOTS * 3 * ((W + 63) / 64) * 8));
+            CTX_TRY(hipMalloc((void **)&s.d_events, F * FE_MAX_SKY_SLOTS * 3 * ((W + 63) / 64) * 8));
             CTX_TRY(hipHostMalloc((void **)&s.h_status, 2 * F * 4, hipHostMallocDefault));
         }
         s.lists_cap = lists_cap;
@@ -746,7 +758,7 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     if (!c || !scene) return set_err(DG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
     for (Slot &s : c->slots) {             // nothing may still read the old scene or write into a buffer a pending readback is copying from
-        HIP_TRY(hipStreamSynchronize(s.stream));
+        HIP_TRY(slot_sync(s));
         HIP_TRY(hipStreamSynchronize(s.copy_stream));
         s.copy_pending = false;
     }
@@ -867,13 +879,13 @@ int dg_readback(dg_ctx *c, int slot, int first, int count, uint8_t *out) {
     if (!out || first < 0 || count < 0 || first + count > s.n_frames) return set_err(DG_ERR_INVALID, "bad readback range");
     HIP_TRY(hipSetDevice(c->cfg.device));
     const size_t fsz = (size_t)3 * (size_t)c->cfg.width * (size_t)c->cfg.height;
+    HIP_TRY(slot_sync(s));
     if (s.fe_check) {
-        HIP_TRY(hipStreamSynchronize(s.stream));
         rc = settle_slot(c, s);
         if (rc) return rc;
     }
     HIP_TRY(hipMemcpyAsync(out, s.d_fb + (size_t)first * fsz, (size_t)count * fsz, hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    HIP_TRY(slot_sync(s));
     s.busy = false;
     return DG_OK;
 }
@@ -885,8 +897,8 @@ int dg_frame_checksums(dg_ctx *c, int slot, int first, int count, uint64_t *out)
     if (!out || first < 0 || count < 0 || first + count > s.n_frames) return set_err(DG_ERR_INVALID, "bad frame range");
     if (count == 0) return DG_OK;
     HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(slot_sync(s));                       // (the kernels run on the ctx's kernel stream: the copy below is not ordered behind them by its stream)
     if (s.fe_check) {
-        HIP_TRY(hipStreamSynchronize(s.stream));
         rc = settle_slot(c, s);
         if (rc) return rc;
     }
@@ -895,7 +907,7 @@ int dg_frame_checksums(dg_ctx *c, int slot, int first, int count, uint64_t *out)
     hipError_t e = hipMemsetAsync(d_sum, 0, (size_t)count * 8, s.stream);
     if (e == hipSuccess) e = launch_checksums(s.d_fb + (size_t)first * fsz, fsz, count, d_sum, s.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_sum, (size_t)count * 8, hipMemcpyDeviceToHost, s.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+    if (e == hipSuccess) e = slot_sync(s);
     if (e != hipSuccess) return set_err(DG_ERR_HIP, std::string("dg_frame_checksums: ") + hipGetErrorString(e));
     s.busy = false;
     return DG_OK;
@@ -922,7 +934,7 @@ int dg_prepare_views(dg_ctx *c, int slot, const dg_view *views, int n) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     Slot &s = c->slots[(size_t)slot];
     if (s.busy || s.copy_pending) { rc = finish_slot(c, s); if (rc) return rc; }   // incl. a readback still copying out of the slot's framebuffer
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    HIP_TRY(slot_sync(s));
     s.busy = false; s.fe_check = false;
     rc = build_batch(c, s, views, nullptr, n);
     if (rc) return rc;
@@ -930,7 +942,7 @@ int dg_prepare_views(dg_ctx *c, int slot, const dg_view *views, int n) {
         rc = enqueue_kernels(c, s);   // is re-prepared that way now, not on a replay
         if (rc) return rc;
     }
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    HIP_TRY(slot_sync(s));
     s.busy = false;
     return settle_slot(c, s);
 }
@@ -946,7 +958,7 @@ int dg_replay_slot(dg_ctx *c, int slot) {
         if (rc) return rc;
     }
     if (s.fe_check) {   // a submission that was never waited for
-        HIP_TRY(hipStreamSynchronize(s.stream));
+        HIP_TRY(slot_sync(s));
         rc = settle_slot(c, s);
         if (rc) return rc;
     }
@@ -978,7 +990,7 @@ int dg_slot_timing(dg_ctx *c, int slot, dg_timing *out) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipEventSynchronize(s.ev_raster));
     if (s.fe_check) {
-        HIP_TRY(hipStreamSynchronize(s.stream));
+        HIP_TRY(slot_sync(s));
         rc = settle_slot(c, s);
         if (rc) return rc;
     }
