@@ -388,7 +388,7 @@ def run(args, backend_factory=DoomGpuBackend):
                 "front_end_kernels_mean_ms": float(np.mean(setup_ms)),
                 "frames_per_launch": B, "pixels_per_s": B * W * H / mean_raster_s,
                 "achievable_write_GBps": achievable_fill, "frac_of_achievable_write": (achieved / achievable_fill) if achievable_fill else None,
-                "note": "achieved/frac are measured over the timed steps, where the next batch's column-walk kernels and H2D overlap these kernels; "
+                "note": "achieved/frac are measured over the timed steps (all kernels on one in-order stream; only the next batch's H2D copy overlaps these kernels); "
                         "isolated_* is the same launch measured with nothing else on the GPU"}
     if iso_ms:
         iso = float(np.mean(iso_ms)) / 1e3
