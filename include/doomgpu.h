@@ -127,7 +127,8 @@ int dg_upload_scene(dg_ctx *ctx, const dg_scene *scene);
 /* ---- full path ---------------------------------------------------------------------------------------------- */
 /* Synchronous: render n views; if rgb24_out != NULL copy n*3*W*H bytes to host memory.  Uses slot 0. */
 int dg_render_views(dg_ctx *ctx, const dg_view *views, int n, uint8_t *rgb24_out);
-/* Asynchronous: build lists on the host (blocking), then enqueue H2D + kernels on the slot's stream. */
+/* Asynchronous: build lists on the host (blocking), then enqueue the H2D copy on the slot's stream and the kernels behind it on the
+ * ctx's kernel stream (all slots' kernels run there, in submission order). */
 int dg_submit_views(dg_ctx *ctx, int slot, const dg_view *views, int n);
 /* The same with a game-state snapshot per view (states[i] for views[i]; states == NULL: none). */
 int dg_submit_views_state(dg_ctx *ctx, int slot, const dg_view *views, const dg_view_state *states, int n);
@@ -216,7 +217,7 @@ int dg_build_lists(const dg_scene *s, int width, int height, const dg_view *view
 const char *dg_last_error(void); /* thread-local message of the last failing call */
 const char *dg_version(void);
 
-/* Timing of the last dg_replay_slot / submit on a slot, from HIP events on the slot's stream (ms). */
+/* Timing of the last dg_replay_slot / submit on a slot, from HIP events on the ctx's kernel stream (ms). */
 typedef struct dg_timing {
     float setup_ms, raster_ms, total_ms;
     float host_ms;            /* host list generation + binning + packing of that submission (wall clock) */
