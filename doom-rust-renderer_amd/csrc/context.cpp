@@ -207,6 +207,7 @@ hipError_t slot_sync(Slot &s) {
 void free_ctx(dg_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
+    if (c->kstream) (void)hipStreamSynchronize(c->kstream);        // every slot's kernels, before anything they use is freed
     for (Slot &s : c->slots) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         if (s.h_lists) (void)hipHostFree(s.h_lists);
@@ -226,7 +227,7 @@ void free_ctx(dg_ctx *c) {
         if (s.copy_stream) { (void)hipStreamSynchronize(s.copy_stream); (void)hipStreamDestroy(s.copy_stream); }
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
-    if (c->kstream) { (void)hipStreamSynchronize(c->kstream); (void)hipStreamDestroy(c->kstream); }
+    if (c->kstream) (void)hipStreamDestroy(c->kstream);
     if (c->d_palette) (void)hipFree(c->d_palette);
     if (c->d_texel_idx) (void)hipFree(c->d_texel_idx);
     if (c->d_texel_opq) (void)hipFree(c->d_texel_opq);
