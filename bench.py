@@ -193,6 +193,32 @@ def bind_rank_cpus(local_rank: int, local_world: int):
     return share, how
 
 
+def cgroup_cpu_quota(root: str = "/sys/fs/cgroup") -> int:
+    """CPUs' worth of run time the container allows this process (cgroup v2 cpu.max, v1 cfs quota), rounded up; 0 = no limit / unknown."""
+    try:
+        q, p = open(os.path.join(root, "cpu.max")).read().split()[:2]
+        return 0 if q == "max" else -(-int(q) // int(p))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open(os.path.join(root, "cpu/cpu.cfs_quota_us")).read())
+        p = int(open(os.path.join(root, "cpu/cpu.cfs_period_us")).read())
+        return -(-q // p) if q > 0 and p > 0 else 0
+    except (OSError, ValueError):
+        return 0
+
+
+def default_host_threads(cgroup_root: str = "/sys/fs/cgroup") -> int:
+    """Host threads of this rank's ctx: its CPU share — the affinity mask bind_rank_cpus has set by now and the container's CPU quota
+    (the GPU boxes show 256 CPUs and allow 16 CPUs of run time per GPU: 64 threads there get the process throttled, 2560x1600 drops
+    from 133 k to 102 k frames/s) — at most 64.  Without a quota: 1.1 / 0.75 / 0.58 ms per 1 000-frame batch with 16 / 32 / 64 threads."""
+    n = len(os.sched_getaffinity(0))
+    quota = cgroup_cpu_quota(cgroup_root)
+    if quota > 0:
+        n = min(n, quota)
+    return max(1, min(n, 64))
+
+
 class DoomGpuBackend:
     """The real thing: libdoomgpu through the ctypes binding, synthetic IWADs, the camera-path generator."""
 
@@ -221,7 +247,7 @@ class DoomGpuBackend:
         B = a.batch
         self.n_slots = max(1, a.slots)                # (with fewer batches per step than slots, a slot holds the same batch every other step)
         fe = self.dg.DG_FE_HOST if a.front_end == "host" else self.dg.DG_FE_DEVICE
-        self.ctx = self.dg.Context(a.width, a.height, max_batch=B, slots=self.n_slots, device=self.device, host_threads=a.host_threads, front_end=fe)
+        self.ctx = self.dg.Context(a.width, a.height, max_batch=B, slots=self.n_slots, device=self.device, host_threads=a.host_threads or default_host_threads(), front_end=fe)
         self.ctx.upload_scene(self.scene)
         loop = np.concatenate([self.path, self.path])
         self.batch_first = [s * B % PATH_FRAMES for s in range(self.n_slots)]

@@ -49,14 +49,16 @@ struct dg_scene { Scene *sc; };
 
 namespace {
 
-// Minimal persistent pool: parallel_for over [0, n) with dynamic chunking.
+// Worker pool for the per-frame host work of a batch.  A batch is ~1 ms of work cut into 1 000 items, and batches follow each other
+// within a millisecond or two, so what matters is how fast the workers get going: they spin on the generation counter for a while after
+// each job (a condition-variable wake-up of 15-31 sleeping threads costs a good part of such a job) and only then block.
 class Pool {
 public:
     explicit Pool(int n) {
         for (int i = 0; i < n; i++) workers_.emplace_back([this, i] { loop(i); });
     }
     ~Pool() {
-        { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_++; }
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_.fetch_add(1); }
         cv_.notify_all();
         for (auto &t : workers_) t.join();
     }
@@ -64,11 +66,15 @@ public:
     // fn(index, worker_id); worker ids are 0..size() (the caller participates as id size()).
     void parallel_for(int n, const std::function<void(int, int)> &fn) {
         if (n <= 0) return;
-        { std::lock_guard<std::mutex> l(m_); fn_ = &fn; n_ = n; next_.store(0); pending_ = (int)workers_.size(); gen_++; }
-        cv_.notify_all();
+        {
+            std::lock_guard<std::mutex> l(m_);
+            fn_ = &fn; n_ = n; next_.store(0); pending_.store((int)workers_.size());
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        if (sleepers_.load() > 0) cv_.notify_all();
         run(fn, (int)workers_.size());
-        std::unique_lock<std::mutex> l(m_);
-        done_.wait(l, [this] { return pending_ == 0; });
+        for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; spin++)
+            if (spin > 2000) std::this_thread::yield();
         fn_ = nullptr;
     }
 private:
@@ -82,25 +88,39 @@ private:
     void loop(int wid) {
         uint64_t seen = 0;
         for (;;) {
+            // spin for ~200 us, then block
+            const auto t0 = std::chrono::steady_clock::now();
+            int polls = 0;
+            while (gen_.load(std::memory_order_acquire) == seen) {
+                if ((++polls & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+                    std::unique_lock<std::mutex> l(m_);
+                    sleepers_.fetch_add(1);
+                    cv_.wait(l, [&] { return gen_.load() != seen; });
+                    sleepers_.fetch_sub(1);
+                    break;
+                }
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
             const std::function<void(int, int)> *fn;
             {
-                std::unique_lock<std::mutex> l(m_);
-                cv_.wait(l, [&] { return gen_ != seen; });
-                seen = gen_;
+                std::lock_guard<std::mutex> l(m_);      // fn_ / n_ / next_ of this generation are published under the mutex
+                seen = gen_.load();
                 if (stop_) return;
                 fn = fn_;
             }
             if (fn) run(*fn, wid);
-            { std::lock_guard<std::mutex> l(m_); if (--pending_ == 0) done_.notify_all(); }
+            pending_.fetch_sub(1, std::memory_order_release);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_;
-    std::condition_variable cv_, done_;
+    std::condition_variable cv_;
     const std::function<void(int, int)> *fn_ = nullptr;
-    std::atomic<int> next_{0};
-    int n_ = 0, pending_ = 0;
-    uint64_t gen_ = 0;
+    std::atomic<int> next_{0}, pending_{0}, sleepers_{0};
+    int n_ = 0;
+    std::atomic<uint64_t> gen_{0};
     bool stop_ = false;
 };
 
@@ -197,6 +217,21 @@ struct dg_ctx {
 namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// CPUs' worth of run time the container allows this process (cgroup v2 cpu.max, v1 cfs quota), rounded up; 0 = no limit / unknown.
+int cgroup_cpu_quota() {
+    long long quota = -1, period = 0;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atoll(q);
+        std::fclose(f);
+    } else {
+        if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%lld", &quota) != 1) quota = -1; std::fclose(g); }
+        if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%lld", &period) != 1) period = 0; std::fclose(g); }
+    }
+    if (quota <= 0 || period <= 0) return 0;
+    return (int)((quota + period - 1) / period);
+}
 
 // Everything queued for the slot so far has finished (its kernels run on the ctx's kernel stream, the rest on its own).
 hipError_t slot_sync(Slot &s) {
@@ -668,13 +703,16 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     c->cfg = *cfg;
     c->fk = make_consts(cfg->width, cfg->height);
     c->dk = DevConsts{c->fk.ARC, c->fk.GCFX, c->fk.CFX, c->fk.CFY, cfg->width, cfg->height};
-    // Default: the process's CPU share (affinity mask), capped at 16 per GPU — an 8-GPU node gives each rank ~1/8 of the cores.
+    // Default: the process's CPU share — its affinity mask and, in a container, its cgroup CPU quota (threads beyond the quota only get
+    // the process throttled) — capped at 32 per ctx: an 8-GPU node gives each rank ~1/8 of the CPUs.
     int nthreads = cfg->host_threads;
     if (nthreads <= 0) {
         cpu_set_t set;
         CPU_ZERO(&set);
         int avail = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
-        nthreads = std::max(1, std::min(avail, 16));
+        const int quota = cgroup_cpu_quota();
+        if (quota > 0) avail = std::min(avail, quota);
+        nthreads = std::max(1, std::min(avail, 32));
     }
     nthreads = std::min(nthreads, 256);
     c->n_threads = nthreads;

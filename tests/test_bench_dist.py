@@ -225,6 +225,29 @@ def test_cpu_binding_on_a_made_up_eight_gpu_topology(tmp_path):
     assert bench.rank_cpu_share(0, 1, range(8), root)[1] == "all allowed CPUs"
 
 
+def test_host_threads_respect_the_container_cpu_quota(tmp_path):
+    """The GPU boxes show 256 CPUs in the affinity mask and allow 16 CPUs of run time (cgroup v2 cpu.max "1600000 100000"): the default
+    thread count must come from the quota, or the process is throttled."""
+    import bench
+    v2 = tmp_path / "v2"; v2.mkdir()
+    (v2 / "cpu.max").write_text("1600000 100000\n")
+    assert bench.cgroup_cpu_quota(str(v2)) == 16
+    (v2 / "cpu.max").write_text("250000 100000\n")
+    assert bench.cgroup_cpu_quota(str(v2)) == 3                       # rounded up
+    (v2 / "cpu.max").write_text("max 100000\n")
+    assert bench.cgroup_cpu_quota(str(v2)) == 0
+    v1 = tmp_path / "v1"; (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("800000\n"); (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.cgroup_cpu_quota(str(v1)) == 8
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert bench.cgroup_cpu_quota(str(v1)) == 0
+    assert bench.cgroup_cpu_quota(str(tmp_path / "none")) == 0
+    n_aff = len(os.sched_getaffinity(0))
+    (v2 / "cpu.max").write_text("200000 100000\n")
+    assert bench.default_host_threads(str(v2)) == min(n_aff, 2)
+    assert bench.default_host_threads(str(tmp_path / "none")) == min(n_aff, 64)
+
+
 def test_route_from_wad_gives_a_closed_walk(synth, campath_mod):
     """bench.py --wad: any map yields a route (midpoints of its two-sided lines around their centroid, from the FIRST marker)."""
     for quirks in (False, True):
