@@ -211,7 +211,7 @@ def cgroup_cpu_quota(root: str = "/sys/fs/cgroup") -> int:
 def default_host_threads(cgroup_root: str = "/sys/fs/cgroup") -> int:
     """Host threads of this rank's ctx: its CPU share — the affinity mask bind_rank_cpus has set by now and the container's CPU quota
     (the GPU boxes show 256 CPUs and allow 16 CPUs of run time per GPU: 64 threads there get the process throttled, 2560x1600 drops
-    from 133 k to 102 k frames/s) — at most 64.  Without a quota: 1.1 / 0.75 / 0.58 ms per 1 000-frame batch with 16 / 32 / 64 threads."""
+    from 133 k to 102 k frames/s) — at most 64."""
     n = len(os.sched_getaffinity(0))
     quota = cgroup_cpu_quota(cgroup_root)
     if quota > 0:

@@ -49,16 +49,14 @@ struct dg_scene { Scene *sc; };
 
 namespace {
 
-// Worker pool for the per-frame host work of a batch.  A batch is ~1 ms of work cut into 1 000 items, and batches follow each other
-// within a millisecond or two, so what matters is how fast the workers get going: they spin on the generation counter for a while after
-// each job (a condition-variable wake-up of 15-31 sleeping threads costs a good part of such a job) and only then block.
+// Minimal persistent pool: parallel_for over [0, n) with dynamic chunking.
 class Pool {
 public:
     explicit Pool(int n) {
         for (int i = 0; i < n; i++) workers_.emplace_back([this, i] { loop(i); });
     }
     ~Pool() {
-        { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_.fetch_add(1); }
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; gen_++; }
         cv_.notify_all();
         for (auto &t : workers_) t.join();
     }
@@ -66,15 +64,11 @@ public:
     // fn(index, worker_id); worker ids are 0..size() (the caller participates as id size()).
     void parallel_for(int n, const std::function<void(int, int)> &fn) {
         if (n <= 0) return;
-        {
-            std::lock_guard<std::mutex> l(m_);
-            fn_ = &fn; n_ = n; next_.store(0); pending_.store((int)workers_.size());
-            gen_.fetch_add(1, std::memory_order_release);
-        }
-        if (sleepers_.load() > 0) cv_.notify_all();
+        { std::lock_guard<std::mutex> l(m_); fn_ = &fn; n_ = n; next_.store(0); pending_ = (int)workers_.size(); gen_++; }
+        cv_.notify_all();
         run(fn, (int)workers_.size());
-        for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; spin++)
-            if (spin > 2000) std::this_thread::yield();
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
         fn_ = nullptr;
     }
 private:
@@ -88,39 +82,25 @@ private:
     void loop(int wid) {
         uint64_t seen = 0;
         for (;;) {
-            // spin for ~200 us, then block
-            const auto t0 = std::chrono::steady_clock::now();
-            int polls = 0;
-            while (gen_.load(std::memory_order_acquire) == seen) {
-                if ((++polls & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
-                    std::unique_lock<std::mutex> l(m_);
-                    sleepers_.fetch_add(1);
-                    cv_.wait(l, [&] { return gen_.load() != seen; });
-                    sleepers_.fetch_sub(1);
-                    break;
-                }
-#if defined(__x86_64__)
-                __builtin_ia32_pause();
-#endif
-            }
             const std::function<void(int, int)> *fn;
             {
-                std::lock_guard<std::mutex> l(m_);      // fn_ / n_ / next_ of this generation are published under the mutex
-                seen = gen_.load();
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return gen_ != seen; });
+                seen = gen_;
                 if (stop_) return;
                 fn = fn_;
             }
             if (fn) run(*fn, wid);
-            pending_.fetch_sub(1, std::memory_order_release);
+            { std::lock_guard<std::mutex> l(m_); if (--pending_ == 0) done_.notify_all(); }
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_;
-    std::condition_variable cv_;
+    std::condition_variable cv_, done_;
     const std::function<void(int, int)> *fn_ = nullptr;
-    std::atomic<int> next_{0}, pending_{0}, sleepers_{0};
-    int n_ = 0;
-    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> next_{0};
+    int n_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
     bool stop_ = false;
 };
 
