@@ -188,17 +188,28 @@ __global__ __launch_bounds__(FE_SCAN_THREADS) void dg_fe_scan(FeParams P) {
 // (distinct keys), resolve the texture-mapping constants (what dg_setup_spans does for host-built lists), scatter into the
 // column-major list.  64 adjacent columns x FE_SCATTER_GROUPS slot groups per workgroup: the lanes of a wave read the
 // same slot of 64 adjacent columns (coalesced in the [slot][column] scratch layout); the keys are staged in LDS once.
+//
+// The spans of the workgroup's 64 columns are ONE contiguous range of the output, but a lane's record lands n_x * 32 bytes from its
+// neighbour's: stored straight from the lanes, every record is its own pair of partial-line writes (9 M of the 14.7 M requests the L2
+// sees per 1 000 frames, profiles/r03_column_walk.md).  So the records are assembled in LDS at their final position and the workgroup
+// then streams the range out, 16 consecutive bytes per lane — full lines.  A range of more than FE_SCATTER_STAGE records is stored directly.
+constexpr uint32_t FE_SCATTER_STAGE = 384;
+
 __global__ __launch_bounds__(64 * FE_SCATTER_GROUPS) void dg_fe_scatter(FeParams P) {
-    extern __shared__ uint32_t lkeys[];       // [col_slots][64]: sized by the ctx's slot count at launch (12 KB at the default 48 slots), so that
-                                              // LDS does not cap the resident workgroups of this latency-bound kernel
+    extern __shared__ uint32_t lds_dyn[];     // FE_SCATTER_STAGE records (12 KB), then the keys [col_slots][64]: sized by the ctx's slot count at
+                                              // launch (12 KB at the default 48 slots), so that LDS does not cap the resident workgroups
+    FeU4 *lout = reinterpret_cast<FeU4 *>(lds_dyn);
+    uint32_t *lkeys = lds_dyn + FE_SCATTER_STAGE * 8;
     const int f = blockIdx.y;
     const int W = P.k.W;
     const int lx = (int)(threadIdx.x & 63);
-    const int x = (int)(blockIdx.x * 64) + lx;
+    const int x0 = (int)(blockIdx.x * 64), x = x0 + lx;
     const uint32_t g = threadIdx.x >> 6;
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
     uint32_t off = 0, n = 0;
     if (x < W) { off = coff[x]; n = coff[x + 1] - off; }      // n = 0 for every column of a frame that did not fit
+    const uint32_t t_first = coff[x0], t_last = coff[min(x0 + 64, W)];            // wave-uniform: the workgroup's range of the output
+    const bool staged = t_last - t_first <= FE_SCATTER_STAGE;
     const FeU4 *src = P.cspans + (size_t)f * P.col_slots * (size_t)W + (size_t)x;
     for (uint32_t i = g; i < n; i += FE_SCATTER_GROUPS) lkeys[i * 64 + (uint32_t)lx] = src[(size_t)i * (size_t)W].x;
     __syncthreads();
@@ -213,9 +224,13 @@ __global__ __launch_bounds__(64 * FE_SCATTER_GROUPS) void dg_fe_scatter(FeParams
             rank += (kj < cs.x || (kj == cs.x && j < i)) ? 1u : 0u;        // the tie-break keeps the scatter a permutation
         }
         const DevRSpan r = fe_resolve(P, fr, ff, x, cs);
-        out[2 * (size_t)(off + rank)] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
-        out[2 * (size_t)(off + rank) + 1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};
+        FeU4 *to = staged ? lout + 2 * (size_t)(off - t_first + rank) : out + 2 * (size_t)(off + rank);
+        to[0] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
+        to[1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};
     }
+    if (!staged) return;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 2 * (t_last - t_first); i += 64 * FE_SCATTER_GROUPS) out[2 * (size_t)t_first + i] = lout[i];
 }
 
 }  // namespace
@@ -226,7 +241,7 @@ hipError_t launch_fe(const FeParams &P, hipStream_t stream) {
     hipLaunchKernelGGL(dg_fe_columns, grid, dim3(FE_COL_THREADS), 0, stream, P);
     if (P.max_sky_slots) hipLaunchKernelGGL(dg_fe_gaps, dim3(P.max_sky_slots, (unsigned)P.n_frames), dim3(64), 0, stream, P);
     hipLaunchKernelGGL(dg_fe_scan, dim3((unsigned)P.n_frames), dim3(FE_SCAN_THREADS), 0, stream, P);
-    hipLaunchKernelGGL(dg_fe_scatter, dim3((unsigned)((P.k.W + 63) / 64), (unsigned)P.n_frames), dim3(64 * FE_SCATTER_GROUPS), (size_t)P.col_slots * 64 * 4, stream, P);
+    hipLaunchKernelGGL(dg_fe_scatter, dim3((unsigned)((P.k.W + 63) / 64), (unsigned)P.n_frames), dim3(64 * FE_SCATTER_GROUPS), (size_t)FE_SCATTER_STAGE * 32 + (size_t)P.col_slots * 64 * 4, stream, P);
     return hipGetLastError();
 }
 
