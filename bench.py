@@ -208,15 +208,16 @@ def cgroup_cpu_quota(root: str = "/sys/fs/cgroup") -> int:
         return 0
 
 
-def default_host_threads(cgroup_root: str = "/sys/fs/cgroup") -> int:
-    """Host threads of this rank's ctx: its CPU share — the affinity mask bind_rank_cpus has set by now and the container's CPU quota
-    (the GPU boxes show 256 CPUs and allow 16 CPUs of run time per GPU: 64 threads there get the process throttled, 2560x1600 drops
-    from 133 k to 102 k frames/s) — at most 64."""
+def default_host_threads(local_world: int = 1, cgroup_root: str = "/sys/fs/cgroup") -> int:
+    """Host threads of this rank's ctx: its CPU share — the affinity mask bind_rank_cpus has set by now and this rank's part of the
+    container's CPU quota (the GPU boxes show 256 CPUs and allow 16 CPUs of run time per GPU: 64 threads there get the process
+    throttled, 2560x1600 drops from 133 k to 102 k frames/s) — at most 16, the count every number in profiles/ was measured with (more
+    do not help the condition-variable pool: 0.95 / 0.85-1.1 ms per 1 000-frame batch with 16 / 32 threads)."""
     n = len(os.sched_getaffinity(0))
     quota = cgroup_cpu_quota(cgroup_root)
     if quota > 0:
-        n = min(n, quota)
-    return max(1, min(n, 64))
+        n = min(n, max(1, quota // max(1, local_world)))
+    return max(1, min(n, 16))
 
 
 class DoomGpuBackend:
@@ -247,7 +248,7 @@ class DoomGpuBackend:
         B = a.batch
         self.n_slots = max(1, a.slots)                # (with fewer batches per step than slots, a slot holds the same batch every other step)
         fe = self.dg.DG_FE_HOST if a.front_end == "host" else self.dg.DG_FE_DEVICE
-        self.ctx = self.dg.Context(a.width, a.height, max_batch=B, slots=self.n_slots, device=self.device, host_threads=a.host_threads or default_host_threads(), front_end=fe)
+        self.ctx = self.dg.Context(a.width, a.height, max_batch=B, slots=self.n_slots, device=self.device, host_threads=a.host_threads or default_host_threads(getattr(a, "local_world", 1)), front_end=fe)
         self.ctx.upload_scene(self.scene)
         loop = np.concatenate([self.path, self.path])
         self.batch_first = [s * B % PATH_FRAMES for s in range(self.n_slots)]
@@ -266,6 +267,7 @@ def run(args, backend_factory=DoomGpuBackend):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     cpus, cpu_how = bind_rank_cpus(local_rank, local_world)           # before torch / HIP are touched
+    args.local_world = local_world                                    # (default_host_threads: this rank's part of a container CPU quota)
 
     # torch first: its bundled HIP runtime must be the one libdoomgpu.so binds to (same soname, loaded once).
     import torch

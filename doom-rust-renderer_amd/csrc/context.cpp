@@ -684,7 +684,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
     c->fk = make_consts(cfg->width, cfg->height);
     c->dk = DevConsts{c->fk.ARC, c->fk.GCFX, c->fk.CFX, c->fk.CFY, cfg->width, cfg->height};
     // Default: the process's CPU share — its affinity mask and, in a container, its cgroup CPU quota (threads beyond the quota only get
-    // the process throttled) — capped at 32 per ctx: an 8-GPU node gives each rank ~1/8 of the CPUs.
+    // the process throttled) — capped at 16 per ctx: an 8-GPU node gives each rank ~1/8 of the cores.
     int nthreads = cfg->host_threads;
     if (nthreads <= 0) {
         cpu_set_t set;
@@ -692,7 +692,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         int avail = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
         const int quota = cgroup_cpu_quota();
         if (quota > 0) avail = std::min(avail, quota);
-        nthreads = std::max(1, std::min(avail, 32));
+        nthreads = std::max(1, std::min(avail, 16));
     }
     nthreads = std::min(nthreads, 256);
     c->n_threads = nthreads;

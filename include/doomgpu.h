@@ -94,7 +94,7 @@ typedef struct dg_config {
     int32_t width, height; /* frame size (the reference's SCREEN_WIDTH/HEIGHT, src/game.rs:28-29); width % 4 == 0 */
     int32_t max_batch;     /* frames per submission */
     int32_t slots;         /* in-flight submissions (>= 1); each owns a framebuffer slab of max_batch frames */
-    int32_t host_threads;  /* list-generation threads for dg_render_views / dg_submit_views (0 = the process's CPU share: affinity mask and cgroup CPU quota, capped at 32) */
+    int32_t host_threads;  /* list-generation threads for dg_render_views / dg_submit_views (0 = the process's CPU share: affinity mask and cgroup CPU quota, capped at 16) */
     int32_t front_end;     /* DG_FE_*: where the per-column half of Segs::process_sidedef / draw_map_objects runs */
 } dg_config;
 

@@ -244,8 +244,12 @@ def test_host_threads_respect_the_container_cpu_quota(tmp_path):
     assert bench.cgroup_cpu_quota(str(tmp_path / "none")) == 0
     n_aff = len(os.sched_getaffinity(0))
     (v2 / "cpu.max").write_text("200000 100000\n")
-    assert bench.default_host_threads(str(v2)) == min(n_aff, 2)
-    assert bench.default_host_threads(str(tmp_path / "none")) == min(n_aff, 64)
+    assert bench.default_host_threads(1, str(v2)) == min(n_aff, 2)
+    assert bench.default_host_threads(1, str(tmp_path / "none")) == min(n_aff, 16)
+    (v2 / "cpu.max").write_text("12800000 100000\n")                  # an 8-GPU node's container: 128 CPUs for 8 ranks
+    assert bench.default_host_threads(8, str(v2)) == min(n_aff, 16)
+    (v2 / "cpu.max").write_text("1600000 100000\n")                   # two ranks rehearsing on the one-GPU box: 8 each
+    assert bench.default_host_threads(2, str(v2)) == min(n_aff, 8)
 
 
 def test_route_from_wad_gives_a_closed_walk(synth, campath_mod):
