@@ -106,7 +106,9 @@ private:
 
 struct Slot {
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_raster = nullptr, ev_h2d = nullptr;   // ev_setup: end of the front-end kernels = start of the raster launch
+    // timing events, attached to the dispatches themselves (kernels.hpp): first / last front-end kernel, raster launch; ev_raster is also
+    // what "the slot's kernels are done" is waited on
+    hipEvent_t ev_start = nullptr, ev_setup = nullptr, ev_rstart = nullptr, ev_raster = nullptr, ev_h2d = nullptr;
     bool raster_recorded = false;
     hipStream_t copy_stream = nullptr;   // dg_readback_async: D2H of this slot's frames while another slot's kernels run
     uint8_t *copy_out = nullptr;         // pending asynchronous readback (re-issued if the batch has to be redone)
@@ -237,6 +239,7 @@ void free_ctx(dg_ctx *c) {
         if (s.ev_start) (void)hipEventDestroy(s.ev_start);
         if (s.ev_setup) (void)hipEventDestroy(s.ev_setup);
         if (s.ev_raster) (void)hipEventDestroy(s.ev_raster);
+        if (s.ev_rstart) (void)hipEventDestroy(s.ev_rstart);
         if (s.ev_h2d) (void)hipEventDestroy(s.ev_h2d);
         if (s.copy_stream) { (void)hipStreamSynchronize(s.copy_stream); (void)hipStreamDestroy(s.copy_stream); }
         if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -455,19 +458,16 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
     hipStream_t ks = c->kstream;
     HIP_TRY(hipEventRecord(s.ev_h2d, s.stream));
     HIP_TRY(hipStreamWaitEvent(ks, s.ev_h2d, 0));
-    HIP_TRY(hipEventRecord(s.ev_start, ks));
     if (s.fe_mode) {
         std::memset(s.h_status, 0, (size_t)2 * (size_t)c->cfg.max_batch * 4);
         const size_t ev_bytes = (size_t)3 * (size_t)s.FP.n_frames * s.FP.max_sky_slots * s.FP.w64 * 8;   // all three event kinds (fe_event_words)
         if (ev_bytes) HIP_TRY(hipMemsetAsync(s.d_events, 0, ev_bytes, ks));
-        HIP_TRY(launch_fe(s.FP, ks));
+        HIP_TRY(launch_fe(s.FP, ks, s.ev_start, s.ev_setup));
         s.fe_check = true;
     } else {
-        HIP_TRY(launch_setup(s.P, s.max_spans, ks));
+        HIP_TRY(launch_setup(s.P, s.max_spans, ks, s.ev_start, s.ev_setup));
     }
-    HIP_TRY(hipEventRecord(s.ev_setup, ks));       // (one event for both: every record in the stream costs ~5 us between the kernels)
-    HIP_TRY(launch_raster(s.P, ks));
-    HIP_TRY(hipEventRecord(s.ev_raster, ks));
+    HIP_TRY(launch_raster(s.P, ks, s.ev_rstart, s.ev_raster));
     s.raster_recorded = true;
     s.busy = true; s.timed = true;
     return DG_OK;
@@ -747,6 +747,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         CTX_TRY(hipEventCreate(&s.ev_start));
         CTX_TRY(hipEventCreate(&s.ev_setup));
         CTX_TRY(hipEventCreate(&s.ev_raster));
+        CTX_TRY(hipEventCreate(&s.ev_rstart));
         CTX_TRY(hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming));
         CTX_TRY(hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking));
         CTX_TRY(hipHostMalloc((void **)&s.h_lists, lists_cap, hipHostMallocDefault));
@@ -1012,7 +1013,7 @@ int dg_slot_timing(dg_ctx *c, int slot, dg_timing *out) {
     }
     std::memset(out, 0, sizeof *out);
     HIP_TRY(hipEventElapsedTime(&out->setup_ms, s.ev_start, s.ev_setup));
-    HIP_TRY(hipEventElapsedTime(&out->raster_ms, s.ev_setup, s.ev_raster));
+    HIP_TRY(hipEventElapsedTime(&out->raster_ms, s.ev_rstart, s.ev_raster));
     HIP_TRY(hipEventElapsedTime(&out->total_ms, s.ev_start, s.ev_raster));
     out->n_spans = s.n_spans; out->n_frames = (uint64_t)s.n_frames; out->covered_pixels = s.covered;
     out->host_ms = s.host_ms; out->list_bytes = s.list_bytes;

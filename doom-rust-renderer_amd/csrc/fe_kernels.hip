@@ -15,6 +15,7 @@
 //
 // Integer / f32 work only — nothing here is GEMM shaped.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "fe_core.h"
 #include "fe_kernels.hpp"
@@ -235,13 +236,19 @@ __global__ __launch_bounds__(64 * FE_SCATTER_GROUPS) void dg_fe_scatter(FeParams
 
 }  // namespace
 
-hipError_t launch_fe(const FeParams &P, hipStream_t stream) {
-    if (P.n_frames <= 0) return hipSuccess;
+hipError_t launch_fe(const FeParams &P, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+    if (P.n_frames <= 0) {
+        hipError_t e = hipSuccess;
+        if (start) e = hipEventRecord(start, stream);
+        if (e == hipSuccess && stop) e = hipEventRecord(stop, stream);
+        return e;
+    }
     dim3 grid((unsigned)((P.k.W + FE_COL_THREADS - 1) / FE_COL_THREADS), (unsigned)P.n_frames);
-    hipLaunchKernelGGL(dg_fe_columns, grid, dim3(FE_COL_THREADS), 0, stream, P);
+    hipExtLaunchKernelGGL(dg_fe_columns, grid, dim3(FE_COL_THREADS), 0, stream, start, nullptr, 0, P);
     if (P.max_sky_slots) hipLaunchKernelGGL(dg_fe_gaps, dim3(P.max_sky_slots, (unsigned)P.n_frames), dim3(64), 0, stream, P);
     hipLaunchKernelGGL(dg_fe_scan, dim3((unsigned)P.n_frames), dim3(FE_SCAN_THREADS), 0, stream, P);
-    hipLaunchKernelGGL(dg_fe_scatter, dim3((unsigned)((P.k.W + 63) / 64), (unsigned)P.n_frames), dim3(64 * FE_SCATTER_GROUPS), (size_t)FE_SCATTER_STAGE * 32 + (size_t)P.col_slots * 64 * 4, stream, P);
+    hipExtLaunchKernelGGL(dg_fe_scatter, dim3((unsigned)((P.k.W + 63) / 64), (unsigned)P.n_frames), dim3(64 * FE_SCATTER_GROUPS),
+                          (uint32_t)((size_t)FE_SCATTER_STAGE * 32 + (size_t)P.col_slots * 64 * 4), stream, nullptr, stop, 0, P);
     return hipGetLastError();
 }
 

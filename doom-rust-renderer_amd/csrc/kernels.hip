@@ -26,6 +26,7 @@
 // Experiment builds (make variant VARIANT=x EXTRA="-D..."; never defined in the product build; results in profiles/r02_*.md):
 //   DG_EXP_T_LDSPAD=bytes   pad the tile kernel's LDS (occupancy experiment)      DG_EXP_T_TIMING   per-wave s_memtime phase probe (device printf)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -596,10 +597,18 @@ hipError_t launch_row_table(const DevScene &scene, const DevConsts &k, uint4 *ro
     return hipGetLastError();
 }
 
-hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hipStream_t stream) {
-    if (P.n_frames <= 0 || max_spans_per_frame == 0) return hipSuccess;
+// Nothing to launch: the events still have to be recorded for whoever waits on them or reads their times.
+static hipError_t record_pair(hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+    hipError_t e = hipSuccess;
+    if (start) e = hipEventRecord(start, stream);
+    if (e == hipSuccess && stop) e = hipEventRecord(stop, stream);
+    return e;
+}
+
+hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+    if (P.n_frames <= 0 || max_spans_per_frame == 0) return record_pair(stream, start, stop);
     dim3 grid((max_spans_per_frame + 255) / 256, (unsigned)P.n_frames);
-    hipLaunchKernelGGL(dg_setup_spans, grid, dim3(256), 0, stream, P);
+    hipExtLaunchKernelGGL(dg_setup_spans, grid, dim3(256), 0, stream, start, stop, 0, P);
     return hipGetLastError();
 }
 
@@ -610,13 +619,13 @@ int raster_tile_rows_per_wg(int H) {
     return std::min(n_tile_rows >= 8 ? 3 : 2, n_tile_rows);
 }
 
-hipError_t launch_raster(const RasterParams &P_in, hipStream_t stream) {
-    if (P_in.n_frames <= 0) return hipSuccess;
+hipError_t launch_raster(const RasterParams &P_in, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+    if (P_in.n_frames <= 0) return record_pair(stream, start, stop);
     RasterParams P = P_in;
     const int n_tile_rows = (P.k.H + TILE_H - 1) / TILE_H;
     if (P.tile_rows_per_wg <= 0) P.tile_rows_per_wg = raster_tile_rows_per_wg(P.k.H);
     dim3 grid((unsigned)((P.k.W + TILE_W - 1) / TILE_W), (unsigned)((n_tile_rows + P.tile_rows_per_wg - 1) / P.tile_rows_per_wg), (unsigned)P.n_frames);
-    hipLaunchKernelGGL(dg_raster_tiles, grid, dim3(THREADS), 0, stream, P);
+    hipExtLaunchKernelGGL(dg_raster_tiles, grid, dim3(THREADS), 0, stream, start, stop, 0, P);
     return hipGetLastError();
 }
 

@@ -22,9 +22,11 @@ struct RasterParams {
     int32_t tile_rows_per_wg;    // tile rows one workgroup of dg_raster_tiles renders out of one staging pass; <= 0: launch_raster picks
 };
 
-hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hipStream_t stream);
+// (start / stop: optional timing events attached to the dispatch itself — hipExtLaunchKernelGGL — instead of recorded around it: an event
+// record is a packet of its own in the stream and costs ~5 us between two kernels)
+hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // dg_raster_tiles over every (frame, 64 x 64 tile).
-hipError_t launch_raster(const RasterParams &P, hipStream_t stream);
+hipError_t launch_raster(const RasterParams &P, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // out[k] = checksum (include/doomgpu.h: dg_frame_checksums) of frame k of `count` consecutive frames of `frame_bytes` bytes at fb; out must be zeroed.
 hipError_t launch_checksums(const uint8_t *fb, size_t frame_bytes, int count, unsigned long long *out, hipStream_t stream);
 // Fills row_tab[0 .. H) for the given scene / frame size (once per dg_upload_scene).

@@ -217,7 +217,8 @@ int dg_build_lists(const dg_scene *s, int width, int height, const dg_view *view
 const char *dg_last_error(void); /* thread-local message of the last failing call */
 const char *dg_version(void);
 
-/* Timing of the last dg_replay_slot / submit on a slot, from HIP events on the ctx's kernel stream (ms). */
+/* Timing of the last dg_replay_slot / submit on a slot (ms), from HIP events attached to the kernel dispatches themselves on the ctx's
+ * kernel stream: setup_ms = start of the first front-end kernel .. end of the last, raster_ms = the raster launch, total_ms = both. */
 typedef struct dg_timing {
     float setup_ms, raster_ms, total_ms;
     float host_ms;            /* host list generation + binning + packing of that submission (wall clock) */
