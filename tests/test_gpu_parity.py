@@ -189,6 +189,29 @@ def test_batch_slot_and_replay_independence(dg, scene1993, path1993):
     ctx.close()
 
 
+@pytest.mark.parametrize("front_end", [1, 2], ids=["host-lists", "device-column-walk"])
+def test_timing_events_ride_on_the_dispatches(dg, scene1993, path1993, front_end):
+    """dg_timing reads events attached to the kernel dispatches on the ctx's one kernel stream: the front-end kernels' span, the raster
+    launch, and both.  Two slots submitted back to back (slot 1 is queued behind slot 0 on that stream): each slot's own times are
+    positive, the whole is at least the sum of its parts, and waiting for slot 1 does not need slot 0 to be waited for first."""
+    W, H = 640, 400
+    ctx = make_ctx(dg, scene1993, W, H, 64, slots=2, front_end=front_end)
+    ctx.submit(0, dg.make_views(path1993[0:64]))
+    ctx.submit(1, dg.make_views(path1993[64:128]))
+    ctx.wait(1)
+    ctx.wait(0)
+    for s in (0, 1):
+        t = ctx.timing(s)
+        assert t["n_frames"] == 64 and t["front_end"] == front_end
+        assert 0.0 < t["setup_ms"] < 50.0 and 0.0 < t["raster_ms"] < 50.0, t
+        assert t["total_ms"] >= t["setup_ms"] + t["raster_ms"] - 1e-3, t
+    a = ctx.readback(1, 0, 64)
+    ctx.replay(1); ctx.wait(1)                       # the same slot again: the events are re-used
+    t = ctx.timing(1)
+    assert 0.0 < t["raster_ms"] < 50.0 and np.array_equal(ctx.readback(1, 0, 64), a)
+    ctx.close()
+
+
 def test_checksum_of_checksums_1280x800(dg, scene1993, oracle_scene1993, path1993):
     """BASELINE config 2 (bench size): every 10th frame of the path at 1280x800 against the oracle, plus a digest over
     the whole 1 000-frame run that must be reproducible between two passes (different batch splits)."""
