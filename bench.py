@@ -346,10 +346,14 @@ def run(args, backend_factory=DoomGpuBackend):
         stats.update(t)
 
     t0 = time.perf_counter()
+    step_end = []
     for _ in range(args.steps):
         one_pass(collect)
+        step_end.append(time.perf_counter())          # (a submission blocks while its slot is busy: in steady state this is the GPU's pace)
     sync_all()
     elapsed_local = time.perf_counter() - t0
+    step_end[-1] = t0 + elapsed_local                 # the last step ends when the pipeline has drained
+    step_ms = [1e3 * (b - a) for a, b in zip([t0] + step_end[:-1], step_end)]
     barrier()
     sync_all()
     for s in range(n_slots):
@@ -398,6 +402,14 @@ def run(args, backend_factory=DoomGpuBackend):
     if not args.no_host_frames and hasattr(ctx, "readback_async"):
         e2e_host = host_frames_rate(args, be, ctx, n_slots, views, B, batches_per_step, barrier, dist, world)
 
+    # ---- the drop-in call shape: ONE view per call, synchronously, into caller memory (rank 0, N = 1 only) ------------
+    latency = None
+    if rank == 0 and world == 1 and not args.no_latency and hasattr(ctx, "render_one_into"):
+        try:
+            latency = single_frame_latency(args, be, device, np)
+        except Exception as e:                            # a side measurement must not take the headline line down with it
+            latency = {"error": repr(e)}
+
     # ---- roofline of the rasteriser --------------------------------------------------------------------------------
     mean_raster_s = float(np.mean(raster_ms)) / 1e3
     achieved = float(np.mean(alg_bytes)) / mean_raster_s / 1e9
@@ -433,6 +445,9 @@ def run(args, backend_factory=DoomGpuBackend):
         line = {
             "metric": "frames/sec (fixed e1m1 camera path)", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            # spread over the K timed steps (rank 0's host clock after each step's submissions; the first step starts from an empty
+            # pipeline — its host work is exposed —, the last one ends with the drain; value / ms_per_step above are the contract's K-step mean)
+            "ms_per_step_median": float(np.median(step_ms)), "ms_per_step_min": float(np.min(step_ms)), "ms_per_step_max": float(np.max(step_ms)),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "file" if args.wad else "synthetic",
             "config": {"workload": f"BASELINE {CONFIGS[args.config][0]}; " +
                                    (f"{os.path.basename(args.wad)} {args.map}" if args.wad else
@@ -443,7 +458,7 @@ def run(args, backend_factory=DoomGpuBackend):
                        "front_end": fe_name, "width": W, "height": H, "frames_per_step": frames_per_step, "frames_per_batch": B, "slots": n_slots,
                        "parallelism": f"{world} independent camera path(s) (seeds 1993..{1993 + world - 1}), one per GPU, maps alternating over the ranks "
                                       f"{[m for (m, _) in CONFIGS[args.config][4]]}, no collective"},
-            "roofline": roofline, "cpu_baseline": cpu, "resident_replay": resident, "e2e_host_frames": e2e_host,
+            "roofline": roofline, "cpu_baseline": cpu, "resident_replay": resident, "e2e_host_frames": e2e_host, "latency": latency,
             "host": {"ms_per_batch": float(np.mean(host_ms)), "threads": getattr(ctx, "host_threads", None),
                      "list_bytes_per_frame": int(stats.get("list_bytes", 0) // max(1, stats.get("n_frames", 1)))},
             "fallbacks": fallbacks, "per_rank": reports,
@@ -515,6 +530,56 @@ def cpu_baseline(args, be, ctx, n_slots, np):
     return cpu
 
 
+def single_frame_latency(args, be, device, np):
+    """What the reference's game loop does per displayed frame (src/game.rs:505-525): `Pixels::new()`, `Renderer::new(..).render()`, then
+    `pixels.pixels` is in host memory — here dg_render_views(ctx, &view, 1, host_ptr) on a max_batch = 1 context (rust/src/gpu.rs
+    GpuRenderer::render), one call per frame of the 1 000-frame path, at the reference's native 1024x768 (src/game.rs:28-29) and at the
+    headline size.  Wall-clock per call: host records for one view, H2D, all kernels, D2H of the RGB24 frame, every wait.  The oracle's
+    time per frame (one core) on a sample of the same views stands beside it.  Never `value`."""
+    dg = be.dg
+    doomref = be.oracle()
+    osc = doomref.Scene(be.wad, args.map)
+    out = {"call": "dg_render_views(ctx, &view, 1, host_ptr), max_batch 1, synchronous", "frames": PATH_FRAMES, "sizes": {}}
+    for (W, H) in ((1024, 768), (args.width, args.height)) if (args.width, args.height) != (1024, 768) else ((1024, 768),):
+        ctx1 = dg.Context(W, H, max_batch=1, slots=1, device=device, host_threads=1)
+        try:
+            ctx1.upload_scene(be.scene)
+            views = dg.make_views(be.path)
+            nbytes = 3 * W * H
+            res = {}
+            pinned = dg.lib().dg_alloc_host(nbytes)
+            pageable = np.empty(nbytes, dtype=np.uint8)
+            try:
+                for name, ptr in (("pinned", pinned), ("pageable", pageable.ctypes.data)):
+                    if not ptr:
+                        continue
+                    for i in range(8):                                    # untimed: first touches of the target and of the ctx's paths
+                        ctx1.render_one_into(views[i], ptr)
+                    dts = np.empty(PATH_FRAMES)
+                    for i in range(PATH_FRAMES):
+                        ta = time.perf_counter()
+                        ctx1.render_one_into(views[i], ptr)
+                        dts[i] = time.perf_counter() - ta
+                    res[name] = {"median_ms": float(np.median(dts) * 1e3), "p99_ms": float(np.percentile(dts, 99) * 1e3), "mean_ms": float(dts.mean() * 1e3),
+                                 "frames_per_s": float(PATH_FRAMES / dts.sum())}
+                # the last frame of the pageable run against the oracle, byte for byte
+                ref = np.frombuffer(osc.render(W, H, be.path[PATH_FRAMES - 1]), dtype=np.uint8)
+                res["last_frame_bit_exact"] = bool(np.array_equal(pageable, ref))
+            finally:
+                if pinned:
+                    dg.lib().dg_free_host(pinned)
+            idx = list(range(0, PATH_FRAMES, 50))
+            tc = time.perf_counter()
+            for i in idx:
+                osc.render(W, H, be.path[i])
+            res["cpu_oracle_ms_per_frame"] = (time.perf_counter() - tc) / len(idx) * 1e3
+            res["cpu_oracle_sample"] = f"every 50th frame of the same path ({len(idx)} frames), oracle/doomref.c on 1 core"
+            out["sizes"][f"{W}x{H}"] = res
+        finally:
+            ctx1.close()
+    return out
+
+
 def host_frames_rate(args, be, ctx, n_slots, views, B, batches_per_step, barrier, dist, world):
     """Every frame to page-locked host memory, D2H of batch i overlapped with the kernels of batch i + 1."""
     dg = be.dg
@@ -572,6 +637,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resident", action="store_true")
     ap.add_argument("--no-host-frames", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the one-view-per-call latency leg (`latency` in the JSON line)")
+    ap.add_argument("--latency", action="store_true", help="(default) measure the one-view-per-call latency leg at 1024x768 and the bench size")
     a = ap.parse_args(argv)
     _, cw, ch, cb, _, _ = CONFIGS[a.config]
     a.width = a.width or cw

@@ -260,6 +260,11 @@ class Context:
         _check(lib().dg_render_views(self._h, views, n, out.ctypes.data_as(_P)))
         return out
 
+    def render_one_into(self, view: DgView, host_ptr: int):
+        """`Renderer::new(..).render()` for ONE view, synchronously, RGB24 written to caller memory (the drop-in call shape:
+        rust/src/gpu.rs GpuRenderer::render)."""
+        _check(lib().dg_render_views(self._h, ctypes.byref(view), 1, _P(host_ptr)))
+
     def submit(self, slot: int, views, n=None, states=None):
         if states is None:
             _check(lib().dg_submit_views(self._h, slot, views, len(views) if n is None else n))

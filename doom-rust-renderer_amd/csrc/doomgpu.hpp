@@ -30,6 +30,10 @@ inline void check(int rc) { if (rc < 0) throw Error(rc, dg_last_error()); }
 struct Color { uint8_t r, g, b, a; };            // sdl2::pixels::Color as the reference uses it
 struct Vertex { float x, y; };                   // src/map/vertexes.rs:9-13
 struct Player { Vertex position; float floor_height; float angle; };   // src/game.rs:40-45
+// What the renderer reads of the game state that thinkers mutate between frames:
+struct Sector { int16_t light_level; };                                                          // src/map/sectors.rs:8-17 (src/lights.rs:47-259 writes it)
+struct State { const char *sprite; uint8_t frame; bool full_bright; bool is_null; };             // src/info.rs:1265-1273; sprite = "{:?}" of SpriteId; is_null: StateId::S_NULL
+struct MapObject { State state; };                                                               // src/map_objects.rs:10-17 (MapObjectThinker :63-121 writes it)
 
 // src/renderer/pixels.rs:5-47 with the frame size a run-time value (the reference's SCREEN_WIDTH/HEIGHT constants).
 class Pixels {
@@ -66,11 +70,26 @@ public:
         dg_scene_floor_height_at(h_, p.position.x, p.position.y, &p.floor_height);
         return p;
     }
+    int sector_count() const { return dg_scene_sector_count(h_); }       // = map.sectors.len()
+    int mobj_count() const { return dg_scene_mobj_count(h_); }           // = map_objects.objects.len()
+    // Game::new, BEFORE Device::upload: decode a (sprite, frame) a later state may show (Sprites::new loads every sprite lump eagerly,
+    // src/graphics/sprites.rs:26-97).  false: the WAD has no such sprite.
+    bool preload_sprite_frame(const char *sprite, uint8_t frame) { return dg_scene_sprite_frame(h_, sprite, frame) >= 0; }
     bool sector_floor_height(const Vertex &v, float &out) const { return dg_scene_floor_height_at(h_, v.x, v.y, &out) == 0; }  // bsp.rs:9-44
     dg_scene *handle() const { return h_; }
 private:
     dg_scene *h_ = nullptr;
 };
+
+// Game::render, before Renderer(..).render(): the light levels and map-object states of this tick (rust/src/gpu.rs sync_state).
+// Index = position in `map.sectors` / `map_objects.objects`.
+inline void sync_state(World &world, const std::vector<Sector> &sectors, const std::vector<MapObject> &objects) {
+    for (size_t i = 0; i < sectors.size(); i++) check(dg_scene_set_sector_light(world.handle(), (int)i, sectors[i].light_level));
+    for (size_t i = 0; i < objects.size(); i++) {
+        const State &st = objects[i].state;
+        check(dg_scene_set_mobj_state(world.handle(), (int)i, st.is_null ? nullptr : st.sprite, st.frame, st.full_bright ? 1 : 0));
+    }
+}
 
 // One GPU.  Not in the reference (it has no device); plays the role of the borrowed `&mut Pixels` target's backing store.
 class Device {

@@ -362,10 +362,17 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
     __syncthreads();
     DG_PHASE(1)
 
+#ifdef DG_EXP_RTPREFETCH
+  uint4 rt_next = P.row_tab[min(ty_begin * TILE_H + lane, H - 1)];
+#endif
   for (int ty = ty_begin; ty < ty_end; ty++) {
     const int y0 = ty * TILE_H;
     const int y = y0 + lane;
+#ifdef DG_EXP_RTPREFETCH
+    const uint4 rt = rt_next;
+#else
     const uint4 rt = P.row_tab[y < H ? y : H - 1];                    // dg_row_table
+#endif
     // A tile with at most 8 live rows (the last tile row of a 200-row frame): a wave can take all eight of its columns in ONE pass,
     // lane = (column, row) = (lane >> 3, lane & 7).  Its row constants:
     const bool few_rows = H - y0 <= PACK_ROWS;
@@ -462,13 +469,20 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
                 const uint32_t off = bcast(v_off, __builtin_ctzll(mu));
                 const uint4 a = span_at(L.lspans, off)[0], b = span_at(L.lspans, off)[1];   // same address in every lane: LDS broadcast
                 uint32_t o;
+#ifdef DG_ABL_NOSOLEMAP
+                o = a.z + (uint32_t)lane; C.factor = bits_f32(a.w);
+#else
                 if (ucol_wall & mu) { o = wall_offset_plain(a, b, R.y); C.factor = bits_f32(a.w); }
                 else o = flat_offset_plain(fr, a, b, R, C.factor);
+#endif
                 C.winner = off;                                     // (stage 2 lays later possibly-transparent spans on top)
                 C.tex = P.scene.texel_idx[o];
                 DG_PHASE(3)
                 return;
             }
+#ifdef DG_ABL_NOGENERAL
+            C.tex = 0; C.winner = 0; C.factor = 0.0f; return;
+#endif
             if (big & colmask) {
                 const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
                 C.winner = big_column_owner(L.lw0 + n0, 32u * (n0 + 1u), n, lane, y0, R);
@@ -484,7 +498,11 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
             uint32_t tex = C.tex;
             float factor = C.factor;
             DG_PHASE(4)
+#ifdef DG_ABL_NOOVL
+            if (false) {
+#else
             if (walk2 & colmask) {                                   // possibly-transparent spans on top, in draw order
+#endif
                 if (big & colmask) {
                     const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
                     big_column_overlays(P, L.lw0 + n0, L.lspans, 32u * (n0 + 1u), n, lane, y0, R, C.winner, tex, factor);
@@ -493,7 +511,11 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
                     overlay_loop(P, L.lspans, hit_ov & colmask, hit_ovwall, v_lo, v_rg, v_off, R, C.winner, tex, factor);
                 }
             }
+#ifdef DG_ABL_NOSHADE
+            const uint32_t px = tex + f32_bits(factor);
+#else
             const uint32_t px = shade_f(L.pal[tex], factor);         // palette x light, `as u8` (bitmap_render.rs:202-207), once per pixel
+#endif
             L.tile[(c_lo + wave + WAVES * k) * TILE_TS + lane] = px;
             DG_PHASE(5)
         };
@@ -521,6 +543,9 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         if (c_lo < TILE_W) __syncthreads();   // before the staging area is reused
     }
     DG_PHASE(2)
+#ifdef DG_EXP_RTPREFETCH
+    rt_next = P.row_tab[min(y + TILE_H, H - 1)];                      // the next tile's row constants travel under the barrier and the read-out
+#endif
     __syncthreads();
     DG_PHASE(6)
 
@@ -528,7 +553,11 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
     // 4 rows x 16 groups in an order that is conflict-free in LDS; 8 adjacent lanes write 96 contiguous bytes.
     const int gc = (lane & 7) | ((lane >> 5) << 3), rsub = (lane >> 3) & 3;
 #pragma unroll
+#ifdef DG_ABL_NOREADOUT
+    for (int pass = 0; pass < 0; pass++) {
+#else
     for (int pass = 0; pass < TILE_H / (4 * WAVES); pass++) {
+#endif
         const int row = pass * 4 * WAVES + wave * 4 + rsub;
         const int yy = y0 + row, xx = x0 + 4 * gc;
         if (yy < H && xx < W) {   // W % 4 == 0 (checked at dg_create), so a group never straddles the right edge
@@ -616,6 +645,9 @@ hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hip
 // 0.562 / 0.593 / 0.669 ms per 250 frames; at 320x200 (4 tile rows) 2 rows win (profiles/r03_raster_tiles.md).
 int raster_tile_rows_per_wg(int H) {
     const int n_tile_rows = (H + TILE_H - 1) / TILE_H;
+#ifdef DG_EXP_TILE_ROWS
+    return std::min(DG_EXP_TILE_ROWS, n_tile_rows);
+#endif
     return std::min(n_tile_rows >= 8 ? 3 : 2, n_tile_rows);
 }
 

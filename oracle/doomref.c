@@ -341,7 +341,7 @@ static Flat *get_flat_animated(dr_scene *s, const char *name, float timestamp) {
 /* thing type -> spawn state (sprite, frame, full_bright): map_objects.rs:25-50 + info.rs tables */
 typedef struct { int16_t id; const char *sprite; uint8_t frame; uint8_t full_bright; uint8_t is_null; } SpawnRow;
 static const SpawnRow SPAWN_TABLE[] = {
-#include "../data/mobj_spawn_table.inc"
+#include "mobj_spawn_oracle.inc"   /* the oracle's own copy (tools/extract_mobj_table_oracle.py), not the product's data/mobj_spawn_table.inc */
 };
 
 /* Sprites::new restricted to one (sprite, frame): graphics/sprites.rs:26-97 */

@@ -52,6 +52,9 @@ extern "C" {
     pub fn dg_scene_texture_id(s: *const dg_scene, name: *const c_char) -> c_int;
     pub fn dg_scene_flat_id(s: *const dg_scene, name: *const c_char, timestamp: f32) -> c_int;
     pub fn dg_scene_sprite_bitmap_id(s: *const dg_scene, sprite: *const c_char, frame: u8, rotation: u8) -> c_int;
+    pub fn dg_scene_sprite_frame(s: *mut dg_scene, sprite: *const c_char, frame: u8) -> c_int;
+    pub fn dg_scene_sector_count(s: *const dg_scene) -> c_int;
+    pub fn dg_scene_mobj_count(s: *const dg_scene) -> c_int;
     pub fn dg_create(cfg: *const dg_config, out: *mut *mut dg_ctx) -> c_int;
     pub fn dg_destroy(ctx: *mut dg_ctx);
     pub fn dg_upload_scene(ctx: *mut dg_ctx, scene: *const dg_scene) -> c_int;
@@ -78,13 +81,47 @@ impl<'a> GpuRenderer<'a> {
     }
 }
 
+// ---- live game state: what the thinkers changed since the last frame ------------------------------------------------------------
+// The renderer reads `sector.light_level` (src/renderer/segs.rs:450-455 via the sector, mutated by src/lights.rs:47-259) and
+// `map_object.state` (src/renderer/map_objects.rs:34-70, mutated by MapObjectThinker, src/map_objects.rs:63-121) every frame.  The
+// library keeps its own copy of both inside dg_scene; sync_state() copies the game's current values into it.  Indices are positions
+// in `map.sectors` / `map_objects.objects`, which is how doom-rust-renderer_amd/csrc/scene.cpp numbers them (sectors in lump order,
+// src/map/sectors.rs:20-41; map objects = THINGS minus the player / deathmatch starts, src/map_objects.rs:25-50).
+
+/// `Game::new`, BEFORE dg_upload_scene: decode every (sprite, frame) a state can show — what `Sprites::new` does eagerly
+/// (src/graphics/sprites.rs:26-97) — so that no later `sync_state` meets a bitmap the GPU does not hold.  Sprites the WAD lacks
+/// (shareware IWADs) are skipped exactly like `Sprites::get_picture` would only fail when such a state is drawn.
+pub fn preload_sprite_frames(scene: *mut dg_scene) {
+    for st in crate::info::STATES.iter() {
+        let name = CString::new(format!("{:?}", st.sprite)).unwrap();          // the lump prefix Sprites::new matches on (sprites.rs:30)
+        unsafe { dg_scene_sprite_frame(scene, name.as_ptr(), st.frame) };     // < 0: not in this WAD
+    }
+}
+
+/// `Game::render`, before `GpuRenderer::new(..).render()`: push the light levels and map-object states of this tick.
+pub fn sync_state(scene: *mut dg_scene, map: &crate::map::Map, map_objects: &crate::map_objects::MapObjects) {
+    for (i, sector) in map.sectors.iter().enumerate() {
+        let rc = unsafe { dg_scene_set_sector_light(scene, i as c_int, sector.borrow().light_level) };
+        if rc != 0 { panic!("doomgpu: {}", unsafe { CStr::from_ptr(dg_last_error()) }.to_string_lossy()); }
+    }
+    for (i, object) in map_objects.objects.iter().enumerate() {
+        let o = object.borrow();
+        let rc = if o.state.id == crate::info::StateId::S_NULL {               // not drawn (renderer/map_objects.rs:37)
+            unsafe { dg_scene_set_mobj_state(scene, i as c_int, std::ptr::null(), 0, 0) }
+        } else {
+            let name = CString::new(format!("{:?}", o.state.sprite)).unwrap();
+            unsafe { dg_scene_set_mobj_state(scene, i as c_int, name.as_ptr(), o.state.frame, o.state.full_bright as c_int) }
+        };
+        if rc != 0 { panic!("doomgpu: {}", unsafe { CStr::from_ptr(dg_last_error()) }.to_string_lossy()); }
+    }
+}
+
 // ---- per-view game state (include/doomgpu.h dg_view_state): what the thinkers changed before a frame ------------------
 #[repr(C)] #[derive(Clone, Copy)] pub struct dg_sector_light { pub sector: i32, pub light_level: i32 }
 #[repr(C)] #[derive(Clone, Copy)] pub struct dg_mobj_state { pub mobj: i32, pub sprite_frame: i32, pub full_bright: i32, pub reserved: i32 }
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct dg_view_state { pub lights: *const dg_sector_light, pub n_lights: u32, pub mobjs: *const dg_mobj_state, pub n_mobjs: u32 }
 extern "C" {
-    pub fn dg_scene_sprite_frame(s: *mut dg_scene, sprite: *const c_char, frame: u8) -> c_int;
     pub fn dg_render_views_state(ctx: *mut dg_ctx, views: *const dg_view, states: *const dg_view_state, n: c_int, rgb24_out: *mut u8) -> c_int;
     pub fn dg_submit_views_state(ctx: *mut dg_ctx, slot: c_int, views: *const dg_view, states: *const dg_view_state, n: c_int) -> c_int;
     pub fn dg_wait(ctx: *mut dg_ctx, slot: c_int) -> c_int;

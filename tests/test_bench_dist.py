@@ -113,6 +113,8 @@ def test_two_rank_gloo_bench_run():
     # value = frames of all ranks / the SLOWER rank's time (rank 1 sleeps 4 ms per batch: 12 batches >= 48 ms)
     assert line["value"] <= 2 * 3 * 1000 / 0.048
     assert line["value"] == pytest.approx(2 * 3 * 1000 / (line["ms_per_step"] * 3 / 1e3))
+    assert 0 < line["ms_per_step_min"] <= line["ms_per_step_median"] <= line["ms_per_step_max"]      # the spread over the timed steps
+    assert line["ms_per_step_min"] >= 4 * 2.0 * 0.9 and line["latency"] is None                      # rank 0: 4 batches x 2 ms; no latency leg at N > 1
     per = line["per_rank"]
     assert [p["rank"] for p in per] == [0, 1]
     assert [(p["map_seed"], p["path_seed"]) for p in per] == [(1993, 1993), (1994, 1994)] == [(r[3], r[4]) for r in res]

@@ -83,3 +83,21 @@ def test_diminish_color_sweep_matches_numpy(oracle):
         dist = int(rng.integers(-32768, 32768))
         oracle.lib().dr_diminish_color(bytes(rgb), light, dist, out)
         assert tuple(out.raw) == np_diminish(rgb, light, dist)[0]
+
+
+def test_spawn_tables_agree():
+    """The thing type -> spawn state table exists twice, derived by two scripts that share no code: the product's
+    (data/mobj_spawn_table.inc <- data/mobj_spawn.tsv <- tools/extract_mobj_table.py: states matched by name) and the oracle's
+    (oracle/mobj_spawn_oracle.inc <- tools/extract_mobj_table_oracle.py: `STATES[spawn_state as usize]` by enum ordinal, as
+    src/map_objects.rs:25-59 executes it).  A slip in one of them cannot hide in both sides of the parity tests: the rows must agree."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    row = re.compile(r'\{(-?\d+), "(\w+)", (\d+), (\d+), (\d+)\},')
+    prod = row.findall(open(os.path.join(root, "data", "mobj_spawn_table.inc")).read())
+    orac = row.findall(open(os.path.join(root, "oracle", "mobj_spawn_oracle.inc")).read())
+    tsv = [tuple(l.split("\t")) for l in open(os.path.join(root, "data", "mobj_spawn.tsv")).read().splitlines() if l and not l.startswith("#")]
+    assert len(prod) == len(orac) == len(tsv) > 100
+    assert prod == orac == [tuple(t) for t in tsv]
+    assert "mobj_spawn_oracle.inc" in open(os.path.join(root, "oracle", "doomref.c")).read()
+    assert "data/mobj_spawn_table.inc" not in open(os.path.join(root, "oracle", "Makefile")).read()

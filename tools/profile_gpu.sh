@@ -5,8 +5,8 @@
 set -o pipefail
 TAG=${1:-r01}
 shift
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r03/prof_$TAG
-BENCH="python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-resident --no-host-frames $*"
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r04/prof_$TAG
+BENCH="python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-resident --no-host-frames --no-latency $*"
 export TMPDIR=/tmp
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 && echo trace ok

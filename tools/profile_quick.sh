@@ -2,7 +2,7 @@
 # Quick counter passes for the raster kernel (see profile_gpu.sh for the full recipe).
 TAG=${1:-q}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-BENCH="python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-resident --no-host-frames"
+BENCH="python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-resident --no-host-frames --no-latency"
 export TMPDIR=/tmp
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 && echo trace ok
