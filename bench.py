@@ -93,9 +93,17 @@ def rank_plan(rank: int, world: int, config: int = 3):
     return maps[rank % len(maps)], 1993 + rank
 
 
-def pick_device(local_rank: int, visible: int) -> int:
-    """HIP ordinal of a rank: LOCAL_RANK, wrapped when the launcher masked the GPUs per rank (HIP_VISIBLE_DEVICES = one GPU each)."""
-    return local_rank % visible if visible > 0 else local_rank
+def pick_device(local_rank: int, visible: int, local_world: int = 0) -> int:
+    """HIP ordinal of a rank: LOCAL_RANK; 0 when the launcher masked the GPUs per rank (HIP_VISIBLE_DEVICES = one GPU each, so every
+    rank sees exactly one).  More local ranks than visible GPUs otherwise is an error: two ranks would share a GPU silently and the
+    weak-scaling `value` would still be summed as if each had its own (DOOMGPU_BENCH_DEVICE overrides this to rehearse on one GPU)."""
+    if visible <= 0:
+        return local_rank                 # no GPU visible (CPU rehearsal): unchanged, dg_create reports it
+    if visible == 1:
+        return 0
+    if local_rank >= visible or local_world > visible:
+        raise SystemExit(f"bench.py: {max(local_world, local_rank + 1)} local ranks but only {visible} visible GPUs: one GPU per rank is the contract")
+    return local_rank
 
 
 def aggregate_fps(frames_per_rank: int, world: int, max_seconds: float) -> float:
@@ -272,7 +280,7 @@ def run(args, backend_factory=DoomGpuBackend):
     # torch first: its bundled HIP runtime must be the one libdoomgpu.so binds to (same soname, loaded once).
     import torch
     visible = torch.cuda.device_count()                               # counting devices does not initialise HIP on this image
-    device = int(os.environ.get("DOOMGPU_BENCH_DEVICE", pick_device(local_rank, visible)))   # override only to rehearse N > 1 on a 1-GPU box
+    device = int(os.environ["DOOMGPU_BENCH_DEVICE"]) if "DOOMGPU_BENCH_DEVICE" in os.environ else pick_device(local_rank, visible, local_world)   # override only to rehearse N > 1 on a 1-GPU box
     print(f"[bench rank {rank}/{world}] local_rank {local_rank}, {visible} visible GPU(s) -> device {device}; {len(cpus)} CPUs ({cpu_how})", file=sys.stderr, flush=True)
     dist = None
     if world > 1:

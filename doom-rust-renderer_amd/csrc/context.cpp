@@ -131,6 +131,8 @@ struct Slot {
     uint32_t *d_fe_coloff = nullptr;
     uint32_t *h_status = nullptr;               // pinned host memory the walk's kernels write: [F] overflow flags, [F] spans per frame
     uint64_t *d_events = nullptr;               // sky event bits (fe_event_words), zeroed before every walk
+    size_t flags_bytes = 0;
+    uint32_t *d_flags = nullptr;                // [F] overflow flags the walk's kernels OR into; sits in front of d_events (one memset clears both)
     FeParams FP{};
     bool fe_mode = false;         // the last submission went through the device column walk
     bool fe_check = false;        // ... and its overflow flags have not been looked at yet
@@ -234,7 +236,7 @@ void free_ctx(dg_ctx *c) {
         if (s.h_fe) (void)hipHostFree(s.h_fe);
         if (s.d_fe) (void)hipFree(s.d_fe);
         if (s.d_fe_coloff) (void)hipFree(s.d_fe_coloff);
-        if (s.d_events) (void)hipFree(s.d_events);
+        if (s.d_flags) (void)hipFree(s.d_flags);    // (d_events lies inside this allocation)
         if (s.h_status) (void)hipHostFree(s.h_status);
         if (s.ev_start) (void)hipEventDestroy(s.ev_start);
         if (s.ev_setup) (void)hipEventDestroy(s.ev_setup);
@@ -416,7 +418,8 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_vie
     F.sbin_sprites = reinterpret_cast<const uint16_t *>(s.d_fe + off_sbins);
     F.cspans = c->d_fe_cspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt;
     F.events = s.d_events;
-    F.flags = s.h_status; F.totals = s.h_status + c->cfg.max_batch;      // pinned host memory, written by the kernels directly
+    F.flags = s.d_flags;
+    F.host_flags = s.h_status; F.totals = s.h_status + c->cfg.max_batch;  // pinned host memory, written by dg_fe_scan with plain stores
     F.col_off = s.d_fe_coloff; F.rspans = s.d_rspans;
     F.n_frames = n; F.span_stride = span_stride; F.w64 = (uint32_t)((W + 63) / 64); F.col_slots = c->fe_col_slots;
     RasterParams &P = s.P;
@@ -456,18 +459,27 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
     // written by the kernels directly: nothing is queued behind the raster launch, so no stream ever holds a barrier that another
     // slot's upload could get stuck behind (streams share hardware queues).
     hipStream_t ks = c->kstream;
+    // A HIP call that fails half way leaves the slot describing no submission at all: later calls on it return DG_ERR_INVALID
+    // instead of waiting on a stale event or reading status words nobody wrote.
+    struct Invalidate {
+        Slot &s; bool armed = true;
+        ~Invalidate() { if (armed) { s.n_frames = 0; s.timed = false; s.busy = false; s.fe_check = false; s.raster_recorded = false; } }
+    } guard{s};
+    const bool fe_mode = s.fe_mode;
+    s.fe_check = false;
     HIP_TRY(hipEventRecord(s.ev_h2d, s.stream));
     HIP_TRY(hipStreamWaitEvent(ks, s.ev_h2d, 0));
-    if (s.fe_mode) {
+    if (fe_mode) {
         std::memset(s.h_status, 0, (size_t)2 * (size_t)c->cfg.max_batch * 4);
         const size_t ev_bytes = (size_t)3 * (size_t)s.FP.n_frames * s.FP.max_sky_slots * s.FP.w64 * 8;   // all three event kinds (fe_event_words)
-        if (ev_bytes) HIP_TRY(hipMemsetAsync(s.d_events, 0, ev_bytes, ks));
+        HIP_TRY(hipMemsetAsync(s.d_flags, 0, s.flags_bytes + ev_bytes, ks));                            // the overflow flags and the event bits behind them
         HIP_TRY(launch_fe(s.FP, ks, s.ev_start, s.ev_setup));
-        s.fe_check = true;
     } else {
         HIP_TRY(launch_setup(s.P, s.max_spans, ks, s.ev_start, s.ev_setup));
     }
     HIP_TRY(launch_raster(s.P, ks, s.ev_rstart, s.ev_raster));
+    guard.armed = false;
+    s.fe_check = fe_mode;
     s.raster_recorded = true;
     s.busy = true; s.timed = true;
     return DG_OK;
@@ -597,7 +609,7 @@ int check_slot(dg_ctx *c, int slot) {
 extern "C" {
 
 const char *dg_last_error(void) { return t_err.c_str(); }
-const char *dg_version(void) { return "doomgpu 0.2 (gfx950)"; }
+const char *dg_version(void) { return "doomgpu 0.4 (gfx950; ABI 4)"; }
 
 int dg_scene_load_wad(const uint8_t *wad, size_t len, const char *map_name, dg_scene **out) {
     if (!wad || !map_name || !out) return set_err(DG_ERR_INVALID, "null argument");
@@ -758,7 +770,9 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
             CTX_TRY(hipHostMalloc((void **)&s.h_fe, c->fe_slab_cap, hipHostMallocDefault));
             CTX_TRY(hipMalloc((void **)&s.d_fe, c->fe_slab_cap));
             CTX_TRY(hipMalloc((void **)&s.d_fe_coloff, F * (W + 1) * 4));
-            CTX_TRY(hipMalloc((void **)&s.d_events, F * FE_MAX_SKY_SLOTS * 3 * ((W + 63) / 64) * 8));
+            s.flags_bytes = align_up(F * 4, 256);
+            CTX_TRY(hipMalloc((void **)&s.d_flags, s.flags_bytes + F * FE_MAX_SKY_SLOTS * 3 * ((W + 63) / 64) * 8));
+            s.d_events = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(s.d_flags) + s.flags_bytes);
             CTX_TRY(hipHostMalloc((void **)&s.h_status, 2 * F * 4, hipHostMallocDefault));
         }
         s.lists_cap = lists_cap;
@@ -775,6 +789,10 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     if (!c || !scene) return set_err(DG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
     for (Slot &s : c->slots) {             // nothing may still read the old scene or write into a buffer a pending readback is copying from
+        // A slot with work in flight is FINISHED against the scene it was rendered from (still resident): a device-walk batch that
+        // overflowed a capacity is redone and its pending readback re-issued, exactly as dg_wait would have done.  (If that redo is
+        // impossible — the old scene object itself was changed since its upload — the slot is just drained.)
+        if ((s.busy || s.copy_pending || s.fe_check) && c->scene && s.n_frames > 0 && finish_slot(c, s) == DG_OK) continue;
         HIP_TRY(slot_sync(s));
         HIP_TRY(hipStreamSynchronize(s.copy_stream));
         s.copy_pending = false;

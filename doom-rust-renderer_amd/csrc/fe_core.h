@@ -40,8 +40,10 @@ struct FeParams {
     uint32_t *cnt;                // [frame][W] spans emitted per column
     uint64_t *events;             // [3][n_frames][max_sky_slots][W64] add-floor / add-ceiling / not-flushed bits per column,
                                   // zeroed by the host (= what a horizontally occluded column yields), see fe_event_words
-    uint32_t *flags;              // [frame] FE_OVF_*
-    uint32_t *totals;             // [frame] spans of the frame (written by dg_fe_finalize)
+    uint32_t *flags;              // [frame] FE_OVF_*, DEVICE memory (the walk's kernels OR into it), zeroed by the host with the event bits
+    uint32_t *host_flags;         // [frame] the same word, published once per frame by dg_fe_scan — pinned host memory (plain stores only:
+                                  // an OR is not one of the atomics PCIe carries)
+    uint32_t *totals;             // [frame] spans of the frame, pinned host memory (written by dg_fe_scan)
     // outputs consumed by dg_raster_tiles
     uint32_t *col_off;            // [frame][W + 1]
     DevRSpan *rspans;

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(FE_SCAN_THREADS) void dg_fe_scan(FeParams P) {
     if (tid == 0) {
         coff[W] = fits ? total : 0u;
         P.totals[f] = total;
-        if (!fits) atomicOr(&P.flags[f], (uint32_t)FE_OVF_FRAME);
+        // the frame's overflow word goes to the host here, with a plain store: dg_fe_columns and dg_fe_gaps have finished (same stream)
+        P.host_flags[f] = P.flags[f] | (fits ? 0u : (uint32_t)FE_OVF_FRAME);
     }
     for (int x = xa; x < xb; x++) {
         coff[x] = fits ? off : 0u;

@@ -510,6 +510,19 @@ struct Walker {
     // are all spanned by earlier full-height solid parts (every part of every seg in it would be dropped by
     // solid_cols.covers).  The column range is widened by two columns against f32 rounding of the per-seg projection;
     // boxes that straddle the viewer's depth-zero plane are always walked.
+    //
+    // Why two columns are enough (W <= 16384; tests/test_host_logic.py::test_subtree_cull_at_16384_columns_next_to_walls is the stress
+    // case).  Past the `xmin < 1` test all four corners have view depth x >= 1.  In exact arithmetic every seg endpoint e inside the
+    // box maps to a point p of the convex hull of the transformed corners, x(p) >= 1 there, and t = y / x — a ratio of affine
+    // functions, monotone along any segment — takes its extremes over the hull at corners: t(p) in [tmin, tmax].  clip_to_viewport
+    // (misc.rs:13-115) replaces an endpoint only by a point of the same seg on y = x or y = -x, so every endpoint that reaches
+    // make_sidedef_non_vertical_line has t in [max(tmin, -1), min(tmax, 1)]: the interval projected below.  In f32: corner and
+    // endpoint go through the same six operations of rot(sub(.)), each with relative error u = 2^-24, so |dx|, |dy| <= 4.3 u r with
+    // r = |e - pos|; a kept endpoint has |y| <= x, i.e. r <= 1.42 x, which bounds its error in t by (|dy| + |t| |dx|) / x <= 12.3 u;
+    // an intersection computed by Line::intersection (geometry.rs:56-82) adds a few more operations — 32 u = 1.9e-6 is generous.
+    // sx = trunc(CFX - ARC * (GCFX * y / x)) (misc.rs:147-158) then moves by at most K * 1.9e-6 = 0.016 columns (K = ARC * GCFX <=
+    // 8192) plus three roundings of values below 16384 (<= 0.003 columns): under 0.02 columns between the corner-derived bounds and
+    // any endpoint's sx, before truncation.  floor() of the bounds minus / plus 2 therefore leaves a margin of more than 1.9 columns.
     bool box_matters(const float *bb) const {
         if (bb[0] > bb[2]) return false;                             // no segs below this child
         float tmin = 3.0e38f, tmax = -3.0e38f, xmin = 3.0e38f, xmax = -3.0e38f;

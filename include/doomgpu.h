@@ -94,7 +94,9 @@ typedef struct dg_config {
     int32_t width, height; /* frame size (the reference's SCREEN_WIDTH/HEIGHT, src/game.rs:28-29); width % 4 == 0 */
     int32_t max_batch;     /* frames per submission */
     int32_t slots;         /* in-flight submissions (>= 1); each owns a framebuffer slab of max_batch frames */
-    int32_t host_threads;  /* list-generation threads for dg_render_views / dg_submit_views (0 = the process's CPU share: affinity mask and cgroup CPU quota, capped at 16) */
+    int32_t host_threads;  /* list-generation threads for dg_render_views / dg_submit_views (0 = the process's CPU share: affinity mask and cgroup CPU quota, capped at 16).
+                            * The default assumes ONE ctx per container quota: a process tree with several contexts (one rank per GPU) passes each its
+                            * part of the quota, as bench.py does (default_host_threads) */
     int32_t front_end;     /* DG_FE_*: where the per-column half of Segs::process_sidedef / draw_map_objects runs */
 } dg_config;
 
@@ -215,6 +217,9 @@ int dg_build_lists(const dg_scene *s, int width, int height, const dg_view *view
 
 /* ---- misc ----------------------------------------------------------------------------------------------------- */
 const char *dg_last_error(void); /* thread-local message of the last failing call */
+/* "doomgpu <release> (gfx950; ABI <n>)".  The ABI number changes whenever a struct in this header changes size or a function its
+ * arguments: ABI 3 (round 3) dropped dg_timing.strips_ms and the third argument of dg_ctx_fallbacks; ABI 4 changes no signature
+ * (it marks the library in which dg_version started to carry the number).  A caller built against another ABI must not call on. */
 const char *dg_version(void);
 
 /* Timing of the last dg_replay_slot / submit on a slot (ms), from HIP events attached to the kernel dispatches themselves on the ctx's

@@ -539,7 +539,7 @@ def get_sector_from_vertex(m: Map, v):                    # bsp.rs:9-44
         ni = c
 
 
-def render_frame(m: Map, things, sprites: SpriteTable, np_wad, nm, W: int, H: int, view, sky_name: str = "SKY1"):
+def render_frame(m: Map, things, sprites: SpriteTable, np_wad, nm, W: int, H: int, view, sky_name: str = "SKY1", timestamp: float = 0.0):
     """Renderer::render (mod.rs:118-136) in full: walls inline, visplanes, map objects with the masked walls behind them, the remaining
     masked walls.  np_wad / nm: tests/np_mappers.py's Wad and module (the three texture mappers).  -> H x W x 3 uint8."""
     calls = per_seg_calls(m, W, H, view)
@@ -573,7 +573,7 @@ def render_frame(m: Map, things, sprites: SpriteTable, np_wad, nm, W: int, H: in
                      "extends_to_bottom": lower or (not two and full), "extends_to_top": upper or (not two and full), "draw_ceiling": bool(fl & DRAW_CEILING)})
     for (ci, which, left, right, tb) in visplanes:                            # mod.rs:106-116
         c = calls[ci]
-        p = {"flat": get_animated(c["floor_flat"] if which == "floor" else c["ceiling_flat"], 0.0), "height": c["floor_height_i16"] if which == "floor" else c["ceiling_height_i16"],
+        p = {"flat": get_animated(c["floor_flat"] if which == "floor" else c["ceiling_flat"], timestamp), "height": c["floor_height_i16"] if which == "floor" else c["ceiling_height_i16"],
              "light_level": c["light_level"], "left": left, "right": right, "tb": tb}
         if "SKY" in p["flat"]:
             nm.draw_sky(fr, texture(sky_name), pal, mview, p)

@@ -163,6 +163,11 @@ def test_device_ordinal_survives_masked_visibility():
     assert [bench.pick_device(r, 8) for r in range(8)] == list(range(8))
     assert [bench.pick_device(r, 1) for r in range(8)] == [0] * 8
     assert bench.pick_device(3, 0) == 3                 # no GPU visible (CPU rehearsal): unchanged, dg_create reports it
+    assert [bench.pick_device(r, 8, 4) for r in range(4)] == [0, 1, 2, 3]
+    with pytest.raises(SystemExit):                     # 8 ranks on 4 unmasked GPUs: two ranks would share a GPU silently
+        bench.pick_device(5, 4, 8)
+    with pytest.raises(SystemExit):
+        bench.pick_device(1, 4, 8)
 
 
 def _fake_eight_gpu_sysfs(root, numa_of_gpu, cpulists, gpu_first=False):

@@ -422,6 +422,19 @@ def test_device_front_end_capacity_falls_back_to_host_lists(dg, scene1994, oracl
     ctx.wait(0)
     assert np.array_equal(ctx.readback(0, 0, len(idx)), out) and ctx.timing(0)["front_end"] == dg.DG_FE_DEVICE
     assert ctx.fallbacks()["front_end"] == 4 and ctx.fallbacks()["redone_frames"] == 4 * fb["redone_frames"]   # render, submit, prepare (it runs the walk once), replay
+    # a readback queued behind an overflowing batch, then dg_upload_scene instead of dg_wait: the upload settles the slot first (the
+    # overflowed frames are redone against the scene they were rendered from and the copy is issued again), so the host buffer holds
+    # the right frames, not the overflowed run's
+    buf = dg.lib().dg_alloc_host(len(idx) * ctx.frame_bytes)
+    assert buf
+    host = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctypes.c_uint8)), shape=(len(idx), H, W, 3))
+    host[:] = 0
+    ctx.submit(1, views)
+    ctx.readback_async(1, 0, len(idx), buf)
+    ctx.upload_scene(scene1994)
+    ctx.wait(1)
+    assert np.array_equal(host, out) and ctx.fallbacks()["front_end"] == 5
+    dg.lib().dg_free_host(buf)
     ctx.close()
 
 

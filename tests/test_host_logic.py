@@ -271,3 +271,52 @@ def test_per_view_state_equals_scene_state(synth, oracle, path1993):
     assert changed >= 2                                      # the snapshots really changed what these views show
     with pytest.raises(RuntimeError):
         es.render_state(W, H, path1993[10], [(10 ** 6, 5)], [])
+
+
+def _lump(wad: bytes, name: str, after: str = None):
+    import struct
+    n, off = struct.unpack_from("<II", wad, 4)
+    names = [wad[off + 16 * i + 8:off + 16 * i + 16].rstrip(b"\0").decode() for i in range(n)]
+    i0 = names.index(after) if after else 0
+    i = names.index(name, i0)
+    o, sz = struct.unpack_from("<II", wad, off + 16 * i)
+    return wad[o:o + sz]
+
+
+def test_subtree_cull_at_16384_columns_next_to_walls(oracle, synth, campath_mod):
+    """Walker::box_matters (frontend.cpp) skips a BSP subtree whose bounding box projects into columns already spanned by full-height
+    solid walls, after widening the projected range by two columns; the comment there bounds the rounding difference between the
+    box-corner projection and any seg endpoint's `sx` by far less than one column for W <= 16384.  This is the stress case for that
+    bound: W = 16384 (K = ARC * GCFX = 8192 columns per unit of y / x), viewpoints 1e-3 map units in front of and behind walls (depths
+    near the x >= 1 cut-off, large y / x spreads), at wall ends and at vertices, random headings: the culled product front end + kernel
+    bodies must reproduce the un-culled oracle byte for byte."""
+    import struct
+    W, H = 16384, 64
+    for seed, heavy, vanilla in ((1993, False, False), (1995, False, True)):
+        wad = synth.build_synth_iwad(seed, heavy=heavy, vanilla=vanilla)
+        osc = oracle.Scene(wad, "e1m1")
+        es = emul_bind.EmulScene(wad)
+        vx = np.frombuffer(_lump(wad, "VERTEXES", "E1M1"), dtype="<i2").reshape(-1, 2).astype(np.float64)
+        ld = np.frombuffer(_lump(wad, "LINEDEFS", "E1M1"), dtype="<i2").reshape(-1, 7)
+        rng = np.random.default_rng(seed)
+        checked = 0
+        for j in range(36):
+            l = ld[int(rng.integers(len(ld)))]
+            a, b = vx[l[0]], vx[l[1]]
+            d = b - a
+            nrm = np.array([d[1], -d[0]]) / np.hypot(*d)
+            t = [0.5, 0.0, 1.0, 0.001, 0.37][j % 5]
+            side = 1.0 if j % 2 else -1.0
+            dist = [1e-3, 1e-3, 0.9990, 1.0005, 3e-2][j % 5]              # around the `xmin < 1` cut-off of box_matters as well
+            p = a + t * d + side * dist * nrm
+            ang = float(rng.uniform(-np.pi, np.pi)) if j % 3 else float(np.arctan2(-side * nrm[1], -side * nrm[0]) + rng.uniform(-0.8, 0.8))
+            rec = campath_mod.view_record(np.float32(p[0]), np.float32(p[1]), np.float32(ang), np.float32(osc.floor_height_at(float(p[0]), float(p[1]), 0.0)))
+            try:
+                ref = osc.render(W, H, rec)
+            except RuntimeError:
+                with pytest.raises(RuntimeError):
+                    es.render(W, H, rec)
+                continue
+            assert es.render(W, H, rec)[0] == ref, f"seed {seed} view {j}: culled front end differs from the un-culled oracle"
+            checked += 1
+        assert checked >= 24
