@@ -25,6 +25,8 @@
 // divide expansion keeps its own internal FMAs, which is what makes it correctly rounded).
 // Experiment builds (make variant VARIANT=x EXTRA="-D..."; never defined in the product build; results in profiles/r02_*.md):
 //   DG_EXP_T_LDSPAD=bytes   pad the tile kernel's LDS (occupancy experiment)      DG_EXP_T_TIMING   per-wave s_memtime phase probe (device printf)
+//   DG_EXP_TILE_ROWS=n      tile rows per workgroup                               DG_ABL_NOGENERAL / _NOSOLEMAP / _NOOVL / _NOSHADE / _NOREADOUT
+//                           ablations: the kernel minus one of its parts (wrong pixels; profiles/r04_raster_tiles.md)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -362,17 +364,10 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
     __syncthreads();
     DG_PHASE(1)
 
-#ifdef DG_EXP_RTPREFETCH
-  uint4 rt_next = P.row_tab[min(ty_begin * TILE_H + lane, H - 1)];
-#endif
   for (int ty = ty_begin; ty < ty_end; ty++) {
     const int y0 = ty * TILE_H;
     const int y = y0 + lane;
-#ifdef DG_EXP_RTPREFETCH
-    const uint4 rt = rt_next;
-#else
-    const uint4 rt = P.row_tab[y < H ? y : H - 1];                    // dg_row_table
-#endif
+    const uint4 rt = P.row_tab[y < H ? y : H - 1];                    // dg_row_table (prefetching the next tile's under the barrier: measured, neutral)
     // A tile with at most 8 live rows (the last tile row of a 200-row frame): a wave can take all eight of its columns in ONE pass,
     // lane = (column, row) = (lane >> 3, lane & 7).  Its row constants:
     const bool few_rows = H - y0 <= PACK_ROWS;
@@ -543,9 +538,6 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         if (c_lo < TILE_W) __syncthreads();   // before the staging area is reused
     }
     DG_PHASE(2)
-#ifdef DG_EXP_RTPREFETCH
-    rt_next = P.row_tab[min(y + TILE_H, H - 1)];                      // the next tile's row constants travel under the barrier and the read-out
-#endif
     __syncthreads();
     DG_PHASE(6)
 
@@ -641,21 +633,30 @@ hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hip
     return hipGetLastError();
 }
 
-// Tile rows one workgroup renders out of one staging pass.  Measured at 1280x800 (13 tile rows): 1 / 2 / 3 / 4 / 13 rows = 0.586 / 0.577 /
-// 0.562 / 0.593 / 0.669 ms per 250 frames; at 320x200 (4 tile rows) 2 rows win (profiles/r03_raster_tiles.md).
-int raster_tile_rows_per_wg(int H) {
+// Tile rows one workgroup renders out of one staging pass.  Fewer, longer workgroups pay the staging chain (two scalar loads -> span
+// loads -> LDS -> barrier) and the workgroup launch / drain less often, but a launch needs enough workgroups for its tail not to show
+// (the chip holds 1 024 of them at a time) and the segments of a strip should be of equal length.  Measured (profiles/r04_raster_tiles.md):
+// 1280x800 (13 tile rows) at 1 000 frames per launch 3 / 5 / 7 / 13 rows = 1.83 / 1.78 / 1.75 / 1.81 ms, at 250 frames 0.51 / 0.51 / 0.54 /
+// 0.60 ms; 1024x768 (12) at 1 000 frames 3 / 5 / 6 / 7 / 9 = 1.60 / 1.54 / 1.50 / 1.69 / 2.13 ms (7 + 5 and 9 + 3 are unbalanced);
+// 2560x1600 (25) at 250 frames 3 / 5 / 9 / 13 = 1.66 / 1.63 / 1.65 / 1.70 ms; 320x200 (4 tile rows) 2 rows win.
+// Rule: the fewest equal segments per strip that still give ~30 000 workgroups, never fewer than 3 rows' worth for tall frames.
+int raster_tile_rows_per_wg(int W, int H, int n_frames) {
     const int n_tile_rows = (H + TILE_H - 1) / TILE_H;
 #ifdef DG_EXP_TILE_ROWS
     return std::min(DG_EXP_TILE_ROWS, n_tile_rows);
 #endif
-    return std::min(n_tile_rows >= 8 ? 3 : 2, n_tile_rows);
+    if (n_tile_rows < 8) return std::min(2, n_tile_rows);
+    const long long strips = (long long)((W + TILE_W - 1) / TILE_W) * (long long)std::max(1, n_frames);
+    long long segments = (30000 + strips - 1) / strips;
+    segments = std::max(1ll, std::min(segments, (long long)((n_tile_rows + 2) / 3)));
+    return (int)((n_tile_rows + segments - 1) / segments);
 }
 
 hipError_t launch_raster(const RasterParams &P_in, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
     if (P_in.n_frames <= 0) return record_pair(stream, start, stop);
     RasterParams P = P_in;
     const int n_tile_rows = (P.k.H + TILE_H - 1) / TILE_H;
-    if (P.tile_rows_per_wg <= 0) P.tile_rows_per_wg = raster_tile_rows_per_wg(P.k.H);
+    if (P.tile_rows_per_wg <= 0) P.tile_rows_per_wg = raster_tile_rows_per_wg(P.k.W, P.k.H, P.n_frames);
     dim3 grid((unsigned)((P.k.W + TILE_W - 1) / TILE_W), (unsigned)((n_tile_rows + P.tile_rows_per_wg - 1) / P.tile_rows_per_wg), (unsigned)P.n_frames);
     hipExtLaunchKernelGGL(dg_raster_tiles, grid, dim3(THREADS), 0, stream, start, stop, 0, P);
     return hipGetLastError();
