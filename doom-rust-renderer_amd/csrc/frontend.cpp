@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "fs_core.h"
 #include "rust_num.h"
 
 namespace dg {
@@ -17,77 +18,9 @@ namespace {
 const float kPi = 3.14159265358979323846f;
 const float kEye = 41.0f;  // PLAYER_EYE_HEIGHT, src/renderer/constants.rs:3
 
-struct V2 { float x, y; };
-struct Seg2 { V2 a, b; };
-
-inline V2 sub(V2 p, V2 q) { return V2{p.x - q.x, p.y - q.y}; }
-inline V2 rot(V2 v, float c, float s) { return V2{v.x * c - v.y * s, v.y * c + v.x * s}; }          // vertexes.rs:20-25
-inline bool left_of(V2 v, const Seg2 &l) {                                                           // vertexes.rs:27-34
-    V2 p = sub(v, l.a), d = sub(l.b, l.a);
-    return p.x * d.y - p.y * d.x <= 0.0f;
-}
-inline float dist(V2 p, V2 q) { float dx = p.x - q.x, dy = p.y - q.y; return std::sqrt(dx * dx + dy * dy); }
-
-// Line::intersection, src/geometry.rs:56-82
-inline bool intersect(const Seg2 &m, const Seg2 &n, V2 &out) {
-    float x1 = m.a.x, y1 = m.a.y, x2 = m.b.x, y2 = m.b.y, x3 = n.a.x, y3 = n.a.y, x4 = n.b.x, y4 = n.b.y;
-    float quot = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4);
-    if (std::fabs(quot) < 0.001f) return false;
-    float inv = 1.0f / quot;
-    float c12 = x1 * y2 - y1 * x2, c34 = x3 * y4 - y3 * x4;
-    out.x = inv * (c12 * (x3 - x4) - (x1 - x2) * c34);
-    out.y = inv * (c12 * (y3 - y4) - (y1 - y2) * c34);
-    return true;
-}
-
-struct Clipped { Seg2 line; float start_offset; };
-
-// clip_to_viewport, src/renderer/misc.rs:13-115
-bool clip_to_viewport(const Seg2 &line, Clipped &out) {
-    const Seg2 left{{0.0f, 0.0f}, {1.0f, 1.0f}}, right{{0.0f, 0.0f}, {1.0f, -1.0f}};
-    bool s_out_l = left_of(line.a, left), e_out_l = left_of(line.b, left);
-    bool s_out_r = !left_of(line.a, right), e_out_r = !left_of(line.b, right);
-    bool s_in = line.a.x > 0.0f && !s_out_l && !s_out_r;
-    bool e_in = line.b.x > 0.0f && !e_out_l && !e_out_r;
-    if (s_in && e_in) { out.line = line; out.start_offset = 0.0f; return true; }
-    V2 li{0.0f, 0.0f}, ri{0.0f, 0.0f};
-    bool l_hit = intersect(line, left, li) && li.x >= 0.0f;
-    bool r_hit = intersect(line, right, ri) && ri.x >= 0.0f;
-    if (!s_in && !e_in && !l_hit && !r_hit) return false;
-    if (!s_in && !e_in && (l_hit != r_hit)) return false;
-    if ((r_hit && s_out_r && e_out_r) || (l_hit && s_out_l && e_out_l)) return false;
-    V2 s = line.a, e = line.b;
-    float so = 0.0f;
-    if (l_hit) {
-        if (s_out_l) { so = dist(li, s); s = li; }
-        if (e_out_l) e = li;
-    }
-    if (r_hit) {
-        if (s_out_r) s = ri;
-        if (e_out_r) e = ri;
-    }
-    out.line = Seg2{s, e};
-    out.start_offset = so;
-    return true;
-}
-
-struct ScreenLine { int32_t sx, sy, ex, ey; };
-
-// perspective_transform + make_sidedef_non_vertical_line, src/renderer/misc.rs:130-161
-inline ScreenLine project(const FrameConsts &k, const Seg2 &l, float height) {
-    float tsx = k.GCFX * l.a.y / l.a.x, tsy = k.GCFX * height / l.a.x;
-    float tex = k.GCFX * l.b.y / l.b.x, tey = k.GCFX * height / l.b.x;
-    tsx *= k.ARC;
-    tex *= k.ARC;
-    ScreenLine o;
-    o.sx = f32_as_i32(k.CFX - tsx);
-    o.sy = f32_as_i32(k.CFY - tsy);
-    o.ex = f32_as_i32(k.CFX - tex);
-    o.ey = f32_as_i32(k.CFY - tey);
-    o.sx = std::min(o.sx, k.W - 1);
-    o.ex = std::min(o.ex, k.W - 1);
-    return o;
-}
+// (V2, Seg2, clip_to_viewport, project, ... : fs_core.h — shared with the GPU's per-seg kernels)
+inline V2 sub(V2 p, V2 q) { return v2_sub(p, q); }
+inline V2 rot(V2 v, float c, float s) { return v2_rot(v, c, s); }
 
 enum : uint8_t { ST_SOLID, ST_TWOSIDED, ST_DRAWN, ST_MAPOBJECT };   // bitmap_render.rs:11-17
 
@@ -122,24 +55,8 @@ FrameConsts make_consts(int W, int H) {
 
 DevWallRec make_wall_rec(const BitmapInfo &bi, float lsx, float lsy, float lex, float ley, float start_offset, int32_t start_x, int32_t end_x,
                          float bottom_height, float top_height, int16_t offset_x, int16_t offset_y, int16_t light_level) {
-    DevWallRec d;
-    float dx = lsx - lex, dy = lsy - ley;
-    float len = std::sqrt(dx * dx + dy * dy);                  // Line::length, geometry.rs:84-86
-    float uz0 = lsx, uz1 = lex;
-    d.A = 0.0f / uz0;
-    d.B = len / uz1;
-    d.C = 1.0f / uz0;
-    d.D = 1.0f / uz1;
-    d.uy1 = top_height - bottom_height;
-    d.lightf = (float)light_level / 255.0f;
-    d.dxf = (float)(end_x - start_x);
-    d.start_x = start_x;
-    d.texel_off = bi.texel_off;
-    d.w = (int16_t)bi.w; d.h = (int16_t)bi.h;
-    d.off_x = (int16_t)wrap_i16(f32_as_i16(start_offset) + offset_x);
-    d.off_y = offset_y;
-    d.has_holes = bi.has_holes;
-    return d;
+    const FsBitmap fb{bi.texel_off, (int16_t)bi.w, (int16_t)bi.h, bi.top_offset, (uint16_t)bi.has_holes};
+    return fs_wall_rec(fb, lsx, lsy, lex, ley, start_offset, start_x, end_x, bottom_height, top_height, offset_x, offset_y, light_level);
 }
 
 void fill_view_trig(dg_view &v) {
@@ -258,15 +175,6 @@ struct Walker {
         return status;
     }
 
-    // Flats::get_animated at this frame's timestamp
-    int resolve_flat(int flat, int anim) {
-        if (anim < 0) return flat;
-        const AnimList &a = sc.anim[(size_t)anim];
-        float t = view.timestamp * 3.0f;
-        size_t cyc = !(t > 0.0f) ? 0 : (t >= 18446744073709551616.0f ? SIZE_MAX : (size_t)t);
-        return a.flat[cyc % (size_t)a.n];
-    }
-
     void occlude(int x) {                                           // segs.rs:113-117
         A.hor_ocl[(size_t)x] = 1;
         A.floor_ocl[(size_t)x] = (int16_t)((int16_t)k.H / 2);
@@ -296,7 +204,6 @@ struct Walker {
 
     struct Side {                                                   // SideDefDetails, segs.rs:42-51
         const Clipped *cl;
-        const SidedefRec *sd;
         int16_t offset_x, floor_h, ceil_h, light;
         int floor_flat, ceil_flat;
     };
@@ -318,8 +225,42 @@ struct Walker {
     }
 
     // Segs::process_sidedef, segs.rs:121-350
-    void process_sidedef(const Side &s, float bottom_height, float top_height, int32_t offset_y, int tex, Flags f) {
+    void process_sidedef(const FsSegOut &so, const FsCall &call) {
         const int W = k.W, H = k.H;
+        const Clipped *cl = &so.cl;
+        const Side s{cl, so.seg_offset, so.floor_h, so.ceil_h, so.light, so.floor_flat, so.ceil_flat};
+        const float bottom_height = call.bottom_height, top_height = call.top_height;
+        const int32_t offset_y = call.offset_y;
+        const int tex = call.tex;
+        const Flags f{(call.flags & FEP_ONLY_OCCL) != 0, (call.flags & FEP_LOWER) != 0, (call.flags & FEP_UPPER) != 0, (call.flags & FEP_DRAW_CEILING) != 0,
+                      (call.flags & FEP_TWO_SIDED_MID) != 0};
+        if (parts_mode) {                                            // the per-column half runs on the GPU: record the part
+            FePart p;
+            std::memset(&p, 0, sizeof p);
+            const int32_t st = fs_part(k, so, call, sc.fs_bitmaps.data(), sc.flat_sky.data(), view.floor_height, p);
+            if (st == FS_SKIP) return;
+            if (st == FS_FAIL_PARTS) { fail_parts(fs_message(st)); return; }
+            if (st != FS_OK) { fail(fs_message(st)); return; }
+            // Columns that an earlier full-height solid part spans are horizontally occluded whatever that part's own
+            // visibility was (segs.rs:341-344 runs for every column of the part).  A part lying entirely inside them can
+            // neither draw, clip, add a visplane entry nor occlude anything new (segs.rs:211,337-341): it is dropped here.
+            if (solid_cols.covers(p.sx, p.ex)) return;
+            if (fs_part_is_solid(p.flags) && p.sx <= p.ex) solid_cols.add(p.sx, p.ex);
+            if (fs_part_wants_sky_slot(p.flags)) {
+                p.sky_slot = (int32_t)A.n_sky_slots++;
+                A.sky_parts.push_back((uint32_t)A.parts.size());
+            }
+            if (A.parts.size() >= 65535) { fail_parts("more than 65535 wall records in a frame"); return; }
+            A.parts.push_back(p);
+            Rec r;
+            std::memset(&r, 0, sizeof r);
+            r.line = cl->line;
+            r.min_x = std::fmin(r.line.a.x, r.line.b.x); r.max_x = std::fmax(r.line.a.x, r.line.b.x);
+            r.state = f.two_sided_mid ? ST_TWOSIDED : ST_SOLID;
+            r.out_index = -1;
+            recs.push_back(r);
+            return;
+        }
         ScreenLine bot = project(k, s.cl->line, bottom_height);
         ScreenLine top = project(k, s.cl->line, top_height);
         if (tex == TEX_UNKNOWN) { fail("Unknown texture (Textures::get panics, textures.rs:158)"); return; }
@@ -341,8 +282,8 @@ struct Walker {
         r.start_x = bot.sx; r.end_x = bot.ex; r.bitmap = tex;
         r.first_col = (uint32_t)A.columns.size(); r.n_cols = 0; r.out_index = -1;
         r.light = s.light;
-        r.offset_x = (int16_t)wrap_i16(f32_as_i16(s.sd->xoff) + s.offset_x);
-        r.offset_y = (int16_t)wrap_i16(f32_as_i16(s.sd->yoff) + wrap_i16(offset_y));
+        r.offset_x = (int16_t)wrap_i16(f32_as_i16(so.sd_xoff) + s.offset_x);
+        r.offset_y = (int16_t)wrap_i16(f32_as_i16(so.sd_yoff) + wrap_i16(offset_y));
         r.state = f.two_sided_mid ? ST_TWOSIDED : ST_SOLID;
         r.ext_bottom = f.lower || (!f.two_sided_mid && full_height);
         r.ext_top = f.upper || (!f.two_sided_mid && full_height);
@@ -355,42 +296,6 @@ struct Walker {
         // neither draw, clip, add a visplane entry nor occlude anything new (segs.rs:211,337-341): it is dropped here.
         if (solid_cols.covers(bot.sx, bot.ex)) return;
         if (!f.two_sided_mid && full_height && bot.sx <= bot.ex) solid_cols.add(bot.sx, bot.ex);
-        if (parts_mode) {
-            if (tex >= 0) {
-                const BitmapInfo &bi = sc.bitmaps[(size_t)tex];
-                if (bi.w <= 0 || bi.h <= 0) { fail_parts("zero-sized bitmap"); return; }
-            }
-            FePart p;
-            std::memset(&p, 0, sizeof p);
-            p.sx = bot.sx; p.ex = bot.ex;
-            p.bsy = (float)bot.sy; p.bsx = (float)bot.sx; p.bdelta = bottom_delta;
-            p.tsy = (float)top.sy; p.tsx = (float)top.sx; p.tdelta = top_delta;
-            const bool fsky = sc.flat_sky[(size_t)s.floor_flat] != 0, csky = sc.flat_sky[(size_t)s.ceil_flat] != 0;
-            p.flags = (f.only_occlusions ? FEP_ONLY_OCCL : 0u) | (f.lower ? FEP_LOWER : 0u) | (f.upper ? FEP_UPPER : 0u) |
-                      (f.draw_ceiling ? FEP_DRAW_CEILING : 0u) | (f.two_sided_mid ? FEP_TWO_SIDED_MID : 0u) | (tex >= 0 ? FEP_HAS_BITMAP : 0u) |
-                      (fsky ? FEP_FLOOR_SKY : 0u) | (csky ? FEP_CEIL_SKY : 0u);
-            p.sky_slot = -1;
-            if (planes_here && (fsky || (csky && f.draw_ceiling))) {
-                p.sky_slot = (int32_t)A.n_sky_slots++;
-                A.sky_parts.push_back((uint32_t)A.parts.size());
-            }
-            if (tex >= 0)
-                p.wall = make_wall_rec(sc.bitmaps[(size_t)tex], r.line.a.x, r.line.a.y, r.line.b.x, r.line.b.y, r.start_offset, r.start_x, r.end_x,
-                                       bottom_height, top_height, r.offset_x, r.offset_y, r.light);
-            const float lightf = (float)s.light / 255.0f;
-            p.floor_plane.wz = (float)s.floor_h - view.floor_height - 41.0f;      // visplanes.rs:112
-            p.floor_plane.gwz = k.GCFX * p.floor_plane.wz;
-            p.floor_plane.lightf = lightf;
-            p.floor_plane.flat_off = (uint32_t)s.floor_flat * 4096u;
-            p.ceil_plane.wz = (float)s.ceil_h - view.floor_height - 41.0f;
-            p.ceil_plane.gwz = k.GCFX * p.ceil_plane.wz;
-            p.ceil_plane.lightf = lightf;
-            p.ceil_plane.flat_off = (uint32_t)s.ceil_flat * 4096u;
-            if (A.parts.size() >= 65535) { fail_parts("more than 65535 wall records in a frame"); return; }
-            A.parts.push_back(p);
-            recs.push_back(r);
-            return;
-        }
         const int16_t hm1 = (int16_t)(H - 1);
         for (int x = bot.sx; x <= bot.ex; x++) {
             if (!A.hor_ocl[(size_t)x]) {
@@ -438,70 +343,29 @@ struct Walker {
         if (!f.two_sided_mid && !f.only_occlusions && tex >= 0 && r.n_cols > 0) emit_draw(recs.back());
     }
 
-    // Segs::process_seg, segs.rs:353-590
-    void process_seg(const SegRec &sg) {
-        const LinedefRec &ld = sc.linedefs[(size_t)sg.linedef];
-        int fsd = sg.direction ? ld.back : ld.front;
-        int bsd = sg.direction ? ld.front : ld.back;
-        if (fsd < 0) return;
-        const SidedefRec &front = sc.sidedefs[(size_t)fsd];
-        const SectorRec &fs = sc.sectors[(size_t)front.sector];
-        const SectorRec *bs = bsd >= 0 ? &sc.sectors[(size_t)sc.sidedefs[(size_t)bsd].sector] : nullptr;
-
-        float floor_height = (float)fs.floor_h, ceiling_height = (float)fs.ceil_h;
-        bool has_pb = false, has_pt = false;
-        float pb_h = 0.0f, pt_h = 0.0f;
-        if (bs) {
-            if (bs->floor_h > fs.floor_h) { has_pb = true; pb_h = (float)bs->floor_h; }
-            if (bs->ceil_h < fs.ceil_h) { has_pt = true; pt_h = (float)bs->ceil_h; }
+    static const char *fs_message(int32_t code) {
+        switch (code) {
+            case FS_FAIL_CLIP_X: return "Clipped line x < -0.01 (segs.rs:431-436)";
+            case FS_FAIL_FLAT: return "Could not find flat lump (Flat::new unwrap, flats.rs:117)";
+            case FS_FAIL_TEXTURE: return "Unknown texture (Textures::get panics, textures.rs:158)";
+            case FS_FAIL_VERTICAL: return "Wall start not vertical (segs.rs:140-145)";
+            case FS_FAIL_LINE_X: return "Invalid line x (segs.rs:103-111)";
+            case FS_FAIL_ROTATION: return "Invalid rotation (sprites.rs:106-108)";
+            case FS_FAIL_MOBJ_CLIP_X: return "Clipped line x < -0.01 (map_objects.rs:92-97)";
+            case FS_FAIL_MOBJ_COLUMN: return "map object column out of range (index panic)";
+            default: return "zero-sized bitmap";
         }
-        bool two_sided = (ld.flags & 4) != 0, top_unpegged = (ld.flags & 8) != 0, bottom_unpegged = (ld.flags & 16) != 0;
+    }
 
-        V2 a = rot(sub(V2{sc.vx[(size_t)sg.v1], sc.vy[(size_t)sg.v1]}, ppos), view.cos_na, view.sin_na);
-        V2 b = rot(sub(V2{sc.vx[(size_t)sg.v2], sc.vy[(size_t)sg.v2]}, ppos), view.cos_na, view.sin_na);
-        Clipped cl;
-        if (!clip_to_viewport(Seg2{a, b}, cl)) return;
-        if (cl.line.a.x < -0.01f) { fail("Clipped line x < -0.01 (segs.rs:431-436)"); return; }
-
-        ScreenLine fl = project(k, cl.line, floor_height - player_height);
-        if (fl.sx > fl.ex) return;                                   // back face
-
-        int floor_flat = resolve_flat(fs.floor_flat, fs.floor_anim);
-        int ceil_flat = resolve_flat(fs.ceil_flat, fs.ceil_anim);
-        if (floor_flat < 0 || ceil_flat < 0) { fail("Could not find flat lump (Flat::new unwrap, flats.rs:117)"); return; }
-
-        bool draw_ceiling = true;
-        if (bs && fs.ceil_tex_sky && bs->ceil_tex_sky) {             // sky hack, segs.rs:463-477
-            has_pt = false;
-            ceiling_height = std::fmin((float)bs->ceil_h, ceiling_height);
-            draw_ceiling = false;
-        }
-        Side s{&cl, &front, sg.offset, fs.floor_h, fs.ceil_h, sector_light(front.sector), floor_flat, ceil_flat};
-
-        if (!two_sided) {
-            int32_t oy = bottom_unpegged ? f32_as_i32(floor_height - ceiling_height) : 0;
-            process_sidedef(s, floor_height - player_height, ceiling_height - player_height, oy, front.middle,
-                            Flags{false, false, false, draw_ceiling, false});
-            return;
-        }
-        process_sidedef(s, floor_height - player_height, ceiling_height - player_height, 0, front.middle,
-                        Flags{true, false, false, draw_ceiling, false});
-        if (status) return;
-        float mid_floor = has_pb ? pb_h : floor_height, mid_ceil = has_pt ? pt_h : ceiling_height;
-        process_sidedef(s, mid_floor - player_height, mid_ceil - player_height, 0, front.middle,
-                        Flags{false, false, false, draw_ceiling, true});
-        if (status) return;
-        if (has_pb) {
-            int32_t oy = bottom_unpegged ? f32_as_i32(ceiling_height - pb_h) : 0;
-            process_sidedef(s, floor_height - player_height, pb_h - player_height, oy, front.lower,
-                            Flags{false, true, false, draw_ceiling, false});
-            if (status) return;
-        }
-        if (has_pt) {
-            int32_t oy = top_unpegged ? 0 : f32_as_i32(pt_h - ceiling_height);
-            process_sidedef(s, pt_h - player_height, ceiling_height - player_height, oy, front.upper,
-                            Flags{false, false, true, draw_ceiling, false});
-        }
+    // Segs::process_seg, segs.rs:353-590: fs_seg (fs_core.h) classifies the seg and lists its process_sidedef calls
+    void process_seg(size_t seg_index) {
+        const FsSeg &sg = sc.fs_segs[seg_index];
+        FsSegOut so;
+        const int16_t light = sg.front_sector >= 0 ? sector_light(sg.front_sector) : (int16_t)0;
+        const int32_t st = fs_seg(k, sg, sc.fs_sectors.data(), sc.fs_anims.data(), ppos, view.cos_na, view.sin_na, player_height, view.timestamp, light, so);
+        if (st == FS_SKIP) return;
+        if (st != FS_OK) { fail(fs_message(st)); return; }
+        for (int i = 0; i < so.n_calls && !status; i++) process_sidedef(so, so.call[i]);
     }
 
     // Renderer::render_node, mod.rs:69-104 — iterative, front child first, no culling (the reference has none)
@@ -553,7 +417,7 @@ struct Walker {
             if (cull && box[sp] && !box_matters(box[sp])) continue;
             if (c & (int16_t)0x8000) {
                 const SubSectorRec &ss = sc.subsectors[(size_t)(c & 0x7fff)];
-                for (int i = 0; i < ss.count && !status; i++) process_seg(sc.segs[(size_t)(ss.first + i)]);
+                for (int i = 0; i < ss.count && !status; i++) process_seg((size_t)(ss.first + i));
                 continue;
             }
             const NodeRec &n = sc.nodes[(size_t)c];
@@ -585,6 +449,33 @@ struct Walker {
             int32_t m_sprite_frame, m_full_bright;
             mobj_state(mi, m_sprite_frame, m_full_bright);
             if (m_sprite_frame < 0) continue;                         // S_NULL
+            if (parts_mode) {                                         // the per-column half runs on the GPU: record the sprite (fs_core.h)
+                FsSpriteOut so;
+                std::memset(&so.sp, 0, sizeof so.sp);
+                const FsMobj &fm = sc.fs_mobjs[mi];
+                const int32_t st = fs_mobj(k, fm, sc.sprite_frames_fs()[(size_t)m_sprite_frame], sc.fs_bitmaps.data(), sc.fs_sectors.data(), ppos, view.angle,
+                                           view.cos_na, view.sin_na, player_height, m_full_bright, fm.sector >= 0 ? sector_light(fm.sector) : (int16_t)0, so);
+                if (st == FS_SKIP) continue;
+                if (st == FS_FAIL_PARTS) { fail_parts(fs_message(st)); return; }
+                if (st != FS_OK) { fail(fs_message(st)); return; }
+                Rec r;
+                std::memset(&r, 0, sizeof r);
+                r.line = so.line;
+                r.min_x = std::fmin(r.line.a.x, r.line.b.x); r.max_x = std::fmax(r.line.a.x, r.line.b.x);
+                r.first_col = (uint32_t)A.sprites.size(); r.out_index = -1;   // first_col: index into A.sprites
+                r.state = ST_MAPOBJECT;
+                r.sort_key = (int16_t)so.sort_key;
+                // which wall records clip this sprite (the ones NOT behind its centre, map_objects.rs:138-140)
+                const size_t row = A.behind.size();
+                A.behind.resize(row + A.behind_words, 0u);
+                for (size_t ri = 0; ri < n_wall_recs; ri++)
+                    if (behind(recs[ri], so.centre)) A.behind[row + (ri >> 5)] |= 1u << (ri & 31);
+                so.sp.behind_off = (uint32_t)row;
+                A.sprites.push_back(so.sp);
+                mo.push_back((uint32_t)recs.size());
+                recs.push_back(r);
+                continue;
+            }
             float angle = view.angle - m.angle - kPi;
             angle += kPi / 16.0f;
             angle = std::fmod(angle, 2.0f * kPi);
@@ -617,37 +508,6 @@ struct Walker {
 
             int x0 = wrap_i16(bot.sx), x1 = wrap_i16(bot.ex);        // columns [x0, x1)
             if (x0 < x1 && (x0 < 0 || x1 > W)) { fail("map object column out of range (index panic)"); return; }
-            if (parts_mode) {
-                if (bi.w <= 0 || bi.h <= 0) { fail_parts("zero-sized bitmap"); return; }
-                FeSprite sp;
-                std::memset(&sp, 0, sizeof sp);
-                sp.x0 = x0; sp.x1 = x1;
-                sp.bsy = (float)bot.sy; sp.bsx = (float)bot.sx;
-                sp.bdelta = ((float)bot.sy - (float)bot.ey) / ((float)bot.sx - (float)bot.ex);
-                sp.tsy = (float)top.sy; sp.tsx = (float)top.sx;
-                sp.tdelta = ((float)top.sy - (float)top.ey) / ((float)top.sx - (float)top.ex);
-                sp.wall = make_wall_rec(bi, cl.line.a.x, cl.line.a.y, cl.line.b.x, cl.line.b.y, cl.start_offset, bot.sx, bot.ex,
-                                        bottom_height, top_height, 0, 0, light);
-                Rec r;
-                r.line = cl.line; r.start_offset = cl.start_offset;
-                r.bottom_height = bottom_height; r.top_height = top_height;
-                r.min_x = std::fmin(r.line.a.x, r.line.b.x); r.max_x = std::fmax(r.line.a.x, r.line.b.x);
-                r.start_x = bot.sx; r.end_x = bot.ex; r.bitmap = bitmap;
-                r.first_col = (uint32_t)A.sprites.size(); r.n_cols = 0; r.out_index = -1;   // first_col: index into A.sprites
-                r.light = light; r.offset_x = 0; r.offset_y = 0;
-                r.state = ST_MAPOBJECT; r.ext_bottom = r.ext_top = r.draw_ceiling = 0;
-                r.sort_key = (int16_t)f32_as_i16(cl.line.a.x);
-                // which wall records clip this sprite (the ones NOT behind its centre, map_objects.rs:138-140)
-                const size_t row = A.behind.size();
-                A.behind.resize(row + A.behind_words, 0u);
-                for (size_t ri = 0; ri < n_wall_recs; ri++)
-                    if (behind(recs[ri], vpv)) A.behind[row + (ri >> 5)] |= 1u << (ri & 31);
-                sp.behind_off = (uint32_t)row;
-                A.sprites.push_back(sp);
-                mo.push_back((uint32_t)recs.size());
-                recs.push_back(r);
-                continue;
-            }
             for (int x = x0; x < x1; x++) { A.top_clip[(size_t)x] = -1; A.bottom_clip[(size_t)x] = (int16_t)H; }
             if (x0 < x1) {
                 for (size_t ri = 0; ri < n_wall_recs; ri++) {         // :135-166 (only x in [x0,x1) is ever read back)

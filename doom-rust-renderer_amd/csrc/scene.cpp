@@ -390,11 +390,55 @@ int Scene::find_or_add_sprite_frame(const std::string &sprite, uint8_t frame, st
         b.first_sprite = a; b.last_sprite = e;
         int id = add_sprite_frame(b, sprite, frame);
         revision++;
+        rebuild_fs_tables();
         return id;
     } catch (const std::exception &ex) {
         err = ex.what();
         return -1;
     }
+}
+
+void Scene::rebuild_fs_tables() {
+    fs_sectors.resize(sectors.size());
+    for (size_t i = 0; i < sectors.size(); i++) {
+        const SectorRec &s = sectors[i];
+        fs_sectors[i] = FsSector{s.floor_h, s.ceil_h, s.floor_flat, s.ceil_flat, s.floor_anim, s.ceil_anim, s.ceil_tex_sky};
+    }
+    fs_anims.resize(anim.size());
+    for (size_t i = 0; i < anim.size(); i++) {
+        fs_anims[i].n = anim[i].n;
+        for (int k = 0; k < 4; k++) fs_anims[i].flat[k] = anim[i].flat[k];
+    }
+    fs_bitmaps.resize(bitmaps.size());
+    for (size_t i = 0; i < bitmaps.size(); i++)
+        fs_bitmaps[i] = FsBitmap{bitmaps[i].texel_off, (int16_t)bitmaps[i].w, (int16_t)bitmaps[i].h, bitmaps[i].top_offset, (uint16_t)bitmaps[i].has_holes};
+    fs_segs.resize(segs.size());
+    for (size_t i = 0; i < segs.size(); i++) {
+        const SegRec &sg = segs[i];
+        const LinedefRec &ld = linedefs[(size_t)sg.linedef];
+        const int fsd = sg.direction ? ld.back : ld.front, bsd = sg.direction ? ld.front : ld.back;   // segs.rs:358-362
+        FsSeg f;
+        std::memset(&f, 0, sizeof f);
+        f.v1x = vx[(size_t)sg.v1]; f.v1y = vy[(size_t)sg.v1]; f.v2x = vx[(size_t)sg.v2]; f.v2y = vy[(size_t)sg.v2];
+        f.front_sector = -1; f.back_sector = -1;
+        f.tex_mid = f.tex_low = f.tex_up = TEX_NONE;
+        if (fsd >= 0) {
+            const SidedefRec &sd = sidedefs[(size_t)fsd];
+            f.front_sector = sd.sector;
+            f.sd_xoff = sd.xoff; f.sd_yoff = sd.yoff;
+            f.tex_mid = sd.middle; f.tex_low = sd.lower; f.tex_up = sd.upper;
+            if (bsd >= 0) f.back_sector = sidedefs[(size_t)bsd].sector;
+        }
+        f.seg_offset = sg.offset;
+        f.ld_flags = (uint16_t)ld.flags;
+        fs_segs[i] = f;
+    }
+    fs_seg_leaf.assign(segs.size(), 0);
+    for (size_t l = 0; l < subsectors.size(); l++)
+        for (int i = 0; i < subsectors[l].count; i++)
+            if ((size_t)(subsectors[l].first + i) < segs.size()) fs_seg_leaf[(size_t)(subsectors[l].first + i)] = (uint16_t)l;
+    fs_mobjs.resize(mobjs.size());
+    for (size_t i = 0; i < mobjs.size(); i++) fs_mobjs[i] = FsMobj{mobjs[i].x, mobjs[i].y, mobjs[i].angle, mobjs[i].sector};
 }
 
 Scene *load_scene_from_wad(const uint8_t *bytes, size_t len, const char *map_name, std::string &err) {
@@ -584,6 +628,7 @@ Scene *load_scene_from_wad(const uint8_t *bytes, size_t len, const char *map_nam
                 sc->mobjs.push_back(m);
             }
         }
+        sc->rebuild_fs_tables();
         return sc;
     } catch (const std::exception &ex) {
         err = ex.what();

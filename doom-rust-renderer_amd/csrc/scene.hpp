@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include "fs_core.h"
+
 namespace dg {
 
 struct BitmapInfo {          // reference Bitmap (src/graphics/bitmap.rs:11-15): [y][x] Option<u8>
@@ -43,7 +45,8 @@ struct NodeRec {
     float bb[2][4];   // [0] = right child, [1] = left child: min x, min y, max x, max y over the seg vertices of the subtree
                       // (computed at load from the segs themselves, not the NODES lump's boxes, which the reference ignores)
 };
-struct SpriteFrameRec { int32_t rotate; int32_t bitmap[8]; };     // sprites.rs:20-23
+struct SpriteFrameRec { int32_t rotate; int32_t bitmap[8]; };     // sprites.rs:20-23 (= FsSpriteFrame, fs_core.h)
+static_assert(sizeof(SpriteFrameRec) == sizeof(FsSpriteFrame), "SpriteFrameRec / FsSpriteFrame");
 struct MapObjectRec {                                            // map_objects.rs:11-17, renderer-visible part
     float x, y, angle;
     int32_t sprite_frame;   // index into Scene::sprite_frames, -1 = state S_NULL (skipped: renderer/map_objects.rs:37)
@@ -82,6 +85,16 @@ struct Scene {
     std::vector<std::string> sprite_frame_keys;     // "SPRT<frame>"
     int32_t sky_bitmap = TEX_UNKNOWN;
     uint64_t revision = 0;                          // bumped by the mutable-state setters
+    // The per-seg / per-sprite inputs of fs_core.h, flattened (rebuild_fs_tables: at load and whenever bitmaps or sprite frames are added):
+    // what the host walker reads per seg and what dg_upload_scene copies to the GPU for DG_FE_DEVICE_SEGS.
+    std::vector<FsSeg> fs_segs;                     // one per seg
+    std::vector<uint16_t> fs_seg_leaf;              // subsector of every seg
+    std::vector<FsSector> fs_sectors;
+    std::vector<FsAnim> fs_anims;
+    std::vector<FsBitmap> fs_bitmaps;
+    std::vector<FsMobj> fs_mobjs;
+    const FsSpriteFrame *sprite_frames_fs() const { return reinterpret_cast<const FsSpriteFrame *>(sprite_frames.data()); }
+    void rebuild_fs_tables();
 
     // lookups used by the C-ABI
     int texture_id(const std::string &name) const;                               // Textures::get
