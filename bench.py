@@ -255,7 +255,7 @@ class DoomGpuBackend:
             self.path = self.cp.make_camera_path(seeded_route(route, path_seed), lambda x, y, d: self.scene.floor_height_at(x, y, d), PATH_FRAMES)
         B = a.batch
         self.n_slots = max(1, a.slots)                # (with fewer batches per step than slots, a slot holds the same batch every other step)
-        fe = self.dg.DG_FE_HOST if a.front_end == "host" else self.dg.DG_FE_DEVICE
+        fe = {"host": self.dg.DG_FE_HOST, "device": self.dg.DG_FE_DEVICE, "segs": self.dg.DG_FE_DEVICE_SEGS}[a.front_end]
         self.ctx = self.dg.Context(a.width, a.height, max_batch=B, slots=self.n_slots, device=self.device, host_threads=a.host_threads or default_host_threads(getattr(a, "local_world", 1)), front_end=fe)
         self.ctx.upload_scene(self.scene)
         loop = np.concatenate([self.path, self.path])
@@ -449,7 +449,7 @@ def run(args, backend_factory=DoomGpuBackend):
 
     line = None
     if rank == 0:
-        fe_name = "device column walk" if stats.get("front_end", 2) == 2 else "host span lists"
+        fe_name = {1: "host span lists", 2: "device column walk (per-seg half on the host)", 3: "device seg walk + device column walk (nothing on the host)"}[stats.get("front_end", 2)]
         line = {
             "metric": "frames/sec (fixed e1m1 camera path)", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -638,7 +638,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="frames per batch; must divide the 1000-frame path")
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--host-threads", type=int, default=0)
-    ap.add_argument("--front-end", choices=["device", "host"], default="device", help="where the per-column half of the seg / sprite processing runs")
+    ap.add_argument("--front-end", choices=["device", "host", "segs"], default="device",
+                    help="host: everything of the front end on the host; device: the per-column half on the GPU (DG_FE_DEVICE); segs: the per-seg half too (DG_FE_DEVICE_SEGS)")
     ap.add_argument("--cpu-sample", type=int, default=4, help="cpu_baseline renders every n-th path frame")
     ap.add_argument("--wad", default=None, help="IWAD file to render instead of the synthetic one (e.g. doom1.wad); the camera path is derived from the map")
     ap.add_argument("--map", default="e1m1")

@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("DOOMGPU_LIB") or os.path.join(_HERE, "libdoomgpu.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "doomgpu.h")
 
 DG_OK, DG_ERR_INVALID, DG_ERR_NO_DEVICE, DG_ERR_HIP, DG_ERR_WAD, DG_ERR_RENDER, DG_ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
-DG_FE_AUTO, DG_FE_HOST, DG_FE_DEVICE = 0, 1, 2
+DG_FE_AUTO, DG_FE_HOST, DG_FE_DEVICE, DG_FE_DEVICE_SEGS = 0, 1, 2, 3
 
 
 class DoomGpuError(RuntimeError):

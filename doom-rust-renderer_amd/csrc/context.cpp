@@ -30,6 +30,7 @@
 #include "../../include/doomgpu.h"
 #include "binner.hpp"
 #include "fe_kernels.hpp"
+#include "fs_kernels.hpp"
 #include "frontend.hpp"
 #include "kernels.hpp"
 #include "scene.hpp"
@@ -134,6 +135,8 @@ struct Slot {
     size_t flags_bytes = 0;
     uint32_t *d_flags = nullptr;                // [F] overflow flags the walk's kernels OR into; sits in front of d_events (one memset clears both)
     FeParams FP{};
+    FsParams FSP{};               // DG_FE_DEVICE_SEGS: the device seg walk in front of the column walk
+    bool fs_mode = false;         // the last submission's per-seg half ran on the GPU too
     bool fe_mode = false;         // the last submission went through the device column walk
     bool fe_check = false;        // ... and its overflow flags have not been looked at yet
     std::vector<dg_view> views;   // the views of that submission (to redo it on the host if a capacity overflowed)
@@ -186,6 +189,12 @@ struct dg_ctx {
     // device column walk
     bool fe_enabled = false;            // cfg.front_end asks for it
     bool fe_scene_ok = false;           // ... and the uploaded scene allows it (sky bitmap >= 256x128, see bin_frame)
+    // device seg walk (DG_FE_DEVICE_SEGS): the scene's per-seg tables + BSP tables in one allocation, per-batch scratch sized by the scene
+    bool fs_enabled = false, fs_scene_ok = false;
+    uint8_t *d_fs_scene = nullptr;
+    uint8_t *d_fs_scratch = nullptr;    // [cand_cnt F | ord F x n_segs] (zeroed per batch) | leaf_base F x n_leaves | cands F x cand_cap
+    size_t fs_zero_bytes = 0;
+    FsParams fs_proto{};                // scene pointers and counts, filled at upload
     uint64_t fallbacks_fe = 0;          // batches in which frames were redone because a device-side capacity was exceeded (dg_ctx_fallbacks)
     uint64_t redone_frames = 0;         // frames redone through the host list path, one at a time (dg_ctx_redone_frames)
     DevRSpan *d_redo_rspans = nullptr;  // resolved spans of ONE frame being redone (allocated on first use)
@@ -256,6 +265,8 @@ void free_ctx(dg_ctx *c) {
     if (c->d_fe_cnt) (void)hipFree(c->d_fe_cnt);
     if (c->d_fe_cspans) (void)hipFree(c->d_fe_cspans);
     if (c->d_fe_recs) (void)hipFree(c->d_fe_recs);
+    if (c->d_fs_scene) (void)hipFree(c->d_fs_scene);
+    if (c->d_fs_scratch) (void)hipFree(c->d_fs_scratch);
     delete c;
 }
 
@@ -326,7 +337,7 @@ int build_batch_host(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_li
     P.n_frames = n;
     s.max_spans = max_spans; s.n_spans = spans; s.covered = covered; s.n_frames = n; s.n_walls = walls; s.n_planes = planes;
     s.list_bytes = total;
-    s.fe_mode = false; s.fe_check = false;
+    s.fe_mode = false; s.fs_mode = false; s.fe_check = false;
     s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIP_TRY(hipMemcpyAsync(s.d_lists, s.h_lists, total, hipMemcpyHostToDevice, s.stream));
     return DG_OK;
@@ -434,7 +445,7 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_vie
     P.n_frames = n;
     s.max_spans = 0; s.n_spans = 0; s.covered = 0; s.n_frames = n; s.n_walls = parts; s.n_planes = sprites;
     s.list_bytes = total;
-    s.fe_mode = true; s.fe_check = false;
+    s.fe_mode = true; s.fs_mode = false; s.fe_check = false;
     s.views.assign(views, views + n);
     s.keep_states(states, n);
     s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -442,7 +453,155 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_vie
     return DG_OK;
 }
 
+// DG_FE_DEVICE_SEGS: the scene's per-seg / per-sprite tables and BSP tables (Scene::rebuild_fs_tables) in one device allocation, and the
+// per-batch scratch of the seg walk, whose size follows the scene (segs, leaves).
+int upload_fs_scene(dg_ctx *c, const Scene &sc) {
+    if (c->d_fs_scene) { (void)hipFree(c->d_fs_scene); c->d_fs_scene = nullptr; }
+    if (c->d_fs_scratch) { (void)hipFree(c->d_fs_scratch); c->d_fs_scratch = nullptr; }
+    struct Piece { const void *src; size_t bytes; size_t at; };
+    std::vector<Piece> pieces;
+    size_t total = 0;
+    auto add = [&](const void *src, size_t bytes) { pieces.push_back(Piece{src, bytes, total}); total = align_up(total + std::max<size_t>(bytes, 16), 256); return pieces.size() - 1; };
+    const size_t i_segs = add(sc.fs_segs.data(), sc.fs_segs.size() * sizeof(FsSeg));
+    const size_t i_leaf = add(sc.fs_seg_leaf.data(), sc.fs_seg_leaf.size() * 2);
+    const size_t i_first = add(sc.fs_leaf_first.data(), sc.fs_leaf_first.size() * 4);
+    const size_t i_sectors = add(sc.fs_sectors.data(), sc.fs_sectors.size() * sizeof(FsSector));
+    const size_t i_anims = add(sc.fs_anims.data(), sc.fs_anims.size() * sizeof(FsAnim));
+    const size_t i_bitmaps = add(sc.fs_bitmaps.data(), sc.fs_bitmaps.size() * sizeof(FsBitmap));
+    const size_t i_sky = add(sc.flat_sky.data(), sc.flat_sky.size());
+    const size_t i_mobjs = add(sc.fs_mobjs.data(), sc.fs_mobjs.size() * sizeof(FsMobj));
+    const size_t i_sframes = add(sc.sprite_frames.data(), sc.sprite_frames.size() * sizeof(SpriteFrameRec));
+    const size_t i_nodes = add(sc.fs_nodes.data(), sc.fs_nodes.size() * sizeof(FsNode));
+    const size_t i_aoff = add(sc.fs_anc_off.data(), sc.fs_anc_off.size() * 4);
+    const size_t i_anc = add(sc.fs_anc.data(), sc.fs_anc.size() * 4);
+    HIP_TRY(hipMalloc((void **)&c->d_fs_scene, total));
+    for (const Piece &p : pieces)
+        if (p.bytes) HIP_TRY(hipMemcpy(c->d_fs_scene + p.at, p.src, p.bytes, hipMemcpyHostToDevice));
+    FsParams &P = c->fs_proto;
+    P = FsParams{};
+    P.k = c->dk;
+    auto at = [&](size_t i) { return c->d_fs_scene + pieces[i].at; };
+    P.segs = reinterpret_cast<const FsSeg *>(at(i_segs)); P.seg_leaf = reinterpret_cast<const uint16_t *>(at(i_leaf)); P.leaf_first = reinterpret_cast<const uint32_t *>(at(i_first));
+    P.sectors = reinterpret_cast<const FsSector *>(at(i_sectors)); P.anims = reinterpret_cast<const FsAnim *>(at(i_anims));
+    P.bitmaps = reinterpret_cast<const FsBitmap *>(at(i_bitmaps)); P.flat_sky = at(i_sky);
+    P.mobjs = reinterpret_cast<const FsMobj *>(at(i_mobjs)); P.sframes = reinterpret_cast<const FsSpriteFrame *>(at(i_sframes));
+    P.nodes = reinterpret_cast<const FsNode *>(at(i_nodes)); P.anc_off = reinterpret_cast<const uint32_t *>(at(i_aoff)); P.anc = reinterpret_cast<const uint32_t *>(at(i_anc));
+    P.n_segs = (uint32_t)sc.segs.size(); P.n_leaves = (uint32_t)sc.subsectors.size(); P.n_mobjs = (uint32_t)sc.mobjs.size();
+    P.cand_cap = (uint32_t)std::min<size_t>(5 * sc.segs.size(), FS_CAND_CAP_MAX);
+    // scratch: [cand_cnt | ord] are zeroed before every walk with one memset
+    const size_t F = (size_t)c->cfg.max_batch;
+    const size_t off_ord = align_up(F * 4, 256);
+    c->fs_zero_bytes = off_ord + F * P.n_segs * 4;
+    const size_t off_leaf = align_up(c->fs_zero_bytes, 256);
+    const size_t off_cands = align_up(off_leaf + F * P.n_leaves * 4, 256);
+    const size_t off_lite = align_up(off_cands + F * (size_t)P.cand_cap * sizeof(FsCand), 256);
+    HIP_TRY(hipMalloc((void **)&c->d_fs_scratch, off_lite + F * (size_t)P.cand_cap * 8));
+    P.cand_cnt = reinterpret_cast<uint32_t *>(c->d_fs_scratch);
+    P.ord = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_ord);
+    P.leaf_base = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_leaf);
+    P.cands = reinterpret_cast<FsCand *>(c->d_fs_scratch + off_cands);
+    P.cand_lite = reinterpret_cast<uint2 *>(c->d_fs_scratch + off_lite);
+    c->fs_scene_ok = true;
+    return DG_OK;
+}
+
+// DG_FE_DEVICE_SEGS: nothing of the front end runs on the host.  Per frame it ships the view (trig filled) and the DevFrame header,
+// per batch the scene's current light levels and map-object states; dg_fs_* then write the same record arrays build_batch_fe packs,
+// with fixed per-frame strides (fs_frame.h), into the slot's record slab.
+int build_batch_fs(dg_ctx *c, Slot &s, const dg_view *views, int n) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n <= 0 || n > c->cfg.max_batch) return set_err(DG_ERR_CAPACITY, "batch size outside [1, max_batch]");
+    const Scene &sc = *c->scene;
+    if (sc.texel_idx.size() != c->uploaded_texels) return set_err(DG_ERR_INVALID, "the scene decoded new bitmaps since dg_upload_scene: upload it again");
+    const int W = c->cfg.width;
+    const size_t nb1 = (size_t)(W + FE_BIN_W - 1) / FE_BIN_W + 1;
+    const uint32_t span_stride = (uint32_t)(c->span_cap_per_batch / (size_t)c->cfg.max_batch);
+    // uploaded part
+    const size_t off_frames = 0;
+    const size_t off_views = align_up(off_frames + (size_t)n * sizeof(DevFrame), 256);
+    const size_t off_lights = align_up(off_views + (size_t)n * sizeof(dg_view), 256);
+    const size_t off_mstate = align_up(off_lights + sc.sectors.size() * 2, 256);
+    const size_t upload = align_up(off_mstate + sc.mobjs.size() * 4, 256);
+    // device-written part
+    const size_t off_ff = upload;
+    const size_t off_parts = align_up(off_ff + (size_t)n * sizeof(FeFrame), 256);
+    const size_t off_sprites = align_up(off_parts + (size_t)n * FS_PART_CAP * sizeof(FePart), 256);
+    const size_t off_behind = align_up(off_sprites + (size_t)n * FS_SPRITE_CAP * sizeof(FeSprite), 256);
+    const size_t off_sky = align_up(off_behind + (size_t)n * FS_SPRITE_CAP * FS_BEHIND_WORDS * 4, 256);
+    const size_t off_boff = align_up(off_sky + (size_t)n * FS_SKY_CAP * 4, 256);
+    const size_t off_sboff = align_up(off_boff + (size_t)n * nb1 * 4, 256);
+    const size_t off_bins = align_up(off_sboff + (size_t)n * nb1 * 4, 256);
+    const size_t off_sbins = align_up(off_bins + (size_t)n * FS_BIN_CAP * 2, 256);
+    const size_t total = off_sbins + (size_t)n * FS_SBIN_CAP * 2;
+    if (total > c->fe_slab_cap) return kPartsUnsupported;
+    s.views.assign(views, views + n);
+    c->pool->parallel_for(n, [&](int i, int) {
+        dg_view &v = s.views[(size_t)i];
+        fill_view_trig(v);
+        DevFrame hdr = make_frame_header(v);
+        hdr.span_base = (uint32_t)i * span_stride;
+        std::memcpy(s.h_fe + off_frames + (size_t)i * sizeof(DevFrame), &hdr, sizeof hdr);
+        std::memcpy(s.h_fe + off_views + (size_t)i * sizeof(dg_view), &v, sizeof v);
+    });
+    int16_t *lights = reinterpret_cast<int16_t *>(s.h_fe + off_lights);
+    for (size_t i = 0; i < sc.sectors.size(); i++) lights[i] = sc.sectors[i].light;
+    int32_t *mstate = reinterpret_cast<int32_t *>(s.h_fe + off_mstate);
+    for (size_t i = 0; i < sc.mobjs.size(); i++) mstate[i] = sc.mobjs[i].sprite_frame < 0 ? -1 : sc.mobjs[i].sprite_frame * 2 + (sc.mobjs[i].full_bright ? 1 : 0);
+
+    FsParams &Q = s.FSP;
+    Q = c->fs_proto;
+    Q.k = c->dk;
+    Q.sector_light = reinterpret_cast<const int16_t *>(s.d_fe + off_lights);
+    Q.mobj_state = reinterpret_cast<const int32_t *>(s.d_fe + off_mstate);
+    Q.views = reinterpret_cast<const dg_view *>(s.d_fe + off_views);
+    Q.n_frames = n;
+    Q.flags = s.d_flags;
+    Q.fframes = reinterpret_cast<FeFrame *>(s.d_fe + off_ff);
+    Q.parts = reinterpret_cast<FePart *>(s.d_fe + off_parts);
+    Q.sprites = reinterpret_cast<FeSprite *>(s.d_fe + off_sprites);
+    Q.behind = reinterpret_cast<uint32_t *>(s.d_fe + off_behind);
+    Q.sky_parts = reinterpret_cast<uint32_t *>(s.d_fe + off_sky);
+    Q.bin_off = reinterpret_cast<uint32_t *>(s.d_fe + off_boff);
+    Q.sbin_off = reinterpret_cast<uint32_t *>(s.d_fe + off_sboff);
+    Q.bin_parts = reinterpret_cast<uint16_t *>(s.d_fe + off_bins);
+    Q.sbin_sprites = reinterpret_cast<uint16_t *>(s.d_fe + off_sbins);
+    FeParams &F = s.FP;
+    F.scene = c->dscene;
+    F.k = c->dk;
+    F.frames = reinterpret_cast<const DevFrame *>(s.d_fe + off_frames);
+    F.fframes = Q.fframes; F.parts = Q.parts; F.sprites = Q.sprites; F.behind = Q.behind; F.sky_parts = Q.sky_parts;
+    F.max_sky_slots = FS_SKY_CAP;
+    F.bin_off = Q.bin_off; F.sbin_off = Q.sbin_off; F.bin_parts = Q.bin_parts; F.sbin_sprites = Q.sbin_sprites;
+    F.cspans = c->d_fe_cspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt;
+    F.events = s.d_events;
+    F.flags = s.d_flags;
+    F.host_flags = s.h_status; F.totals = s.h_status + c->cfg.max_batch;
+    F.col_off = s.d_fe_coloff; F.rspans = s.d_rspans;
+    F.n_frames = n; F.span_stride = span_stride; F.w64 = (uint32_t)((W + 63) / 64); F.col_slots = c->fe_col_slots;
+    RasterParams &P = s.P;
+    P.scene = c->dscene;
+    P.k = c->dk;
+    P.frames = F.frames;
+    P.col_off = s.d_fe_coloff;
+    P.walls = nullptr; P.planes = nullptr; P.spans = nullptr;
+    P.rspans = s.d_rspans;
+    P.fb = s.d_fb;
+    P.row_tab = c->d_row_tab;
+    P.n_frames = n;
+    s.max_spans = 0; s.n_spans = 0; s.covered = 0; s.n_frames = n; s.n_walls = 0; s.n_planes = 0;
+    s.list_bytes = upload;
+    s.fe_mode = true; s.fs_mode = true; s.fe_check = false;
+    s.keep_states(nullptr, n);
+    s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    HIP_TRY(hipMemcpyAsync(s.d_fe, s.h_fe, upload, hipMemcpyHostToDevice, s.stream));
+    return DG_OK;
+}
+
 int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *given, int n, const dg_view_state *states = nullptr) {
+    if (!given && !states && c->fs_enabled && c->fs_scene_ok) {
+        const int rc = build_batch_fs(c, s, views, n);
+        if (rc != kPartsUnsupported) return rc;
+    }
     if (!given && c->fe_enabled && c->fe_scene_ok) {
         const int rc = build_batch_fe(c, s, views, n, states);
         if (rc != kPartsUnsupported) return rc;
@@ -473,7 +632,11 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
         std::memset(s.h_status, 0, (size_t)2 * (size_t)c->cfg.max_batch * 4);
         const size_t ev_bytes = (size_t)3 * (size_t)s.FP.n_frames * s.FP.max_sky_slots * s.FP.w64 * 8;   // all three event kinds (fe_event_words)
         HIP_TRY(hipMemsetAsync(s.d_flags, 0, s.flags_bytes + ev_bytes, ks));                            // the overflow flags and the event bits behind them
-        HIP_TRY(launch_fe(s.FP, ks, s.ev_start, s.ev_setup));
+        if (s.fs_mode) {                                                                                // the seg walk writes what the column walk reads
+            HIP_TRY(hipMemsetAsync(c->d_fs_scratch, 0, c->fs_zero_bytes, ks));
+            HIP_TRY(launch_fs(s.FSP, ks, s.ev_start));
+        }
+        HIP_TRY(launch_fe(s.FP, ks, s.fs_mode ? nullptr : s.ev_start, s.ev_setup));
     } else {
         HIP_TRY(launch_setup(s.P, s.max_spans, ks, s.ev_start, s.ev_setup));
     }
@@ -679,7 +842,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         return set_err(DG_ERR_INVALID, "width/height must be positive, width % 4 == 0, both <= 16384");
     if (cfg->max_batch <= 0 || cfg->max_batch > 65535 || cfg->slots <= 0 || cfg->slots > 16)
         return set_err(DG_ERR_INVALID, "max_batch must be in [1, 65535], slots in [1, 16]");
-    if (cfg->front_end < DG_FE_AUTO || cfg->front_end > DG_FE_DEVICE) return set_err(DG_ERR_INVALID, "front_end must be DG_FE_AUTO, DG_FE_HOST or DG_FE_DEVICE");
+    if (cfg->front_end < DG_FE_AUTO || cfg->front_end > DG_FE_DEVICE_SEGS) return set_err(DG_ERR_INVALID, "front_end must be DG_FE_AUTO, DG_FE_HOST, DG_FE_DEVICE or DG_FE_DEVICE_SEGS");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(DG_ERR_NO_DEVICE, "no HIP device (this library has no CPU path)");
     if (cfg->device < 0 || cfg->device >= ndev) return set_err(DG_ERR_NO_DEVICE, "device ordinal out of range");
@@ -718,6 +881,7 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
                              align_up(c->wall_cap_per_batch * sizeof(DevWallRec), 256) +
                              align_up(c->plane_cap_per_batch * sizeof(DevPlaneRec), 256) + c->span_cap_per_batch * sizeof(DevSpan) + 1024;
     c->fe_enabled = cfg->front_end != DG_FE_HOST;
+    c->fs_enabled = cfg->front_end == DG_FE_DEVICE_SEGS;
     if (c->fe_enabled) {
         // Scratch slots per screen column (spans and wall-record columns).  A column that needs more sends its batch through
         // the host list path; DOOMGPU_FE_COLUMN_SLOTS trades scratch HBM (24 B x slots x width x max_batch) against that.
@@ -831,6 +995,11 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     c->scene = &sc;
     c->fe_scene_ok = sky.w >= 256 && sky.h >= 128;    // a smaller sky bitmap is an index panic only when a sky visplane is drawn: host path
     c->uploaded_texels = sc.texel_idx.size();
+    c->fs_scene_ok = false;
+    if (c->fs_enabled && c->fe_scene_ok && sc.fs_ok && c->cfg.width <= FS_MAX_W) {
+        const int rc = upload_fs_scene(c, sc);
+        if (rc) return rc;
+    }
     return DG_OK;
 }
 
@@ -1036,7 +1205,7 @@ int dg_slot_timing(dg_ctx *c, int slot, dg_timing *out) {
     out->n_spans = s.n_spans; out->n_frames = (uint64_t)s.n_frames; out->covered_pixels = s.covered;
     out->host_ms = s.host_ms; out->list_bytes = s.list_bytes;
     out->n_walls = s.n_walls; out->n_planes = s.n_planes;
-    out->front_end = s.fe_mode ? DG_FE_DEVICE : DG_FE_HOST;
+    out->front_end = s.fs_mode ? DG_FE_DEVICE_SEGS : s.fe_mode ? DG_FE_DEVICE : DG_FE_HOST;
     return DG_OK;
 }
 

@@ -1,0 +1,464 @@
+// fs_frame.h — the device seg walk (DG_FE_DEVICE_SEGS): the ORDER-DEPENDENT half of the per-seg front end, one wavefront per frame.
+//
+// The reference walks the BSP front to back (src/renderer/mod.rs:61-104) and every step of it is cheap, branchy and order-dependent
+// only through three things: the order itself, which earlier full-height walls hide a later part (the host walker's solid-column
+// intervals, frontend.cpp), and the sprite / masked-wall draw sequence (renderer/map_objects.rs:216-240).  The GPU does it in three
+// kernels per batch (fs_kernels.hip), with the arithmetic of fs_core.h:
+//   dg_fs_order   one lane per (frame, BSP leaf): position of the leaf's first seg in the reference's visit order — the sum, over the
+//                 leaf's ancestors on whose BACK side it lies for this viewer, of the seg count of the ancestor's front subtree;
+//   dg_fs_segs    one lane per (frame, seg): process_seg + the head of every process_sidedef call (transform, clip, projection, pegging,
+//                 the finished FePart records), written to a per-frame candidate area; ord[frame][visit position] says where;
+//   dg_fs_frame   one wavefront per frame, the phases below: candidates in visit order -> hidden-part culling -> the frame's FePart list;
+//                 the map objects (FeSprite), their behind-bit rows and draw sequence; the column bins; the FeFrame header —
+//                 exactly the arrays the host ships in DG_FE_DEVICE mode, which the column walk (fe_kernels.hip) then consumes unchanged.
+// A frame the reference would panic on, or one that exceeds a capacity below, is flagged (FE_OVF_SEGS) and redone by the host.
+//
+// The phases are plain functions of (lane, shared state): inside a phase the 64 lanes touch disjoint data (or use atomics), between
+// phases stands a barrier.  tests/emul runs them on the CPU — lanes one after another — against the host walker's records.
+#pragma once
+#include "../../include/doomgpu.h"
+#include "fe_core.h"
+#include "fs_core.h"
+
+#if !defined(__HIPCC__)
+struct uint2 { uint32_t x, y; };
+#endif
+
+namespace dg {
+
+constexpr uint32_t FE_OVF_SEGS = 8;            // the device seg walk gave the frame up (reference panic / capacity): redone on the host
+constexpr int FS_LANES = 256;                  // threads of dg_fs_frame's workgroup (four wavefronts per frame)
+constexpr int FS_BLOCK = 16;                   // lanes per block of the two-level prefix sums
+constexpr uint32_t FS_CAND_CAP_MAX = 16384;    // candidate parts of one frame (visible segs x their process_sidedef calls): FsParams.cand_cap <= this
+constexpr uint32_t FS_VIS_CAP = 3072;          // visible segs of one frame (no subtree culling here: every seg inside the frustum that faces the viewer)
+constexpr uint32_t FS_PART_CAP = 256;          // parts of one frame after the hidden-part culling
+constexpr uint32_t FS_CL_CAP = 4096;           // candidate parts of one frame the culling stages in shared memory
+constexpr int FS_MAX_W = 3072;                 // widest frame the culling's per-column table holds (wider: DG_FE_DEVICE)
+constexpr int FS_GROUP = 16;                   // lanes that share one candidate in the column passes of the culling
+constexpr uint32_t FS_SPRITE_CAP = 256;        // visible map objects of one frame
+constexpr uint32_t FS_SKY_CAP = 64;            // parts of one frame that may produce sky visplanes (event rows of dg_fe_gaps)
+constexpr uint32_t FS_BIN_CAP = 4096;          // (part, column bin) pairs of one frame
+constexpr uint32_t FS_SBIN_CAP = 2048;         // (sprite, column bin) pairs
+constexpr uint32_t FS_BEHIND_WORDS = FS_PART_CAP / 32;
+
+struct FsNode { float x, y, dx, dy; uint32_t segs_right, segs_left; };       // partition line + seg counts of the two subtrees
+static_assert(sizeof(FsNode) == 24, "FsNode layout");
+
+struct FsCand {                                // one process_sidedef call that reached its column loop (dg_fs_segs)
+    FePart part;
+    float ax, ay, bx, by;                      // the seg's clipped line (is_behind_vertex, bitmap_render.rs:137-165)
+};
+static_assert(sizeof(FsCand) == 144, "FsCand layout");
+
+struct FsParams {
+    DevConsts k;
+    // scene (immutable per upload)
+    const FsSeg *segs; const uint16_t *seg_leaf; const uint32_t *leaf_first;
+    const FsSector *sectors; const FsAnim *anims; const FsBitmap *bitmaps; const uint8_t *flat_sky;
+    const FsMobj *mobjs; const FsSpriteFrame *sframes;
+    const FsNode *nodes; const uint32_t *anc_off; const uint32_t *anc;           // per leaf: its ancestors, root first: node | (lies in the LEFT subtree) << 31
+    uint32_t n_segs, n_leaves, n_mobjs;
+    uint32_t cand_cap;                         // candidate slots per frame in `cands` (min(5 n_segs, FS_CAND_CAP_MAX))
+    // game state of this batch (scene-wide values as of submission)
+    const int16_t *sector_light;               // [n_sectors]
+    const int32_t *mobj_state;                 // [n_mobjs] sprite_frame * 2 + full_bright, negative: S_NULL
+    // per frame
+    const dg_view *views;                      // [n_frames], trig filled
+    int32_t n_frames;
+    // scratch (shared by all slots: every kernel runs on the ctx's one stream)
+    uint32_t *leaf_base;                       // [frame][n_leaves]
+    uint32_t *ord;                             // [frame][n_segs]: 0 = seg not visible, else (first candidate << 3 | calls), zeroed per batch
+    uint32_t *cand_cnt;                        // [frame], zeroed per batch
+    FsCand *cands;                             // [frame][cand_cap]
+    uint2 *cand_lite;                          // [frame][cand_cap]: x = sx | ex << 16, y = FEP_* flags | 1 << 31 when the slot holds a part (what the culling reads)
+    uint32_t *flags;                           // [frame] FE_OVF_* (the column walk's flag words)
+    // outputs: the DG_FE_DEVICE record arrays with fixed per-frame strides
+    FeFrame *fframes; FePart *parts; FeSprite *sprites; uint32_t *behind; uint32_t *sky_parts;
+    uint32_t *bin_off; uint16_t *bin_parts; uint32_t *sbin_off; uint16_t *sbin_sprites;
+};
+
+// ---- dg_fs_order: one (frame, leaf) --------------------------------------------------------------------------------------------------
+DG_HD void fs_leaf_order(const FsParams &P, int f, uint32_t leaf) {
+    const dg_view &v = P.views[f];
+    const V2 ppos{v.x, v.y};
+    uint32_t base = 0;
+    for (uint32_t i = P.anc_off[leaf]; i < P.anc_off[leaf + 1]; i++) {
+        const uint32_t a = P.anc[i];
+        const FsNode &n = P.nodes[a & 0x7fffffffu];
+        const bool is_left = left_of(ppos, Seg2{V2{n.x, n.y}, V2{n.x + n.dx, n.y + n.dy}});     // mod.rs:70-77: the viewer's side is visited first
+        const bool leaf_left = (a >> 31) != 0;
+        if (leaf_left != is_left) base += is_left ? n.segs_left : n.segs_right;                 // the whole front subtree comes before this leaf
+    }
+    P.leaf_base[(size_t)f * P.n_leaves + leaf] = base;
+}
+
+// ---- dg_fs_segs: one (frame, seg) ----------------------------------------------------------------------------------------------------
+DG_HD void fs_flag(const FsParams &P, int f, uint32_t bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(&P.flags[f], bits);
+#else
+    P.flags[f] |= bits;
+#endif
+}
+DG_HD uint32_t fs_take(uint32_t *counter, uint32_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(counter, n);
+#else
+    const uint32_t v = *counter; *counter = v + n; return v;
+#endif
+}
+DG_HD void fs_seg_lane(const FsParams &P, int f, uint32_t si) {
+    const dg_view &v = P.views[f];
+    const FsSeg &sg = P.segs[si];
+    FsSegOut so;
+    const int16_t light = sg.front_sector >= 0 ? P.sector_light[sg.front_sector] : (int16_t)0;
+    const int32_t st = fs_seg(P.k, sg, P.sectors, P.anims, V2{v.x, v.y}, v.cos_na, v.sin_na, v.floor_height + 41.0f, v.timestamp, light, so);
+    if (st == FS_SKIP) return;
+    if (st != FS_OK) { fs_flag(P, f, FE_OVF_SEGS); return; }
+    const uint32_t first = fs_take(&P.cand_cnt[f], (uint32_t)so.n_calls);
+    if (first + (uint32_t)so.n_calls > P.cand_cap) { fs_flag(P, f, FE_OVF_SEGS); return; }
+    FsCand *out = P.cands + (size_t)f * P.cand_cap + first;
+    for (int i = 0; i < so.n_calls; i++) {
+        FsCand &c = out[i];
+        const int32_t ps = fs_part(P.k, so, so.call[i], P.bitmaps, P.flat_sky, v.floor_height, c.part);
+        uint2 &lite = P.cand_lite[(size_t)f * P.cand_cap + first + (uint32_t)i];
+        if (ps == FS_SKIP) { lite = uint2{0u, 0u}; continue; }                 // nothing (a zero-width part)
+        if (ps != FS_OK) { fs_flag(P, f, FE_OVF_SEGS); lite = uint2{0u, 0u}; continue; }
+        lite = uint2{(uint32_t)c.part.sx | ((uint32_t)c.part.ex << 16), c.part.flags | 0x80000000u};
+        c.ax = so.cl.line.a.x; c.ay = so.cl.line.a.y; c.bx = so.cl.line.b.x; c.by = so.cl.line.b.y;
+    }
+    const uint32_t leaf = P.seg_leaf[si];
+    const uint32_t pos = P.leaf_base[(size_t)f * P.n_leaves + leaf] + (si - P.leaf_first[leaf]);
+    P.ord[(size_t)f * P.n_segs + pos] = (first << 3) | (uint32_t)so.n_calls;
+}
+
+// ---- dg_fs_frame: one wavefront per frame --------------------------------------------------------------------------------------------
+struct FsShared {                              // LDS on the GPU
+    uint32_t lane_cnt[FS_LANES], block_sum[FS_LANES / FS_BLOCK];
+    union {                                    // (the visit-ordered seg list is dead once the candidates are staged)
+        uint32_t vis[FS_VIS_CAP];              // ord entries of the visible segs, in visit order
+        uint32_t first[FS_MAX_W];              // per screen column: visit index of the first full-height solid candidate that spans it
+    };
+    uint32_t n_vis;
+    // every candidate part of the frame in visit order: x = sx | ex << 16, y = FEP_* (bits 0-7) | is-a-part << 8 | candidate slot << 12
+    // | survives the hidden-part culling << 9
+    uint2 cl[FS_CL_CAP];
+    uint32_t n_cl;
+    // kept parts
+    uint32_t kept_cand[FS_PART_CAP];           // candidate index
+    int16_t kept_sky[FS_PART_CAP];
+    uint16_t kept_sx[FS_PART_CAP], kept_ex[FS_PART_CAP];
+    uint16_t kept_t[FS_PART_CAP];              // two-sided middle parts: order index of the first sprite they are drawn behind (0xffff: none; 0xfffe: not two-sided)
+    float kline[FS_PART_CAP][4];
+    uint32_t n_parts, n_sky;
+    // sprites
+    float s_centre[FS_SPRITE_CAP][2], s_mid[FS_SPRITE_CAP][2];
+    int16_t s_key[FS_SPRITE_CAP];
+    uint16_t s_order[FS_SPRITE_CAP], s_x0b[FS_SPRITE_CAP], s_x1b[FS_SPRITE_CAP];   // place in the far-to-near order; first / last column bin (x0b > x1b: no columns)
+    uint32_t n_sprites;
+    uint32_t fail;
+};
+
+// phase 0 (lane 0): reset
+DG_HD void fs_ph_init(FsShared &S) { S.n_vis = 0; S.n_cl = 0; S.n_parts = 0; S.n_sky = 0; S.n_sprites = 0; S.fail = 0; }
+
+// Two-level exclusive prefix over lane_cnt[]: a phase in which the first FS_LANES / FS_BLOCK lanes sum their block, then any lane adds
+// the blocks before its own and the lanes before it in its block (at most 2 FS_BLOCK reads instead of FS_LANES).
+DG_HD void fs_ph_block_sums(FsShared &S, int lane) {
+    if (lane >= FS_LANES / FS_BLOCK) return;
+    uint32_t sum = 0;
+    for (int i = 0; i < FS_BLOCK; i++) sum += S.lane_cnt[lane * FS_BLOCK + i];
+    S.block_sum[lane] = sum;
+}
+DG_HD uint32_t fs_lane_offset(const FsShared &S, int lane) {
+    uint32_t at = 0;
+    for (int b = 0; b < lane / FS_BLOCK; b++) at += S.block_sum[b];
+    for (int l = lane / FS_BLOCK * FS_BLOCK; l < lane; l++) at += S.lane_cnt[l];
+    return at;
+}
+
+// phases 1a / 1b / 1c: the visible segs in visit order.  Lane l owns the slice [l * per, (l + 1) * per) of the frame's ord row.
+DG_HD void fs_ph_count(const FsParams &P, FsShared &S, int f, int lane) {
+    const uint32_t per = (P.n_segs + FS_LANES - 1) / FS_LANES;
+    const uint32_t *ord = P.ord + (size_t)f * P.n_segs;
+    uint32_t n = 0;
+    for (uint32_t i = (uint32_t)lane * per; i < ((uint32_t)lane + 1) * per && i < P.n_segs; i++) n += ord[i] != 0u;
+    S.lane_cnt[lane] = n;
+}
+DG_HD void fs_ph_gather(const FsParams &P, FsShared &S, int f, int lane) {
+    const uint32_t per = (P.n_segs + FS_LANES - 1) / FS_LANES;
+    const uint32_t *ord = P.ord + (size_t)f * P.n_segs;
+    uint32_t at = fs_lane_offset(S, lane);
+    if (lane == FS_LANES - 1) {
+        S.n_vis = at + S.lane_cnt[lane];
+        if (S.n_vis > FS_VIS_CAP) { S.fail = 1; S.n_vis = 0; }
+    }
+    for (uint32_t i = (uint32_t)lane * per; i < ((uint32_t)lane + 1) * per && i < P.n_segs; i++)
+        if (ord[i] != 0u && at < FS_VIS_CAP) S.vis[at++] = ord[i];
+}
+// ---- the hidden-part culling ---------------------------------------------------------------------------------------------------------
+// The host walker drops a part whose columns [sx, ex] are all spanned by full-height solid parts it met EARLIER in the visit order
+// (frontend.cpp process_sidedef: solid_cols.covers, then solid_cols.add for a solid part that survives).  A dropped solid part lies
+// inside the union already, so that union is simply "every solid candidate before this one" — no decision depends on an earlier
+// decision, and the test can run for all candidates at once:  first[c] = visit index of the first solid candidate spanning column c;
+// candidate k survives iff some column of it has first[c] >= k.
+// phases 2a / 2b: the candidates of the visible segs, in visit order, into cl[].  Lane l owns the slice [l * per, ..) of vis[].
+DG_HD void fs_ph_cand_count(FsShared &S, int lane) {
+    const uint32_t per = (S.n_vis + FS_LANES - 1) / FS_LANES;
+    uint32_t n = 0;
+    for (uint32_t i = (uint32_t)lane * per; i < ((uint32_t)lane + 1) * per && i < S.n_vis; i++) n += S.vis[i] & 7u;
+    S.lane_cnt[lane] = n;
+}
+DG_HD void fs_ph_cand_stage(const FsParams &P, FsShared &S, int f, int lane) {
+    const uint32_t per = (S.n_vis + FS_LANES - 1) / FS_LANES;
+    uint32_t at = fs_lane_offset(S, lane);
+    if (lane == FS_LANES - 1) {
+        S.n_cl = at + S.lane_cnt[lane];
+        if (S.n_cl > FS_CL_CAP) { S.fail = 1; S.n_cl = 0; }
+    }
+    for (uint32_t i = (uint32_t)lane * per; i < ((uint32_t)lane + 1) * per && i < S.n_vis; i++) {
+        const uint32_t e = S.vis[i];
+        const uint2 *c = P.cand_lite + (size_t)f * P.cand_cap + (e >> 3);
+        for (uint32_t j = 0; j < (e & 7u); j++, at++) {
+            if (at >= FS_CL_CAP) continue;
+            const uint2 q = c[j];
+            S.cl[at] = uint2{q.x, (q.y & 0xffu) | ((q.y >> 31) << 8) | (((e >> 3) + j) << 12)};
+        }
+    }
+}
+// phase 2c: the column table starts empty (it overlays vis[], which is dead from here on)
+DG_HD void fs_ph_first_clear(const FsParams &P, FsShared &S, int lane) {
+    for (int c = lane; c < P.k.W; c += FS_LANES) S.first[c] = 0xffffffffu;
+}
+DG_HD void fs_or_u32(uint32_t *p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(p, v);
+#else
+    *p |= v;
+#endif
+}
+DG_HD void fs_min_u32(uint32_t *p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
+#endif
+}
+// phases 2d / 2e: FS_GROUP lanes share a candidate and stride over its columns; the groups take the candidates round robin.
+DG_HD void fs_ph_solids(FsShared &S, int lane) {
+    if (S.fail) return;
+    const uint32_t g = (uint32_t)lane / FS_GROUP, sub = (uint32_t)lane % FS_GROUP;
+    for (uint32_t k = g; k < S.n_cl; k += FS_LANES / FS_GROUP) {
+        const uint2 q = S.cl[k];
+        if (!(q.y & 0x100u) || !fs_part_is_solid(q.y & 0xffu)) continue;
+        const uint32_t sx = q.x & 0xffffu, ex = q.x >> 16;
+        for (uint32_t c = sx + sub; c <= ex; c += FS_GROUP) fs_min_u32(&S.first[c], k);
+    }
+}
+DG_HD void fs_ph_keep(FsShared &S, int lane) {
+    if (S.fail) return;
+    const uint32_t g = (uint32_t)lane / FS_GROUP, sub = (uint32_t)lane % FS_GROUP;
+    for (uint32_t k = g; k < S.n_cl; k += FS_LANES / FS_GROUP) {
+        const uint2 q = S.cl[k];
+        if (!(q.y & 0x100u)) continue;
+        const uint32_t sx = q.x & 0xffffu, ex = q.x >> 16;
+        bool open = false;
+        for (uint32_t c = sx + sub; c <= ex; c += FS_GROUP) open |= S.first[c] >= k;
+        if (open) fs_or_u32(&S.cl[k].y, 0x200u);
+    }
+}
+// phases 2f / 2g: the survivors get their place in the frame's part list (and their sky event slot).  Lane l owns a slice of cl[];
+// lane_cnt packs (survivors | survivors that want a sky slot << 16).
+DG_HD void fs_ph_kept_count(FsShared &S, int lane) {
+    const uint32_t per = (S.n_cl + FS_LANES - 1) / FS_LANES;
+    uint32_t n = 0;
+    for (uint32_t k = (uint32_t)lane * per; k < ((uint32_t)lane + 1) * per && k < S.n_cl; k++)
+        if (S.cl[k].y & 0x200u) n += 1u + (fs_part_wants_sky_slot(S.cl[k].y & 0xffu) ? 0x10000u : 0u);
+    S.lane_cnt[lane] = n;
+}
+DG_HD void fs_ph_kept_place(FsShared &S, int lane) {
+    const uint32_t per = (S.n_cl + FS_LANES - 1) / FS_LANES;
+    const uint32_t off = fs_lane_offset(S, lane);
+    uint32_t o = off & 0xffffu, sky = off >> 16;
+    if (lane == FS_LANES - 1) {
+        const uint32_t end = off + S.lane_cnt[lane];
+        S.n_parts = end & 0xffffu; S.n_sky = end >> 16;
+        if (S.n_parts > FS_PART_CAP || S.n_sky > FS_SKY_CAP) { S.fail = 1; S.n_parts = 0; S.n_sky = 0; }
+    }
+    for (uint32_t k = (uint32_t)lane * per; k < ((uint32_t)lane + 1) * per && k < S.n_cl; k++) {
+        const uint2 q = S.cl[k];
+        if (!(q.y & 0x200u)) continue;
+        const bool wants = fs_part_wants_sky_slot(q.y & 0xffu);
+        if (o < FS_PART_CAP && sky < FS_SKY_CAP + 1u) {
+            S.kept_cand[o] = q.y >> 12;
+            S.kept_sky[o] = wants ? (int16_t)sky : (int16_t)-1;
+            S.kept_sx[o] = (uint16_t)(q.x & 0xffffu); S.kept_ex[o] = (uint16_t)(q.x >> 16);
+            S.kept_t[o] = (q.y & FEP_TWO_SIDED_MID) ? 0xffffu : 0xfffeu;
+        }
+        o++; sky += wants;
+    }
+}
+// phase 3: kept part o (lane-strided): the finished FePart to its place, its line to shared memory, its sky slot recorded
+DG_HD void fs_ph_emit(const FsParams &P, FsShared &S, int f, int lane) {
+    if (S.fail) return;
+    for (uint32_t o = (uint32_t)lane; o < S.n_parts; o += FS_LANES) {
+        const FsCand &c = P.cands[(size_t)f * P.cand_cap + S.kept_cand[o]];
+        FePart p = c.part;
+        p.sky_slot = S.kept_sky[o];
+        P.parts[(size_t)f * FS_PART_CAP + o] = p;
+        S.kline[o][0] = c.ax; S.kline[o][1] = c.ay; S.kline[o][2] = c.bx; S.kline[o][3] = c.by;
+        if (S.kept_sky[o] >= 0) P.sky_parts[(size_t)f * FS_SKY_CAP + (uint32_t)S.kept_sky[o]] = o;
+    }
+}
+// phase 4a: lane l looks at map object base + l (draw_map_objects' per-object part); lane_cnt = 1 when it shows
+struct FsSpriteTmp { FsSpriteOut so; int32_t status; };
+DG_HD void fs_ph_mobj(const FsParams &P, FsShared &S, int f, uint32_t base, int lane, FsSpriteTmp &T) {
+    S.lane_cnt[lane] = 0;
+    T.status = FS_SKIP;
+    const uint32_t mi = base + (uint32_t)lane;
+    if (S.fail || mi >= P.n_mobjs) return;
+    const int32_t st = P.mobj_state[mi];
+    if (st < 0) return;                                                // S_NULL (renderer/map_objects.rs:37)
+    const dg_view &v = P.views[f];
+    const FsMobj &m = P.mobjs[mi];
+    T.status = fs_mobj(P.k, m, P.sframes[st >> 1], P.bitmaps, P.sectors, V2{v.x, v.y}, v.angle, v.cos_na, v.sin_na, v.floor_height + 41.0f, st & 1,
+                       m.sector >= 0 ? P.sector_light[m.sector] : (int16_t)0, T.so);
+    if (T.status == FS_OK) S.lane_cnt[lane] = 1;
+    else if (T.status != FS_SKIP) S.fail = 1;                          // a failure (every lane that sees one writes the same 1)
+}
+// phase 4c: the FeSprite records, sprite indices in map-object order (n_before: sprites of the chunks before this one)
+DG_HD void fs_ph_mobj_emit(const FsParams &P, FsShared &S, int f, int lane, const FsSpriteTmp &T, uint32_t n_before) {
+    const uint32_t si = n_before + fs_lane_offset(S, lane);
+    if (lane == FS_LANES - 1) {
+        S.n_sprites = si + S.lane_cnt[lane];
+        if (S.n_sprites > FS_SPRITE_CAP) { S.fail = 1; S.n_sprites = 0; }
+    }
+    if (S.fail || S.lane_cnt[lane] != 1 || si >= FS_SPRITE_CAP) return;
+    FeSprite sp = T.so.sp;
+    sp.behind_off = si * FS_BEHIND_WORDS;
+    P.sprites[(size_t)f * FS_SPRITE_CAP + si] = sp;
+    S.s_centre[si][0] = T.so.centre.x; S.s_centre[si][1] = T.so.centre.y;
+    const Seg2 &l = T.so.line;
+    S.s_mid[si][0] = (l.a.x + l.b.x) / 2.0f; S.s_mid[si][1] = (l.a.y + l.b.y) / 2.0f;       // map_objects.rs:222-226
+    S.s_key[si] = (int16_t)T.so.sort_key;
+    const int nb = (P.k.W + FE_BIN_W - 1) / FE_BIN_W;
+    if (sp.x0 < sp.x1) { S.s_x0b[si] = (uint16_t)(sp.x0 / FE_BIN_W); S.s_x1b[si] = (uint16_t)((sp.x1 - 1) / FE_BIN_W); }
+    else { S.s_x0b[si] = (uint16_t)nb; S.s_x1b[si] = 0; }
+}
+// phase 5: the behind-bit rows (which wall records do NOT clip a sprite: map_objects.rs:138-140), one (sprite, word) per step
+DG_HD void fs_ph_behind(const FsParams &P, FsShared &S, int f, int lane) {
+    if (S.fail) return;
+    const uint32_t words = (S.n_parts + 31) / 32;
+    for (uint32_t it = (uint32_t)lane; it < S.n_sprites * words; it += FS_LANES) {
+        const uint32_t si = it / words, w = it % words;
+        const V2 c{S.s_centre[si][0], S.s_centre[si][1]};
+        uint32_t bits = 0;
+        for (uint32_t b = 0; b < 32 && w * 32 + b < S.n_parts; b++) {
+            const float *k = S.kline[w * 32 + b];
+            if (fs_behind(Seg2{V2{k[0], k[1]}, V2{k[2], k[3]}}, c)) bits |= 1u << b;
+        }
+        P.behind[((size_t)f * FS_SPRITE_CAP + si) * FS_BEHIND_WORDS + w] = bits;
+    }
+}
+// phase 6: place of every sprite in the far-to-near order: stable ascending sort on the key, reversed (map_objects.rs:216-217)
+DG_HD void fs_ph_sprite_order(FsShared &S, int lane) {
+    if (S.fail) return;
+    for (uint32_t si = (uint32_t)lane; si < S.n_sprites; si += FS_LANES) {
+        uint32_t before = 0;
+        for (uint32_t t = 0; t < S.n_sprites; t++) before += (S.s_key[t] < S.s_key[si]) || (S.s_key[t] == S.s_key[si] && t < si);
+        S.s_order[si] = (uint16_t)(S.n_sprites - 1 - before);
+    }
+}
+// phase 7: a two-sided middle part is drawn just before the first sprite (in that order) whose midpoint it is behind (map_objects.rs:220-240)
+DG_HD void fs_ph_masked_when(FsShared &S, int lane) {
+    if (S.fail) return;
+    for (uint32_t r = (uint32_t)lane; r < S.n_parts; r += FS_LANES) {
+        if (S.kept_t[r] == 0xfffeu) continue;
+        const Seg2 line{V2{S.kline[r][0], S.kline[r][1]}, V2{S.kline[r][2], S.kline[r][3]}};
+        uint32_t t = 0xffffu;
+        for (uint32_t si = 0; si < S.n_sprites; si++)
+            if (S.s_order[si] < t && fs_behind(line, V2{S.s_mid[si][0], S.s_mid[si][1]})) t = S.s_order[si];
+        S.kept_t[r] = (uint16_t)t;
+    }
+}
+// phase 8: the draw sequence numbers (what the host walker counts while it replays the interleave, frontend.cpp map_objects)
+DG_HD void fs_ph_seq(const FsParams &P, FsShared &S, int f, int lane) {
+    if (S.fail) return;
+    for (uint32_t si = (uint32_t)lane; si < S.n_sprites; si += FS_LANES) {
+        const uint32_t m = S.s_order[si];
+        uint32_t walls = 0;
+        for (uint32_t r = 0; r < S.n_parts; r++) walls += S.kept_t[r] <= m;                 // (0xfffe / 0xffff never are)
+        P.sprites[(size_t)f * FS_SPRITE_CAP + si].seq = m + walls;
+    }
+    for (uint32_t r = (uint32_t)lane; r < S.n_parts; r += FS_LANES) {
+        const uint32_t t = S.kept_t[r];
+        if (t == 0xfffeu) continue;
+        uint32_t earlier = 0;
+        for (uint32_t q = 0; q < S.n_parts; q++) {
+            const uint32_t tq = S.kept_t[q];
+            if (tq == 0xfffeu) continue;
+            earlier += tq < t || (tq == t && q > r);                                          // same sprite: later records first (reversed list)
+        }
+        P.parts[(size_t)f * FS_PART_CAP + r].seq = (t == 0xffffu ? S.n_sprites : t) + earlier;
+    }
+}
+// phases 9a / 9b / 9c: the column bins (frontend.cpp bin_by_columns).  9a: bin b's counts; 9b (lane 0): offsets; 9c: the lists, in order.
+DG_HD void fs_ph_bin_count(const FsParams &P, FsShared &S, int lane, uint32_t *cnt_parts, uint32_t *cnt_sprites) {
+    const uint32_t nb = (uint32_t)(P.k.W + FE_BIN_W - 1) / FE_BIN_W;
+    for (uint32_t b = (uint32_t)lane; b < nb; b += FS_LANES) {
+        uint32_t np = 0, ns = 0;
+        if (!S.fail) {
+            for (uint32_t r = 0; r < S.n_parts; r++) np += (uint32_t)(S.kept_sx[r] / FE_BIN_W) <= b && b <= (uint32_t)(S.kept_ex[r] / FE_BIN_W);
+            for (uint32_t s = 0; s < S.n_sprites; s++) ns += S.s_x0b[s] <= b && b <= S.s_x1b[s];
+        }
+        cnt_parts[b] = np; cnt_sprites[b] = ns;
+    }
+}
+DG_HD void fs_ph_bin_prefix(const FsParams &P, FsShared &S, int f, uint32_t *cnt_parts, uint32_t *cnt_sprites) {      // lane 0
+    const uint32_t nb = (uint32_t)(P.k.W + FE_BIN_W - 1) / FE_BIN_W;
+    uint32_t *bo = P.bin_off + (size_t)f * (nb + 1), *so = P.sbin_off + (size_t)f * (nb + 1);
+    uint32_t rp = 0, rs = 0;
+    for (uint32_t b = 0; b < nb; b++) {
+        const uint32_t np = cnt_parts[b], ns = cnt_sprites[b];
+        bo[b] = rp; so[b] = rs;
+        cnt_parts[b] = rp; cnt_sprites[b] = rs;
+        rp += np; rs += ns;
+    }
+    bo[nb] = rp; so[nb] = rs;
+    if (rp > FS_BIN_CAP || rs > FS_SBIN_CAP) S.fail = 1;
+}
+DG_HD void fs_ph_bin_fill(const FsParams &P, FsShared &S, int f, int lane, const uint32_t *off_parts, const uint32_t *off_sprites) {
+    if (S.fail) return;
+    const uint32_t nb = (uint32_t)(P.k.W + FE_BIN_W - 1) / FE_BIN_W;
+    for (uint32_t b = (uint32_t)lane; b < nb; b += FS_LANES) {
+        uint16_t *bp = P.bin_parts + (size_t)f * FS_BIN_CAP + off_parts[b];
+        for (uint32_t r = 0; r < S.n_parts; r++)
+            if ((uint32_t)(S.kept_sx[r] / FE_BIN_W) <= b && b <= (uint32_t)(S.kept_ex[r] / FE_BIN_W)) *bp++ = (uint16_t)r;
+        uint16_t *sp = P.sbin_sprites + (size_t)f * FS_SBIN_CAP + off_sprites[b];
+        for (uint32_t s = 0; s < S.n_sprites; s++)
+            if (S.s_x0b[s] <= b && b <= S.s_x1b[s]) *sp++ = (uint16_t)s;
+    }
+}
+// phase 10 (lane 0): the frame header the column walk reads; a frame that was given up carries nothing and is flagged for the host
+DG_HD void fs_ph_header(const FsParams &P, FsShared &S, int f) {
+    const uint32_t nb = (uint32_t)(P.k.W + FE_BIN_W - 1) / FE_BIN_W;
+    const bool bad = S.fail || (P.flags[f] & FE_OVF_SEGS);
+    FeFrame ff;
+    ff.part_base = (uint32_t)f * FS_PART_CAP; ff.n_parts = bad ? 0u : S.n_parts;
+    ff.sprite_base = (uint32_t)f * FS_SPRITE_CAP; ff.n_sprites = bad ? 0u : S.n_sprites;
+    ff.behind_base = (uint32_t)f * FS_SPRITE_CAP * FS_BEHIND_WORDS;
+    ff.behind_words = FS_BEHIND_WORDS;
+    ff.n_sky_slots = bad ? 0u : S.n_sky;
+    ff.sky_base = (uint32_t)f * FS_SKY_CAP;
+    ff.bin_base = (uint32_t)f * FS_BIN_CAP;
+    ff.sbin_base = (uint32_t)f * FS_SBIN_CAP;
+    ff.pad[0] = ff.pad[1] = 0;
+    P.fframes[f] = ff;
+    if (bad) {
+        uint32_t *bo = P.bin_off + (size_t)f * (nb + 1), *so = P.sbin_off + (size_t)f * (nb + 1);
+        for (uint32_t b = 0; b <= nb; b++) { bo[b] = 0; so[b] = 0; }
+        if (S.fail) fs_flag(P, f, FE_OVF_SEGS);
+    }
+}
+
+}  // namespace dg

@@ -1,0 +1,112 @@
+// fs_kernels.hip — the device seg walk (DG_FE_DEVICE_SEGS): BSP visit order, per-seg processing, hidden-part culling, map objects, draw
+// sequence and column bins on the GPU.  Bodies: fs_core.h (arithmetic shared with the host walker) and fs_frame.h (the per-frame
+// phases, also run by tests/emul on the CPU).  Integer / f32 work with short dependent chains; nothing here is a contraction (no MFMA).
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "fs_kernels.hpp"
+
+namespace dg {
+
+namespace {
+
+__global__ __launch_bounds__(64) void dg_fs_order(FsParams P) {
+    const uint32_t leaf = blockIdx.x * 64u + threadIdx.x;
+    if (leaf < P.n_leaves) fs_leaf_order(P, (int)blockIdx.y, leaf);
+}
+
+__global__ __launch_bounds__(64) void dg_fs_segs(FsParams P) {
+    const uint32_t si = blockIdx.x * 64u + threadIdx.x;
+    if (si < P.n_segs && P.seg_leaf[si] != 0xffffu) fs_seg_lane(P, (int)blockIdx.y, si);
+}
+
+// One workgroup (four wavefronts) per frame.  What the phases cost is their dependent loads, which is why the serial ones (lane 0)
+// read shared memory only and meet nothing but the few candidates that survived the parallel tests.
+__global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
+    __shared__ FsShared S;
+    __shared__ uint32_t bin_cnt[2][256];                 // W <= 16384: at most 256 column bins
+    const int f = (int)blockIdx.x, lane = (int)threadIdx.x;
+#ifdef DG_FS_TIMING
+    unsigned long long tm[12], tp = wall_clock64(); int tk = 0;
+#define FS_T() { const unsigned long long tn = wall_clock64(); tm[tk++] = tn - tp; tp = tn; }
+#else
+#define FS_T()
+#endif
+    if (lane == 0) fs_ph_init(S);
+    __syncthreads();
+    fs_ph_count(P, S, f, lane);
+    __syncthreads();
+    fs_ph_block_sums(S, lane);
+    __syncthreads();
+    fs_ph_gather(P, S, f, lane);
+    __syncthreads();
+    FS_T()
+    fs_ph_cand_count(S, lane);
+    __syncthreads();
+    fs_ph_block_sums(S, lane);
+    __syncthreads();
+    fs_ph_cand_stage(P, S, f, lane);
+    __syncthreads();
+    fs_ph_first_clear(P, S, lane);
+    __syncthreads();
+    fs_ph_solids(S, lane);
+    __syncthreads();
+    fs_ph_keep(S, lane);
+    __syncthreads();
+    fs_ph_kept_count(S, lane);
+    __syncthreads();
+    fs_ph_block_sums(S, lane);
+    __syncthreads();
+    fs_ph_kept_place(S, lane);
+    __syncthreads();
+    FS_T()
+    fs_ph_emit(P, S, f, lane);
+    __syncthreads();
+    FS_T()
+    for (uint32_t base = 0; base < P.n_mobjs; base += FS_LANES) {
+        FsSpriteTmp T;
+        const uint32_t n_before = S.n_sprites;
+        fs_ph_mobj(P, S, f, base, lane, T);
+        __syncthreads();
+        fs_ph_block_sums(S, lane);
+        __syncthreads();
+        fs_ph_mobj_emit(P, S, f, lane, T, n_before);
+        __syncthreads();
+    }
+    FS_T()
+    fs_ph_behind(P, S, f, lane);
+    FS_T()
+    fs_ph_sprite_order(S, lane);
+    __syncthreads();
+    fs_ph_masked_when(S, lane);
+    __syncthreads();
+    FS_T()
+    fs_ph_seq(P, S, f, lane);
+    FS_T()
+    fs_ph_bin_count(P, S, lane, bin_cnt[0], bin_cnt[1]);
+    __syncthreads();
+    if (lane == 0) fs_ph_bin_prefix(P, S, f, bin_cnt[0], bin_cnt[1]);
+    __syncthreads();
+    fs_ph_bin_fill(P, S, f, lane, bin_cnt[0], bin_cnt[1]);
+    __syncthreads();
+    FS_T()
+    if (lane == 0) fs_ph_header(P, S, f);
+#ifdef DG_FS_TIMING
+    FS_T()
+    if (lane == 0 && (f == 100 || f == 500))
+        printf("[fs_frame %d] vis %u parts %u sprites %u | 100 MHz ticks: gather %llu cull %llu emit %llu mobj %llu behind %llu order+when %llu seq %llu bins %llu header %llu\n", f, S.n_vis,
+               S.n_parts, S.n_sprites, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7], tm[8]);
+#endif
+}
+
+}  // namespace
+
+hipError_t launch_fs(const FsParams &P, hipStream_t stream, hipEvent_t start) {
+    if (P.n_frames <= 0) return start ? hipEventRecord(start, stream) : hipSuccess;
+    hipExtLaunchKernelGGL(dg_fs_order, dim3((P.n_leaves + 63u) / 64u, (unsigned)P.n_frames), dim3(64), 0, stream, start, nullptr, 0, P);
+    hipLaunchKernelGGL(dg_fs_segs, dim3((P.n_segs + 63u) / 64u, (unsigned)P.n_frames), dim3(64), 0, stream, P);
+    hipLaunchKernelGGL(dg_fs_frame, dim3((unsigned)P.n_frames), dim3(FS_LANES), 0, stream, P);
+    return hipGetLastError();
+}
+
+}  // namespace dg

@@ -433,10 +433,67 @@ void Scene::rebuild_fs_tables() {
         f.ld_flags = (uint16_t)ld.flags;
         fs_segs[i] = f;
     }
-    fs_seg_leaf.assign(segs.size(), 0);
-    for (size_t l = 0; l < subsectors.size(); l++)
-        for (int i = 0; i < subsectors[l].count; i++)
-            if ((size_t)(subsectors[l].first + i) < segs.size()) fs_seg_leaf[(size_t)(subsectors[l].first + i)] = (uint16_t)l;
+    // every seg belongs to at most one leaf (0xffff: to none — the walk never reaches it)
+    fs_ok = !may_panic && subsectors.size() < 0xffffu && !nodes.empty();
+    fs_seg_leaf.assign(segs.size(), (uint16_t)0xffffu);
+    fs_leaf_first.resize(subsectors.size());
+    for (size_t l = 0; l < subsectors.size(); l++) {
+        fs_leaf_first[l] = (uint32_t)subsectors[l].first;
+        for (int i = 0; i < subsectors[l].count; i++) {
+            const size_t si = (size_t)(subsectors[l].first + i);
+            if (subsectors[l].first < 0 || si >= segs.size() || fs_seg_leaf[si] != 0xffffu) { fs_ok = false; continue; }
+            fs_seg_leaf[si] = (uint16_t)l;
+        }
+    }
+    // the tree: depth-first from the root (the last node, map/mod.rs:57); a leaf reached twice or a path longer than 256 is not a tree
+    fs_nodes.assign(nodes.size(), FsNode{0, 0, 0, 0, 0, 0});
+    fs_anc_off.assign(subsectors.size() + 1, 0);
+    fs_anc.clear();
+    if (fs_ok) {
+        std::vector<std::vector<uint32_t>> chains(subsectors.size());
+        std::vector<uint8_t> seen_leaf(subsectors.size(), 0), seen_node(nodes.size(), 0);
+        std::vector<uint32_t> path;
+        struct Item { int16_t child; uint32_t depth; uint32_t entry; };
+        std::vector<Item> stack;
+        const uint32_t root = (uint32_t)nodes.size() - 1;
+        seen_node[root] = 1;
+        stack.push_back(Item{nodes[root].rchild, 0, root});
+        stack.push_back(Item{nodes[root].lchild, 0, root | 0x80000000u});
+        while (!stack.empty() && fs_ok) {
+            const Item it = stack.back();
+            stack.pop_back();
+            path.resize(it.depth);
+            path.push_back(it.entry);
+            if (path.size() > 256) { fs_ok = false; break; }
+            if (it.child & (int16_t)0x8000) {
+                const size_t l = (size_t)(it.child & 0x7fff);
+                if (l >= subsectors.size() || seen_leaf[l]) { fs_ok = false; break; }
+                seen_leaf[l] = 1;
+                chains[l] = path;
+            } else {
+                const size_t n = (size_t)it.child;
+                if (n >= nodes.size() || seen_node[n]) { fs_ok = false; break; }
+                seen_node[n] = 1;
+                stack.push_back(Item{nodes[n].rchild, (uint32_t)path.size(), (uint32_t)n});
+                stack.push_back(Item{nodes[n].lchild, (uint32_t)path.size(), (uint32_t)n | 0x80000000u});
+            }
+        }
+        for (size_t l = 0; l < subsectors.size() && fs_ok; l++)        // a leaf no path leads to: its segs are never visited
+            if (!seen_leaf[l])
+                for (int i = 0; i < subsectors[l].count; i++) fs_seg_leaf[(size_t)(subsectors[l].first + i)] = (uint16_t)0xffffu;
+        for (size_t n = 0; n < nodes.size() && fs_ok; n++) {
+            fs_nodes[n].x = nodes[n].x; fs_nodes[n].y = nodes[n].y; fs_nodes[n].dx = nodes[n].dx; fs_nodes[n].dy = nodes[n].dy;
+        }
+        for (size_t l = 0; l < subsectors.size() && fs_ok; l++) {
+            fs_anc_off[l] = (uint32_t)fs_anc.size();
+            for (uint32_t e : chains[l]) {
+                fs_anc.push_back(e);
+                FsNode &n = fs_nodes[e & 0x7fffffffu];
+                if (e >> 31) n.segs_left += (uint32_t)subsectors[l].count; else n.segs_right += (uint32_t)subsectors[l].count;
+            }
+        }
+        fs_anc_off[subsectors.size()] = (uint32_t)fs_anc.size();
+    }
     fs_mobjs.resize(mobjs.size());
     for (size_t i = 0; i < mobjs.size(); i++) fs_mobjs[i] = FsMobj{mobjs[i].x, mobjs[i].y, mobjs[i].angle, mobjs[i].sector};
 }

@@ -100,13 +100,18 @@ typedef struct dg_config {
     int32_t front_end;     /* DG_FE_*: where the per-column half of Segs::process_sidedef / draw_map_objects runs */
 } dg_config;
 
-/* dg_config.front_end.  The per-seg half (BSP order, transform, clip, projection: segs.rs:353-590) always runs on the host.
- *   DG_FE_HOST    the host also walks every screen column and ships finished span lists (what dg_draw_lists consumes)
- *   DG_FE_DEVICE  the host ships per-seg / per-sprite records; one GPU lane per screen column does segs.rs:202-345,
- *                 sidedef_visplanes.rs and map_objects.rs:130-209.  A batch that exceeds a device-side capacity is redone
- *                 through DG_FE_HOST transparently (same pixels either way).
- *   DG_FE_AUTO    = DG_FE_DEVICE */
-enum { DG_FE_AUTO = 0, DG_FE_HOST = 1, DG_FE_DEVICE = 2 };
+/* dg_config.front_end: how much of the front end (mod.rs:61-104, segs.rs:121-590, sidedef_visplanes.rs, map_objects.rs) runs on the GPU.
+ *   DG_FE_HOST         everything on the host: it walks every screen column and ships finished span lists (what dg_draw_lists consumes)
+ *   DG_FE_DEVICE       the host does the per-seg half (BSP order, transform, clip, projection: segs.rs:353-590,121-200) and ships per-seg /
+ *                      per-sprite records; one GPU lane per screen column does segs.rs:202-345, sidedef_visplanes.rs and
+ *                      map_objects.rs:130-209.  A frame that exceeds a device-side capacity is redone through DG_FE_HOST transparently
+ *                      (same pixels either way).
+ *   DG_FE_DEVICE_SEGS  the per-seg half runs on the GPU too (one lane per seg / map object, one wavefront per frame for what depends on
+ *                      the BSP order): the host ships 88 bytes per view and nothing else.  Frames it cannot judge (a reference panic,
+ *                      a capacity), batches with per-view game state (dg_submit_views_state) and maps in which a texture / flat lookup
+ *                      would panic fall back to DG_FE_DEVICE / DG_FE_HOST transparently.
+ *   DG_FE_AUTO         = DG_FE_DEVICE */
+enum { DG_FE_AUTO = 0, DG_FE_HOST = 1, DG_FE_DEVICE = 2, DG_FE_DEVICE_SEGS = 3 };
 
 int dg_create(const dg_config *cfg, dg_ctx **out);
 void dg_destroy(dg_ctx *ctx);
@@ -229,7 +234,7 @@ typedef struct dg_timing {
     float host_ms;            /* host list generation + binning + packing of that submission (wall clock) */
     uint64_t n_spans, n_frames, covered_pixels;
     uint64_t n_walls, n_planes, list_bytes; /* drawn records / visplanes, bytes of lists copied to HBM */
-    int32_t front_end;        /* DG_FE_HOST or DG_FE_DEVICE: what that submission actually used; with DG_FE_DEVICE setup_ms is
+    int32_t front_end;        /* DG_FE_HOST, DG_FE_DEVICE or DG_FE_DEVICE_SEGS: what that submission actually used; with DG_FE_DEVICE setup_ms is
                                  the column walk (dg_fe_columns, dg_fe_gaps, dg_fe_scan, dg_fe_scatter), n_walls = wall records,
                                  n_planes = sprites, covered_pixels is not tracked (0) */
 } dg_timing;

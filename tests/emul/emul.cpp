@@ -539,3 +539,112 @@ int emul_frame_lists(void *scene, int W, int H, const dg_view *view_in, int32_t 
     return 0;
 }
 }
+
+// ---- the device seg walk (fs_frame.h) on the CPU ------------------------------------------------------------------------------------
+// Runs the bodies of dg_fs_order / dg_fs_segs / dg_fs_frame for one frame — the "lanes" of every phase one after another, a barrier
+// between phases — and compares what they produce with the host walker's parts mode (build_frame_parts), record by record:
+// every FePart byte for byte, every FeSprite (but its behind_off: the row stride differs), the behind bits, the sky slot table, both
+// column-bin tables.  Returns 0 and stats = [parts, sprites, sky slots, flags, visible segs, candidates], 1 when the host walker
+// itself refuses the frame (then the device walk must have flagged it), < 0 with emul_last_error on a mismatch.
+extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, uint64_t *stats) {
+    const Scene &sc = *(const Scene *)scene;
+    if (!sc.fs_ok || W > FS_MAX_W) { g_err = "scene / frame size not eligible for the device seg walk"; return -100; }
+    dg_view view = *view_in;
+    fill_view_trig(view);
+    static thread_local FrameArena arena;
+    const int host_rc = build_frame_parts(sc, W, H, view, arena, g_err);
+    FrameConsts fk = make_consts(W, H);
+    const uint32_t nb = (uint32_t)(W + FE_BIN_W - 1) / FE_BIN_W;
+    std::vector<int16_t> lights(sc.sectors.size());
+    for (size_t i = 0; i < sc.sectors.size(); i++) lights[i] = sc.sectors[i].light;
+    std::vector<int32_t> mstate(sc.mobjs.size());
+    for (size_t i = 0; i < sc.mobjs.size(); i++) mstate[i] = sc.mobjs[i].sprite_frame < 0 ? -1 : sc.mobjs[i].sprite_frame * 2 + (sc.mobjs[i].full_bright ? 1 : 0);
+    std::vector<uint32_t> leaf_base(sc.subsectors.size() + 1), ord(sc.segs.size() + 1, 0), cand_cnt(1, 0), flags(1, 0);
+    std::vector<FsCand> cands(FS_CAND_CAP_MAX);
+    std::vector<uint2> cand_lite(FS_CAND_CAP_MAX);
+    std::vector<FeFrame> ffr(1);
+    std::vector<FePart> parts(FS_PART_CAP);
+    std::vector<FeSprite> sprites(FS_SPRITE_CAP);
+    std::vector<uint32_t> behind((size_t)FS_SPRITE_CAP * FS_BEHIND_WORDS, 0), sky_parts(FS_SKY_CAP), bin_off(nb + 1), sbin_off(nb + 1);
+    std::vector<uint16_t> bin_parts(FS_BIN_CAP), sbin_sprites(FS_SBIN_CAP);
+    FsParams P;
+    P.k = DevConsts{fk.ARC, fk.GCFX, fk.CFX, fk.CFY, W, H};
+    P.segs = sc.fs_segs.data(); P.seg_leaf = sc.fs_seg_leaf.data(); P.leaf_first = sc.fs_leaf_first.data();
+    P.sectors = sc.fs_sectors.data(); P.anims = sc.fs_anims.data(); P.bitmaps = sc.fs_bitmaps.data(); P.flat_sky = sc.flat_sky.data();
+    P.mobjs = sc.fs_mobjs.data(); P.sframes = sc.sprite_frames_fs();
+    P.nodes = sc.fs_nodes.data(); P.anc_off = sc.fs_anc_off.data(); P.anc = sc.fs_anc.data();
+    P.cand_cap = FS_CAND_CAP_MAX;
+    P.n_segs = (uint32_t)sc.segs.size(); P.n_leaves = (uint32_t)sc.subsectors.size(); P.n_mobjs = (uint32_t)sc.mobjs.size();
+    P.sector_light = lights.data(); P.mobj_state = mstate.data();
+    P.views = &view; P.n_frames = 1;
+    P.leaf_base = leaf_base.data(); P.ord = ord.data(); P.cand_cnt = cand_cnt.data(); P.cands = cands.data(); P.cand_lite = cand_lite.data(); P.flags = flags.data();
+    P.fframes = ffr.data(); P.parts = parts.data(); P.sprites = sprites.data(); P.behind = behind.data(); P.sky_parts = sky_parts.data();
+    P.bin_off = bin_off.data(); P.bin_parts = bin_parts.data(); P.sbin_off = sbin_off.data(); P.sbin_sprites = sbin_sprites.data();
+
+    for (uint32_t l = 0; l < P.n_leaves; l++) fs_leaf_order(P, 0, l);                                      // dg_fs_order
+    for (uint32_t s = 0; s < P.n_segs; s++) if (P.seg_leaf[s] != 0xffffu) fs_seg_lane(P, 0, s);             // dg_fs_segs
+    static thread_local FsShared S;                                                                        // dg_fs_frame
+    static thread_local FsSpriteTmp T[FS_LANES];
+    uint32_t bin_cnt[2][256];
+#define LANES(body) for (int lane = 0; lane < FS_LANES; lane++) { body; }
+    fs_ph_init(S);
+    LANES(fs_ph_count(P, S, 0, lane))
+    LANES(fs_ph_block_sums(S, lane))
+    LANES(fs_ph_gather(P, S, 0, lane))
+    LANES(fs_ph_cand_count(S, lane))
+    LANES(fs_ph_block_sums(S, lane))
+    LANES(fs_ph_cand_stage(P, S, 0, lane))
+    LANES(fs_ph_first_clear(P, S, lane))
+    LANES(fs_ph_solids(S, lane))
+    LANES(fs_ph_keep(S, lane))
+    LANES(fs_ph_kept_count(S, lane))
+    LANES(fs_ph_block_sums(S, lane))
+    LANES(fs_ph_kept_place(S, lane))
+    LANES(fs_ph_emit(P, S, 0, lane))
+    for (uint32_t base = 0; base < P.n_mobjs; base += FS_LANES) {
+        const uint32_t n_before = S.n_sprites;
+        LANES(fs_ph_mobj(P, S, 0, base, lane, T[lane]))
+        LANES(fs_ph_block_sums(S, lane))
+        LANES(fs_ph_mobj_emit(P, S, 0, lane, T[lane], n_before))
+    }
+    LANES(fs_ph_behind(P, S, 0, lane))
+    LANES(fs_ph_sprite_order(S, lane))
+    LANES(fs_ph_masked_when(S, lane))
+    LANES(fs_ph_seq(P, S, 0, lane))
+    LANES(fs_ph_bin_count(P, S, lane, bin_cnt[0], bin_cnt[1]))
+    fs_ph_bin_prefix(P, S, 0, bin_cnt[0], bin_cnt[1]);
+    LANES(fs_ph_bin_fill(P, S, 0, lane, bin_cnt[0], bin_cnt[1]))
+    fs_ph_header(P, S, 0);
+#undef LANES
+    const FeFrame &ff = ffr[0];
+    if (stats) { stats[0] = ff.n_parts; stats[1] = ff.n_sprites; stats[2] = ff.n_sky_slots; stats[3] = flags[0]; stats[4] = S.n_vis; stats[5] = cand_cnt[0]; }
+    if (host_rc) {                                    // the host walker refuses the frame: the device walk must have given it up too
+        if (!(flags[0] & FE_OVF_SEGS)) { g_err = "host walker fails (" + g_err + ") but the device seg walk did not flag the frame"; return -1; }
+        return 1;
+    }
+    if (flags[0] & FE_OVF_SEGS) return 2;             // given up on the device (capacity, or a failure in a part the host culls): the host redoes it
+    auto bad = [&](const std::string &m) { g_err = m; return -2; };
+    if (ff.n_parts != arena.parts.size()) return bad("part count " + std::to_string(ff.n_parts) + " != host " + std::to_string(arena.parts.size()));
+    for (uint32_t i = 0; i < ff.n_parts; i++)
+        if (std::memcmp(&parts[i], &arena.parts[i], sizeof(FePart)) != 0) return bad("part " + std::to_string(i) + " differs from the host walker's");
+    if (ff.n_sprites != arena.sprites.size()) return bad("sprite count " + std::to_string(ff.n_sprites) + " != host " + std::to_string(arena.sprites.size()));
+    for (uint32_t i = 0; i < ff.n_sprites; i++) {
+        FeSprite a = sprites[i], b = arena.sprites[i];
+        if (a.behind_off != i * FS_BEHIND_WORDS) return bad("sprite behind_off");
+        a.behind_off = b.behind_off = 0;
+        if (std::memcmp(&a, &b, sizeof a) != 0) return bad("sprite " + std::to_string(i) + " differs from the host walker's");
+        for (uint32_t p = 0; p < ff.n_parts; p++) {
+            const bool dv = (behind[(size_t)i * FS_BEHIND_WORDS + (p >> 5)] >> (p & 31)) & 1u;
+            const bool hv = (arena.behind[arena.sprites[i].behind_off + (p >> 5)] >> (p & 31)) & 1u;
+            if (dv != hv) return bad("behind bit of sprite " + std::to_string(i) + ", part " + std::to_string(p));
+        }
+    }
+    if (ff.n_sky_slots != arena.n_sky_slots) return bad("sky slot count");
+    for (uint32_t i = 0; i < ff.n_sky_slots; i++)
+        if (sky_parts[i] != arena.sky_parts[i]) return bad("sky slot " + std::to_string(i));
+    for (uint32_t b = 0; b <= nb; b++)
+        if (bin_off[b] != arena.bin_off[b] || sbin_off[b] != arena.sbin_off[b]) return bad("bin offsets of bin " + std::to_string(b));
+    for (uint32_t i = 0; i < bin_off[nb]; i++) if (bin_parts[i] != arena.bin_parts[i]) return bad("part bin entry " + std::to_string(i));
+    for (uint32_t i = 0; i < sbin_off[nb]; i++) if (sbin_sprites[i] != arena.sbin_sprites[i]) return bad("sprite bin entry " + std::to_string(i));
+    return 0;
+}

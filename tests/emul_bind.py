@@ -28,6 +28,7 @@ def lib():
         L.emul_render_fe.argtypes = L.emul_render.argtypes
         L.emul_render_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(DgView), ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
                                         ctypes.c_uint32, ctypes.c_void_p]
+        L.emul_fs_frame.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(DgView), ctypes.POINTER(ctypes.c_uint64)]
         L.emul_sprite_frame.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint8]
         L.emul_set_sector_light.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int16]
         L.emul_set_mobj_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint8, ctypes.c_int]
@@ -75,6 +76,19 @@ class EmulScene:
         if rc:
             raise RuntimeError(f"emul rc {rc}: {lib().emul_last_error().decode()}")
         return buf.tobytes()
+
+    def fs_frame(self, W, H, rec, timestamp=0.0):
+        """The device seg walk's bodies (fs_frame.h: dg_fs_order / dg_fs_segs / dg_fs_frame) on the CPU for one view, compared inside the
+        harness with the host walker's parts mode record by record.  -> (rc, stats): rc 0 = identical records, 1 = the host walker
+        refuses the frame and the device walk flagged it, 2 = the device walk gave the frame up (the host redoes it);
+        stats = [parts, sprites, sky slots, flags, visible segs, candidates].  Raises on any mismatch."""
+        v = DgView(float(rec[0]), float(rec[1]), float(rec[2]), float(rec[7]), float(rec[3]), float(rec[4]), float(rec[5]), float(rec[6]),
+                   float(timestamp), 1)
+        st = (ctypes.c_uint64 * 6)()
+        rc = lib().emul_fs_frame(self._h, W, H, ctypes.byref(v), st)
+        if rc < 0:
+            raise RuntimeError(f"emul_fs_frame rc {rc}: {lib().emul_last_error().decode()}")
+        return rc, list(st)
 
     def render_fe(self, W, H, rec, timestamp=0.0):
         """Same frame through the device column walk's bodies (fe_core.h) on the CPU.  stats = [spans, parts, sprites, overflow

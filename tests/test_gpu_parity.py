@@ -36,7 +36,7 @@ def test_native_library_is_loaded(dg):
     assert "libdoomgpu.so" in open("/proc/self/maps").read()
 
 
-@pytest.mark.parametrize("front_end", [1, 2], ids=["host-lists", "device-column-walk"])
+@pytest.mark.parametrize("front_end", [1, 2, 3], ids=["host-lists", "device-column-walk", "device-seg-walk"])
 def test_full_camera_path_320x200_bit_exact(dg, scene1993, oracle_scene1993, path1993, front_end):
     """BASELINE config 1: 1 000-frame scripted path at 320x200, every frame byte-compared with the CPU oracle."""
     W, H, B = 320, 200, 250
@@ -77,7 +77,7 @@ def test_golden_hashes_on_gpu(dg, scene1993, path1993, golden_frames):
         ctx.close()
 
 
-@pytest.mark.parametrize("front_end", [1, 2], ids=["host-lists", "device-column-walk"])
+@pytest.mark.parametrize("front_end", [1, 2, 3], ids=["host-lists", "device-column-walk", "device-seg-walk"])
 def test_heavy_map_bit_exact(dg, scene1994, oracle_scene1994, path1994, golden_frames, front_end):
     W, H = 320, 200
     idx = sorted(set(range(0, 1000, 8)) | {277} | {int(i) for i in golden_frames[1994]["320x200"]})   # 277: zero-filled sky visplane columns
@@ -91,7 +91,7 @@ def test_heavy_map_bit_exact(dg, scene1994, oracle_scene1994, path1994, golden_f
     ctx.close()
 
 
-@pytest.mark.parametrize("front_end", [1, 2], ids=["host-lists", "device-column-walk"])
+@pytest.mark.parametrize("front_end", [1, 2, 3], ids=["host-lists", "device-column-walk", "device-seg-walk"])
 def test_vanilla_shaped_map_bit_exact(dg, wad1995, oracle_scene1995, path1995, golden_frames, front_end):
     """Seed 1995 — arbitrary integer vertices and wall angles, rounded BSP splits, closed doors (segs.rs:222-225), thing angles in
     1 degree steps, patches with negative / past-the-bottom origins: the committed golden hashes at every size they were taken at,
@@ -189,7 +189,7 @@ def test_batch_slot_and_replay_independence(dg, scene1993, path1993):
     ctx.close()
 
 
-@pytest.mark.parametrize("front_end", [1, 2], ids=["host-lists", "device-column-walk"])
+@pytest.mark.parametrize("front_end", [1, 2, 3], ids=["host-lists", "device-column-walk", "device-seg-walk"])
 def test_timing_events_ride_on_the_dispatches(dg, scene1993, path1993, front_end):
     """dg_timing reads events attached to the kernel dispatches on the ctx's one kernel stream: the front-end kernels' span, the raster
     launch, and both.  Two slots submitted back to back (slot 1 is queued behind slot 0 on that stream): each slot's own times are
@@ -512,11 +512,12 @@ def test_every_frame_of_both_paths_at_1280x800_against_the_oracle_checksums(dg, 
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"checksums_seed{seed}_1280x800.json")))["checksums"]
     scene, path = {1993: (scene1993, path1993), 1994: (scene1994, path1994), 1995: (scene1995, path1995)}[seed]
     W, H, B = 1280, 800, 250
-    for fe in (dg.DG_FE_DEVICE, dg.DG_FE_HOST):
+    for fe in (dg.DG_FE_DEVICE_SEGS, dg.DG_FE_DEVICE, dg.DG_FE_HOST):
         ctx = make_ctx(dg, scene, W, H, B, slots=1, front_end=fe)
         for b0 in range(0, 1000, B):
             ctx.submit(0, dg.make_views(path[b0:b0 + B]))
             ctx.wait(0)
+            assert ctx.timing(0)["front_end"] == fe
             got = [f"{int(v):016x}" for v in ctx.frame_checksums(0, 0, B)]
             bad = [b0 + k for k in range(B) if got[k] != gold[b0 + k]]
             assert not bad, f"front end {fe}: frames {bad[:10]} differ from the oracle"

@@ -224,10 +224,12 @@ def test_hand_assembled_wad_product_loader_and_host_front_end(campath_mod):
             assert es.render(W, H, rec, ts)[0] == ref, (W, H, rec[:3], ts)
             got, st = es.render_fe(W, H, rec, ts)
             assert got == ref and st[3] == 0 and st[4] == 1, (W, H, rec[:3], ts, st)
+            rc, st = es.fs_frame(W, H, rec, ts)                      # the device seg walk's bodies against the host walker's records
+            assert rc == 0 and st[0] > 0, (W, H, rec[:3], ts, rc, st)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("front_end", [1, 2], ids=["host-lists", "device-column-walk"])
+@pytest.mark.parametrize("front_end", [1, 2, 3], ids=["host-lists", "device-column-walk", "device-seg-walk"])
 def test_hand_assembled_wad_on_the_gpu(dg, campath_mod, front_end):
     import doomref
     wad = build_hand_iwad()

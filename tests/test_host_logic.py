@@ -320,3 +320,29 @@ def test_subtree_cull_at_16384_columns_next_to_walls(oracle, synth, campath_mod)
             assert es.render(W, H, rec)[0] == ref, f"seed {seed} view {j}: culled front end differs from the un-culled oracle"
             checked += 1
         assert checked >= 24
+
+
+@pytest.mark.parametrize("seed,heavy,vanilla", [(1993, False, False), (1994, True, False), (1995, False, True)])
+def test_device_seg_walk_bodies_match_the_host_walker(synth, campath_mod, seed, heavy, vanilla):
+    """DG_FE_DEVICE_SEGS: the GPU's per-seg half (fs_frame.h: BSP visit order from per-leaf ancestor sums, one lane per seg, hidden-part
+    culling / map objects / draw sequence / column bins per frame) run on the CPU by tests/emul and compared inside the harness with the
+    host walker's parts mode (frontend.cpp, which culls BSP subtrees and walks in order): every FePart byte for byte, every FeSprite,
+    the behind bits, the sky slot table, both column-bin tables.  Path frames at three sizes plus random viewpoints (inside closed
+    doors, outside the map)."""
+    wad = synth.build_synth_iwad(seed, heavy=heavy, vanilla=vanilla)
+    es = emul_bind.EmulScene(wad)
+    path = load_path(seed)
+    same = 0
+    for (W, H, stride) in ((1280, 800, 13), (320, 200, 17), (2560, 1600, 97), (64, 40, 131)):
+        for i in range(0, 1000, stride):
+            rc, st = es.fs_frame(W, H, path[i])
+            assert rc == 0 and st[3] == 0 and st[0] > 0, (W, H, i, rc, st)
+            same += 1
+    rng = np.random.default_rng(seed)
+    given_up = 0
+    for j in range(200):
+        rec = campath_mod.view_record(float(rng.uniform(-100, 4200)), float(rng.uniform(-100, 3200)), float(rng.uniform(-7, 7)), float(rng.choice([-64, -8, 0, 24, 200])))
+        rc, st = es.fs_frame([320, 1280, 132][j % 3], [200, 800, 67][j % 3], rec, [0.0, 0.4, 0.7][j % 3])
+        assert rc in (0, 1, 2), (j, rc, st)
+        given_up += rc != 0
+    assert same > 150 and given_up < 40
