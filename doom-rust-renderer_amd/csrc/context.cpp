@@ -192,7 +192,7 @@ struct dg_ctx {
     // device seg walk (DG_FE_DEVICE_SEGS): the scene's per-seg tables + BSP tables in one allocation, per-batch scratch sized by the scene
     bool fs_enabled = false, fs_scene_ok = false;
     uint8_t *d_fs_scene = nullptr;
-    uint8_t *d_fs_scratch = nullptr;    // [cand_cnt F | ord F x n_segs] (zeroed per batch) | leaf_base F x n_leaves | cands F x cand_cap
+    uint8_t *d_fs_scratch = nullptr;    // candidate rows F x n_segs x 5 x 8 B (zeroed per batch) | leaf_base F x n_leaves
     size_t fs_zero_bytes = 0;
     FsParams fs_proto{};                // scene pointers and counts, filled at upload
     uint64_t fallbacks_fe = 0;          // batches in which frames were redone because a device-side capacity was exceeded (dg_ctx_fallbacks)
@@ -487,20 +487,15 @@ int upload_fs_scene(dg_ctx *c, const Scene &sc) {
     P.mobjs = reinterpret_cast<const FsMobj *>(at(i_mobjs)); P.sframes = reinterpret_cast<const FsSpriteFrame *>(at(i_sframes));
     P.nodes = reinterpret_cast<const FsNode *>(at(i_nodes)); P.anc_off = reinterpret_cast<const uint32_t *>(at(i_aoff)); P.anc = reinterpret_cast<const uint32_t *>(at(i_anc));
     P.n_segs = (uint32_t)sc.segs.size(); P.n_leaves = (uint32_t)sc.subsectors.size(); P.n_mobjs = (uint32_t)sc.mobjs.size();
-    P.cand_cap = (uint32_t)std::min<size_t>(5 * sc.segs.size(), FS_CAND_CAP_MAX);
-    // scratch: [cand_cnt | ord] are zeroed before every walk with one memset
+    // scratch: the candidate rows (zeroed before every walk), the leaves' visit positions
     const size_t F = (size_t)c->cfg.max_batch;
-    const size_t off_ord = align_up(F * 4, 256);
-    c->fs_zero_bytes = off_ord + F * P.n_segs * 4;
+    const size_t off_lite = align_up(F * FS_LANES * 4, 256);               // [slice counters | candidate rows]: zeroed together
+    c->fs_zero_bytes = off_lite + F * (size_t)P.n_segs * FS_CALLS * sizeof(uint2);
     const size_t off_leaf = align_up(c->fs_zero_bytes, 256);
-    const size_t off_cands = align_up(off_leaf + F * P.n_leaves * 4, 256);
-    const size_t off_lite = align_up(off_cands + F * (size_t)P.cand_cap * sizeof(FsCand), 256);
-    HIP_TRY(hipMalloc((void **)&c->d_fs_scratch, off_lite + F * (size_t)P.cand_cap * 8));
-    P.cand_cnt = reinterpret_cast<uint32_t *>(c->d_fs_scratch);
-    P.ord = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_ord);
+    HIP_TRY(hipMalloc((void **)&c->d_fs_scratch, off_leaf + F * P.n_leaves * 4));
+    P.slice_cnt = reinterpret_cast<uint32_t *>(c->d_fs_scratch);
+    P.lite = reinterpret_cast<uint2 *>(c->d_fs_scratch + off_lite);
     P.leaf_base = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_leaf);
-    P.cands = reinterpret_cast<FsCand *>(c->d_fs_scratch + off_cands);
-    P.cand_lite = reinterpret_cast<uint2 *>(c->d_fs_scratch + off_lite);
     c->fs_scene_ok = true;
     return DG_OK;
 }
@@ -633,7 +628,7 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
         const size_t ev_bytes = (size_t)3 * (size_t)s.FP.n_frames * s.FP.max_sky_slots * s.FP.w64 * 8;   // all three event kinds (fe_event_words)
         HIP_TRY(hipMemsetAsync(s.d_flags, 0, s.flags_bytes + ev_bytes, ks));                            // the overflow flags and the event bits behind them
         if (s.fs_mode) {                                                                                // the seg walk writes what the column walk reads
-            HIP_TRY(hipMemsetAsync(c->d_fs_scratch, 0, c->fs_zero_bytes, ks));
+            HIP_TRY(hipMemsetAsync(c->d_fs_scratch, 0, (size_t)(reinterpret_cast<uint8_t *>(s.FSP.lite) - c->d_fs_scratch) + (size_t)s.FSP.n_frames * s.FSP.n_segs * FS_CALLS * sizeof(uint2), ks));   // slice counters + candidate rows
             HIP_TRY(launch_fs(s.FSP, ks, s.ev_start));
         }
         HIP_TRY(launch_fe(s.FP, ks, s.fs_mode ? nullptr : s.ev_start, s.ev_setup));

@@ -235,6 +235,32 @@ DG_HD int32_t fs_seg(const K &k, const FsSeg &sg, const FsSector *sectors, const
     return FS_OK;
 }
 
+// The x half of make_sidedef_non_vertical_line (misc.rs:138-161): the screen columns of a clipped line do not depend on the height.
+template <typename K> DG_HD void project_x(const K &k, const Seg2 &l, int32_t &sx, int32_t &ex) {
+    float tsx = k.GCFX * l.a.y / l.a.x;
+    float tex = k.GCFX * l.b.y / l.b.x;
+    tsx *= k.ARC;
+    tex *= k.ARC;
+    sx = f32_as_i32(k.CFX - tsx);
+    ex = f32_as_i32(k.CFX - tex);
+    sx = sx < k.W - 1 ? sx : k.W - 1;
+    ex = ex < k.W - 1 ? ex : k.W - 1;
+}
+// The tests of Segs::process_sidedef (segs.rs:121-157) that decide whether a call reaches its column loop, and what the hidden-part
+// culling needs of it: columns [sx, ex] and the FEP_* flags.  (Both edges of a part project to the same columns — the x of
+// perspective_transform does not see the height — so the reference's "Wall start not vertical" panic cannot fire; fs_part keeps the test.)
+template <typename K>
+DG_HD int32_t fs_part_head(const K &k, const FsSegOut &s, const FsCall &c, const FsBitmap *bitmaps, const uint8_t *flat_sky, int32_t &sx, int32_t &ex, uint32_t &flags) {
+    project_x(k, s.cl.line, sx, ex);
+    if (c.tex == -2) return FS_FAIL_TEXTURE;                      // TEX_UNKNOWN
+    if (wrap_i16(sx) == wrap_i16(ex)) return FS_SKIP;
+    if (sx < 0 || sx >= k.W || ex < 0 || ex >= k.W) return FS_FAIL_LINE_X;
+    if (c.tex >= 0 && (bitmaps[c.tex].w <= 0 || bitmaps[c.tex].h <= 0)) return FS_FAIL_PARTS;
+    const bool fsky = flat_sky[s.floor_flat] != 0, csky = flat_sky[s.ceil_flat] != 0;
+    flags = c.flags | (c.tex >= 0 ? FEP_HAS_BITMAP : 0u) | (fsky ? FEP_FLOOR_SKY : 0u) | (csky ? FEP_CEIL_SKY : 0u);
+    return FS_OK;
+}
+
 // Segs::process_sidedef (segs.rs:121-200) up to its column loop, for one call of a seg: the FePart the device column walk consumes,
 // without the two fields that depend on what came before in BSP order (sky_slot, seq: left -1 / 0).  FS_SKIP: a zero-width part.
 // view_floor_height: player.floor_height (visplanes.rs:112).  flat_sky[flat]: the flat's name contains "SKY".

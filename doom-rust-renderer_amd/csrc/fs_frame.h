@@ -6,9 +6,11 @@
 // kernels per batch (fs_kernels.hip), with the arithmetic of fs_core.h:
 //   dg_fs_order   one lane per (frame, BSP leaf): position of the leaf's first seg in the reference's visit order — the sum, over the
 //                 leaf's ancestors on whose BACK side it lies for this viewer, of the seg count of the ancestor's front subtree;
-//   dg_fs_segs    one lane per (frame, seg): process_seg + the head of every process_sidedef call (transform, clip, projection, pegging,
-//                 the finished FePart records), written to a per-frame candidate area; ord[frame][visit position] says where;
-//   dg_fs_frame   one wavefront per frame, the phases below: candidates in visit order -> hidden-part culling -> the frame's FePart list;
+//   dg_fs_segs    one lane per (frame, seg): process_seg + the tests of every process_sidedef call (transform, clip, x projection): the
+//                 columns and flags of each call that reaches its column loop, written at the seg's VISIT POSITION in the frame's
+//                 candidate row — the row then holds the frame's candidate parts in the reference's order;
+//   dg_fs_frame   one workgroup per frame, the phases below: hidden-part culling of the candidates -> the frame's FePart list (built
+//                 here, for the survivors only: a tenth of the candidates);
 //                 the map objects (FeSprite), their behind-bit rows and draw sequence; the column bins; the FeFrame header —
 //                 exactly the arrays the host ships in DG_FE_DEVICE mode, which the column walk (fe_kernels.hip) then consumes unchanged.
 // A frame the reference would panic on, or one that exceeds a capacity below, is flagged (FE_OVF_SEGS) and redone by the host.
@@ -28,12 +30,11 @@ namespace dg {
 
 constexpr uint32_t FE_OVF_SEGS = 8;            // the device seg walk gave the frame up (reference panic / capacity): redone on the host
 constexpr int FS_LANES = 256;                  // threads of dg_fs_frame's workgroup (four wavefronts per frame)
+constexpr int FS_CALLS = 5;                    // process_sidedef calls a seg can make (segs.rs:493-588)
 constexpr int FS_BLOCK = 16;                   // lanes per block of the two-level prefix sums
-constexpr uint32_t FS_CAND_CAP_MAX = 16384;    // candidate parts of one frame (visible segs x their process_sidedef calls): FsParams.cand_cap <= this
-constexpr uint32_t FS_VIS_CAP = 3072;          // visible segs of one frame (no subtree culling here: every seg inside the frustum that faces the viewer)
 constexpr uint32_t FS_PART_CAP = 256;          // parts of one frame after the hidden-part culling
-constexpr uint32_t FS_CL_CAP = 4096;           // candidate parts of one frame the culling stages in shared memory
-constexpr int FS_MAX_W = 3072;                 // widest frame the culling's per-column table holds (wider: DG_FE_DEVICE)
+constexpr uint32_t FS_CL_CAP = 3072;           // candidate parts of one frame the culling stages in shared memory
+constexpr int FS_MAX_W = 2560;                 // widest frame the culling's per-column table holds (wider: DG_FE_DEVICE)
 constexpr int FS_GROUP = 16;                   // lanes that share one candidate in the column passes of the culling
 constexpr uint32_t FS_SPRITE_CAP = 256;        // visible map objects of one frame
 constexpr uint32_t FS_SKY_CAP = 64;            // parts of one frame that may produce sky visplanes (event rows of dg_fe_gaps)
@@ -44,11 +45,6 @@ constexpr uint32_t FS_BEHIND_WORDS = FS_PART_CAP / 32;
 struct FsNode { float x, y, dx, dy; uint32_t segs_right, segs_left; };       // partition line + seg counts of the two subtrees
 static_assert(sizeof(FsNode) == 24, "FsNode layout");
 
-struct FsCand {                                // one process_sidedef call that reached its column loop (dg_fs_segs)
-    FePart part;
-    float ax, ay, bx, by;                      // the seg's clipped line (is_behind_vertex, bitmap_render.rs:137-165)
-};
-static_assert(sizeof(FsCand) == 144, "FsCand layout");
 
 struct FsParams {
     DevConsts k;
@@ -58,7 +54,6 @@ struct FsParams {
     const FsMobj *mobjs; const FsSpriteFrame *sframes;
     const FsNode *nodes; const uint32_t *anc_off; const uint32_t *anc;           // per leaf: its ancestors, root first: node | (lies in the LEFT subtree) << 31
     uint32_t n_segs, n_leaves, n_mobjs;
-    uint32_t cand_cap;                         // candidate slots per frame in `cands` (min(5 n_segs, FS_CAND_CAP_MAX))
     // game state of this batch (scene-wide values as of submission)
     const int16_t *sector_light;               // [n_sectors]
     const int32_t *mobj_state;                 // [n_mobjs] sprite_frame * 2 + full_bright, negative: S_NULL
@@ -67,10 +62,10 @@ struct FsParams {
     int32_t n_frames;
     // scratch (shared by all slots: every kernel runs on the ctx's one stream)
     uint32_t *leaf_base;                       // [frame][n_leaves]
-    uint32_t *ord;                             // [frame][n_segs]: 0 = seg not visible, else (first candidate << 3 | calls), zeroed per batch
-    uint32_t *cand_cnt;                        // [frame], zeroed per batch
-    FsCand *cands;                             // [frame][cand_cap]
-    uint2 *cand_lite;                          // [frame][cand_cap]: x = sx | ex << 16, y = FEP_* flags | 1 << 31 when the slot holds a part (what the culling reads)
+    // [frame][visit position of the seg x FS_CALLS + call], zeroed per batch: x = sx | ex << 16, y = FEP_* (bits 0-7) | 1 << 8 | seg << 12
+    // for a call that reaches its column loop (dg_fs_segs): the frame's candidate parts, already in the reference's visit order
+    uint2 *lite;
+    uint32_t *slice_cnt;                       // [frame][FS_LANES], zeroed per batch: parts in each lane's slice of the frame's row (dg_fs_frame's prefix sums start from these)
     uint32_t *flags;                           // [frame] FE_OVF_* (the column walk's flag words)
     // outputs: the DG_FE_DEVICE record arrays with fixed per-frame strides
     FeFrame *fframes; FePart *parts; FeSprite *sprites; uint32_t *behind; uint32_t *sky_parts;
@@ -100,12 +95,31 @@ DG_HD void fs_flag(const FsParams &P, int f, uint32_t bits) {
     P.flags[f] |= bits;
 #endif
 }
-DG_HD uint32_t fs_take(uint32_t *counter, uint32_t n) {
+DG_HD void fs_count(uint32_t *counter) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return atomicAdd(counter, n);
+    atomicAdd(counter, 1u);
 #else
-    const uint32_t v = *counter; *counter = v + n; return v;
+    *counter += 1u;
 #endif
+}
+// Entries of a frame's candidate row that one lane of dg_fs_frame owns (lane l: [l * len, (l + 1) * len))
+DG_HD uint32_t fs_slice_len(uint32_t n_segs) { return (n_segs * FS_CALLS + FS_LANES - 1) / FS_LANES; }
+// body(i, entry) for every entry i of the lane's slice, the loads issued eight at a time (a loop of dependent single loads would pay
+// the memory latency once per entry)
+template <typename Body> DG_HD void fs_for_slice(const uint2 *row, uint32_t n, uint32_t len, int lane, Body body) {
+    const uint32_t i0 = (uint32_t)lane * len, i1 = i0 + len < n ? i0 + len : n;
+    for (uint32_t i = i0; i < i1; i += 8) {
+        uint2 q[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t j = 0; j < 8; j++) q[j] = row[i + j < n ? i + j : n - 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t j = 0; j < 8; j++)
+            if (i + j < i1) body(i + j, q[j]);
+    }
 }
 DG_HD void fs_seg_lane(const FsParams &P, int f, uint32_t si) {
     const dg_view &v = P.views[f];
@@ -115,37 +129,32 @@ DG_HD void fs_seg_lane(const FsParams &P, int f, uint32_t si) {
     const int32_t st = fs_seg(P.k, sg, P.sectors, P.anims, V2{v.x, v.y}, v.cos_na, v.sin_na, v.floor_height + 41.0f, v.timestamp, light, so);
     if (st == FS_SKIP) return;
     if (st != FS_OK) { fs_flag(P, f, FE_OVF_SEGS); return; }
-    const uint32_t first = fs_take(&P.cand_cnt[f], (uint32_t)so.n_calls);
-    if (first + (uint32_t)so.n_calls > P.cand_cap) { fs_flag(P, f, FE_OVF_SEGS); return; }
-    FsCand *out = P.cands + (size_t)f * P.cand_cap + first;
-    for (int i = 0; i < so.n_calls; i++) {
-        FsCand &c = out[i];
-        const int32_t ps = fs_part(P.k, so, so.call[i], P.bitmaps, P.flat_sky, v.floor_height, c.part);
-        uint2 &lite = P.cand_lite[(size_t)f * P.cand_cap + first + (uint32_t)i];
-        if (ps == FS_SKIP) { lite = uint2{0u, 0u}; continue; }                 // nothing (a zero-width part)
-        if (ps != FS_OK) { fs_flag(P, f, FE_OVF_SEGS); lite = uint2{0u, 0u}; continue; }
-        lite = uint2{(uint32_t)c.part.sx | ((uint32_t)c.part.ex << 16), c.part.flags | 0x80000000u};
-        c.ax = so.cl.line.a.x; c.ay = so.cl.line.a.y; c.bx = so.cl.line.b.x; c.by = so.cl.line.b.y;
-    }
+    // Only what the hidden-part culling reads is computed here — the columns and the flags of every call; the finished FePart of the
+    // few calls that survive it (a tenth of them) is built afterwards, by dg_fs_frame, from (seg, call).
     const uint32_t leaf = P.seg_leaf[si];
     const uint32_t pos = P.leaf_base[(size_t)f * P.n_leaves + leaf] + (si - P.leaf_first[leaf]);
-    P.ord[(size_t)f * P.n_segs + pos] = (first << 3) | (uint32_t)so.n_calls;
+    uint2 *lite = P.lite + ((size_t)f * P.n_segs + pos) * FS_CALLS;
+    for (int i = 0; i < so.n_calls; i++) {
+        int32_t sx, ex;
+        uint32_t flags;
+        const int32_t ps = fs_part_head(P.k, so, so.call[i], P.bitmaps, P.flat_sky, sx, ex, flags);
+        if (ps == FS_SKIP) continue;                                          // nothing (a zero-width part)
+        if (ps != FS_OK) { fs_flag(P, f, FE_OVF_SEGS); continue; }
+        lite[i] = uint2{(uint32_t)sx | ((uint32_t)ex << 16), flags | 0x100u | (si << 12)};
+        fs_count(&P.slice_cnt[(size_t)f * FS_LANES + (pos * FS_CALLS + (uint32_t)i) / fs_slice_len(P.n_segs)]);
+    }
 }
 
 // ---- dg_fs_frame: one wavefront per frame --------------------------------------------------------------------------------------------
 struct FsShared {                              // LDS on the GPU
     uint32_t lane_cnt[FS_LANES], block_sum[FS_LANES / FS_BLOCK];
-    union {                                    // (the visit-ordered seg list is dead once the candidates are staged)
-        uint32_t vis[FS_VIS_CAP];              // ord entries of the visible segs, in visit order
-        uint32_t first[FS_MAX_W];              // per screen column: visit index of the first full-height solid candidate that spans it
-    };
-    uint32_t n_vis;
-    // every candidate part of the frame in visit order: x = sx | ex << 16, y = FEP_* (bits 0-7) | is-a-part << 8 | candidate slot << 12
-    // | survives the hidden-part culling << 9
-    uint2 cl[FS_CL_CAP];
+    uint32_t first[FS_MAX_W];                  // per screen column: visit index of the first full-height solid candidate that spans it
+    uint32_t cl[FS_CL_CAP];                    // the frame's candidate parts in visit order: sx | ex << 12 | FEP_* << 24
+    uint32_t keepw[FS_CL_CAP / 32];            // bit k: candidate k survives the hidden-part culling
+    uint32_t lane_k0[FS_LANES];                // index in cl[] of the first candidate of the lane's slice of the lite row
     uint32_t n_cl;
     // kept parts
-    uint32_t kept_cand[FS_PART_CAP];           // candidate index
+    uint32_t kept_src[FS_PART_CAP];            // seg << 3 | call
     int16_t kept_sky[FS_PART_CAP];
     uint16_t kept_sx[FS_PART_CAP], kept_ex[FS_PART_CAP];
     uint16_t kept_t[FS_PART_CAP];              // two-sided middle parts: order index of the first sprite they are drawn behind (0xffff: none; 0xfffe: not two-sided)
@@ -160,7 +169,7 @@ struct FsShared {                              // LDS on the GPU
 };
 
 // phase 0 (lane 0): reset
-DG_HD void fs_ph_init(FsShared &S) { S.n_vis = 0; S.n_cl = 0; S.n_parts = 0; S.n_sky = 0; S.n_sprites = 0; S.fail = 0; }
+DG_HD void fs_ph_init(FsShared &S) { S.n_cl = 0; S.n_parts = 0; S.n_sky = 0; S.n_sprites = 0; S.fail = 0; }
 
 // Two-level exclusive prefix over lane_cnt[]: a phase in which the first FS_LANES / FS_BLOCK lanes sum their block, then any lane adds
 // the blocks before its own and the lanes before it in its block (at most 2 FS_BLOCK reads instead of FS_LANES).
@@ -177,56 +186,25 @@ DG_HD uint32_t fs_lane_offset(const FsShared &S, int lane) {
     return at;
 }
 
-// phases 1a / 1b / 1c: the visible segs in visit order.  Lane l owns the slice [l * per, (l + 1) * per) of the frame's ord row.
-DG_HD void fs_ph_count(const FsParams &P, FsShared &S, int f, int lane) {
-    const uint32_t per = (P.n_segs + FS_LANES - 1) / FS_LANES;
-    const uint32_t *ord = P.ord + (size_t)f * P.n_segs;
-    uint32_t n = 0;
-    for (uint32_t i = (uint32_t)lane * per; i < ((uint32_t)lane + 1) * per && i < P.n_segs; i++) n += ord[i] != 0u;
-    S.lane_cnt[lane] = n;
-}
-DG_HD void fs_ph_gather(const FsParams &P, FsShared &S, int f, int lane) {
-    const uint32_t per = (P.n_segs + FS_LANES - 1) / FS_LANES;
-    const uint32_t *ord = P.ord + (size_t)f * P.n_segs;
-    uint32_t at = fs_lane_offset(S, lane);
-    if (lane == FS_LANES - 1) {
-        S.n_vis = at + S.lane_cnt[lane];
-        if (S.n_vis > FS_VIS_CAP) { S.fail = 1; S.n_vis = 0; }
-    }
-    for (uint32_t i = (uint32_t)lane * per; i < ((uint32_t)lane + 1) * per && i < P.n_segs; i++)
-        if (ord[i] != 0u && at < FS_VIS_CAP) S.vis[at++] = ord[i];
-}
-// ---- the hidden-part culling ---------------------------------------------------------------------------------------------------------
-// The host walker drops a part whose columns [sx, ex] are all spanned by full-height solid parts it met EARLIER in the visit order
-// (frontend.cpp process_sidedef: solid_cols.covers, then solid_cols.add for a solid part that survives).  A dropped solid part lies
-// inside the union already, so that union is simply "every solid candidate before this one" — no decision depends on an earlier
-// decision, and the test can run for all candidates at once:  first[c] = visit index of the first solid candidate spanning column c;
-// candidate k survives iff some column of it has first[c] >= k.
-// phases 2a / 2b: the candidates of the visible segs, in visit order, into cl[].  Lane l owns the slice [l * per, ..) of vis[].
-DG_HD void fs_ph_cand_count(FsShared &S, int lane) {
-    const uint32_t per = (S.n_vis + FS_LANES - 1) / FS_LANES;
-    uint32_t n = 0;
-    for (uint32_t i = (uint32_t)lane * per; i < ((uint32_t)lane + 1) * per && i < S.n_vis; i++) n += S.vis[i] & 7u;
-    S.lane_cnt[lane] = n;
-}
+// phases 1a / 1b: the candidates of the frame, in visit order, into cl[].  Lane l owns the slice [l * per, (l + 1) * per) of the frame's
+// lite row (entries that hold no part are skipped; the order of the others is the reference's visit order).
+DG_HD void fs_ph_cand_count(const FsParams &P, FsShared &S, int f, int lane) { S.lane_cnt[lane] = P.slice_cnt[(size_t)f * FS_LANES + lane]; }
 DG_HD void fs_ph_cand_stage(const FsParams &P, FsShared &S, int f, int lane) {
-    const uint32_t per = (S.n_vis + FS_LANES - 1) / FS_LANES;
+    const uint32_t n = P.n_segs * FS_CALLS;
     uint32_t at = fs_lane_offset(S, lane);
+    S.lane_k0[lane] = at;
     if (lane == FS_LANES - 1) {
         S.n_cl = at + S.lane_cnt[lane];
         if (S.n_cl > FS_CL_CAP) { S.fail = 1; S.n_cl = 0; }
     }
-    for (uint32_t i = (uint32_t)lane * per; i < ((uint32_t)lane + 1) * per && i < S.n_vis; i++) {
-        const uint32_t e = S.vis[i];
-        const uint2 *c = P.cand_lite + (size_t)f * P.cand_cap + (e >> 3);
-        for (uint32_t j = 0; j < (e & 7u); j++, at++) {
-            if (at >= FS_CL_CAP) continue;
-            const uint2 q = c[j];
-            S.cl[at] = uint2{q.x, (q.y & 0xffu) | ((q.y >> 31) << 8) | (((e >> 3) + j) << 12)};
-        }
-    }
+    if (lane < (int)(FS_CL_CAP / 32)) S.keepw[lane] = 0;
+    fs_for_slice(P.lite + (size_t)f * n, n, fs_slice_len(P.n_segs), lane, [&](uint32_t, const uint2 q) {
+        if (!(q.y & 0x100u)) return;
+        if (at < FS_CL_CAP) S.cl[at] = (q.x & 0xfffu) | ((q.x >> 16) << 12) | (q.y << 24);
+        at++;
+    });
 }
-// phase 2c: the column table starts empty (it overlays vis[], which is dead from here on)
+// phase 2c: the column table starts empty
 DG_HD void fs_ph_first_clear(const FsParams &P, FsShared &S, int lane) {
     for (int c = lane; c < P.k.W; c += FS_LANES) S.first[c] = 0xffffffffu;
 }
@@ -249,9 +227,9 @@ DG_HD void fs_ph_solids(FsShared &S, int lane) {
     if (S.fail) return;
     const uint32_t g = (uint32_t)lane / FS_GROUP, sub = (uint32_t)lane % FS_GROUP;
     for (uint32_t k = g; k < S.n_cl; k += FS_LANES / FS_GROUP) {
-        const uint2 q = S.cl[k];
-        if (!(q.y & 0x100u) || !fs_part_is_solid(q.y & 0xffu)) continue;
-        const uint32_t sx = q.x & 0xffffu, ex = q.x >> 16;
+        const uint32_t q = S.cl[k];
+        if (!fs_part_is_solid(q >> 24)) continue;
+        const uint32_t sx = q & 0xfffu, ex = (q >> 12) & 0xfffu;
         for (uint32_t c = sx + sub; c <= ex; c += FS_GROUP) fs_min_u32(&S.first[c], k);
     }
 }
@@ -259,25 +237,27 @@ DG_HD void fs_ph_keep(FsShared &S, int lane) {
     if (S.fail) return;
     const uint32_t g = (uint32_t)lane / FS_GROUP, sub = (uint32_t)lane % FS_GROUP;
     for (uint32_t k = g; k < S.n_cl; k += FS_LANES / FS_GROUP) {
-        const uint2 q = S.cl[k];
-        if (!(q.y & 0x100u)) continue;
-        const uint32_t sx = q.x & 0xffffu, ex = q.x >> 16;
+        const uint32_t q = S.cl[k];
+        const uint32_t sx = q & 0xfffu, ex = (q >> 12) & 0xfffu;
         bool open = false;
         for (uint32_t c = sx + sub; c <= ex; c += FS_GROUP) open |= S.first[c] >= k;
-        if (open) fs_or_u32(&S.cl[k].y, 0x200u);
+        if (open) fs_or_u32(&S.keepw[k >> 5], 1u << (k & 31u));
     }
 }
-// phases 2f / 2g: the survivors get their place in the frame's part list (and their sky event slot).  Lane l owns a slice of cl[];
-// lane_cnt packs (survivors | survivors that want a sky slot << 16).
+// phases 2f / 2g: the survivors get their place in the frame's part list (and their sky event slot).  Lane l walks its slice of the lite
+// row again (candidate indices from lane_k0); lane_cnt packs (survivors | survivors that want a sky slot << 16).
 DG_HD void fs_ph_kept_count(FsShared &S, int lane) {
-    const uint32_t per = (S.n_cl + FS_LANES - 1) / FS_LANES;
-    uint32_t n = 0;
-    for (uint32_t k = (uint32_t)lane * per; k < ((uint32_t)lane + 1) * per && k < S.n_cl; k++)
-        if (S.cl[k].y & 0x200u) n += 1u + (fs_part_wants_sky_slot(S.cl[k].y & 0xffu) ? 0x10000u : 0u);
-    S.lane_cnt[lane] = n;
+    // (flags of candidate k: cl[k] >> 24)
+    uint32_t c = 0;
+    if (!S.fail) {
+        const uint32_t k1 = lane + 1 < FS_LANES ? S.lane_k0[lane + 1] : S.n_cl;
+        for (uint32_t k = S.lane_k0[lane]; k < k1; k++)
+            if ((S.keepw[k >> 5] >> (k & 31u)) & 1u) c += 1u + (fs_part_wants_sky_slot(S.cl[k] >> 24) ? 0x10000u : 0u);
+    }
+    S.lane_cnt[lane] = c;
 }
-DG_HD void fs_ph_kept_place(FsShared &S, int lane) {
-    const uint32_t per = (S.n_cl + FS_LANES - 1) / FS_LANES;
+DG_HD void fs_ph_kept_place(const FsParams &P, FsShared &S, int f, int lane) {
+    const uint32_t n = P.n_segs * FS_CALLS;
     const uint32_t off = fs_lane_offset(S, lane);
     uint32_t o = off & 0xffffu, sky = off >> 16;
     if (lane == FS_LANES - 1) {
@@ -285,28 +265,38 @@ DG_HD void fs_ph_kept_place(FsShared &S, int lane) {
         S.n_parts = end & 0xffffu; S.n_sky = end >> 16;
         if (S.n_parts > FS_PART_CAP || S.n_sky > FS_SKY_CAP) { S.fail = 1; S.n_parts = 0; S.n_sky = 0; }
     }
-    for (uint32_t k = (uint32_t)lane * per; k < ((uint32_t)lane + 1) * per && k < S.n_cl; k++) {
-        const uint2 q = S.cl[k];
-        if (!(q.y & 0x200u)) continue;
+    if (S.fail || S.lane_cnt[lane] == 0u) return;                        // (no survivor in this lane's slice: nothing to look up)
+    uint32_t k = S.lane_k0[lane];
+    fs_for_slice(P.lite + (size_t)f * n, n, fs_slice_len(P.n_segs), lane, [&](uint32_t i, const uint2 q) {
+        if (!(q.y & 0x100u)) return;
+        const bool kept = (S.keepw[k >> 5] >> (k & 31u)) & 1u;
+        k++;
+        if (!kept) return;
         const bool wants = fs_part_wants_sky_slot(q.y & 0xffu);
-        if (o < FS_PART_CAP && sky < FS_SKY_CAP + 1u) {
-            S.kept_cand[o] = q.y >> 12;
+        if (o < FS_PART_CAP && sky <= FS_SKY_CAP) {
+            S.kept_src[o] = ((q.y >> 12) << 3) | (i % FS_CALLS);
             S.kept_sky[o] = wants ? (int16_t)sky : (int16_t)-1;
             S.kept_sx[o] = (uint16_t)(q.x & 0xffffu); S.kept_ex[o] = (uint16_t)(q.x >> 16);
             S.kept_t[o] = (q.y & FEP_TWO_SIDED_MID) ? 0xffffu : 0xfffeu;
         }
         o++; sky += wants;
-    }
+    });
 }
-// phase 3: kept part o (lane-strided): the finished FePart to its place, its line to shared memory, its sky slot recorded
+// phase 3: kept part o (lane-strided): process_seg + process_sidedef's head again for its (seg, call) — the finished FePart to its
+// place, its clipped line to shared memory (is_behind_vertex), its sky slot recorded
 DG_HD void fs_ph_emit(const FsParams &P, FsShared &S, int f, int lane) {
     if (S.fail) return;
+    const dg_view &v = P.views[f];
     for (uint32_t o = (uint32_t)lane; o < S.n_parts; o += FS_LANES) {
-        const FsCand &c = P.cands[(size_t)f * P.cand_cap + S.kept_cand[o]];
-        FePart p = c.part;
+        const uint32_t src = S.kept_src[o];
+        const FsSeg &sg = P.segs[src >> 3];
+        FsSegOut so;
+        FePart p;
+        const int32_t st = fs_seg(P.k, sg, P.sectors, P.anims, V2{v.x, v.y}, v.cos_na, v.sin_na, v.floor_height + 41.0f, v.timestamp, P.sector_light[sg.front_sector], so);
+        if (st != FS_OK || fs_part(P.k, so, so.call[src & 7u], P.bitmaps, P.flat_sky, v.floor_height, p) != FS_OK) { S.fail = 1; continue; }   // (cannot happen: dg_fs_segs passed it)
         p.sky_slot = S.kept_sky[o];
         P.parts[(size_t)f * FS_PART_CAP + o] = p;
-        S.kline[o][0] = c.ax; S.kline[o][1] = c.ay; S.kline[o][2] = c.bx; S.kline[o][3] = c.by;
+        S.kline[o][0] = so.cl.line.a.x; S.kline[o][1] = so.cl.line.a.y; S.kline[o][2] = so.cl.line.b.x; S.kline[o][3] = so.cl.line.b.y;
         if (S.kept_sky[o] >= 0) P.sky_parts[(size_t)f * FS_SKY_CAP + (uint32_t)S.kept_sky[o]] = o;
     }
 }

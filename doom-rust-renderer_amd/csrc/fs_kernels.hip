@@ -34,21 +34,14 @@ __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
 #endif
     if (lane == 0) fs_ph_init(S);
     __syncthreads();
-    fs_ph_count(P, S, f, lane);
-    __syncthreads();
-    fs_ph_block_sums(S, lane);
-    __syncthreads();
-    fs_ph_gather(P, S, f, lane);
-    __syncthreads();
-    FS_T()
-    fs_ph_cand_count(S, lane);
+    fs_ph_cand_count(P, S, f, lane);
     __syncthreads();
     fs_ph_block_sums(S, lane);
     __syncthreads();
     fs_ph_cand_stage(P, S, f, lane);
-    __syncthreads();
     fs_ph_first_clear(P, S, lane);
     __syncthreads();
+    FS_T()
     fs_ph_solids(S, lane);
     __syncthreads();
     fs_ph_keep(S, lane);
@@ -57,7 +50,7 @@ __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
     __syncthreads();
     fs_ph_block_sums(S, lane);
     __syncthreads();
-    fs_ph_kept_place(S, lane);
+    fs_ph_kept_place(P, S, f, lane);
     __syncthreads();
     FS_T()
     fs_ph_emit(P, S, f, lane);
@@ -94,7 +87,7 @@ __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
 #ifdef DG_FS_TIMING
     FS_T()
     if (lane == 0 && (f == 100 || f == 500))
-        printf("[fs_frame %d] vis %u parts %u sprites %u | 100 MHz ticks: gather %llu cull %llu emit %llu mobj %llu behind %llu order+when %llu seq %llu bins %llu header %llu\n", f, S.n_vis,
+        printf("[fs_frame %d] cands %u parts %u sprites %u | 100 MHz ticks: stage %llu cull %llu emit %llu mobj %llu behind %llu order+when %llu seq %llu bins %llu header %llu\n", f, S.n_cl,
                S.n_parts, S.n_sprites, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7], tm[8]);
 #endif
 }

@@ -6,7 +6,7 @@
 
 namespace dg {
 
-// dg_fs_order, dg_fs_segs, dg_fs_frame on `stream`.  P.ord, P.cand_cnt and P.flags must be zeroed (in stream order) before the launch.
+// dg_fs_order, dg_fs_segs, dg_fs_frame on `stream`.  P.lite and P.flags must be zeroed (in stream order) before the launch.
 // start: attached to the first kernel's dispatch.
 hipError_t launch_fs(const FsParams &P, hipStream_t stream, hipEvent_t start = nullptr);
 

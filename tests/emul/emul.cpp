@@ -559,9 +559,8 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     for (size_t i = 0; i < sc.sectors.size(); i++) lights[i] = sc.sectors[i].light;
     std::vector<int32_t> mstate(sc.mobjs.size());
     for (size_t i = 0; i < sc.mobjs.size(); i++) mstate[i] = sc.mobjs[i].sprite_frame < 0 ? -1 : sc.mobjs[i].sprite_frame * 2 + (sc.mobjs[i].full_bright ? 1 : 0);
-    std::vector<uint32_t> leaf_base(sc.subsectors.size() + 1), ord(sc.segs.size() + 1, 0), cand_cnt(1, 0), flags(1, 0);
-    std::vector<FsCand> cands(FS_CAND_CAP_MAX);
-    std::vector<uint2> cand_lite(FS_CAND_CAP_MAX);
+    std::vector<uint32_t> leaf_base(sc.subsectors.size() + 1), flags(1, 0);
+    std::vector<uint2> lite(sc.segs.size() * FS_CALLS + 1, uint2{0u, 0u});
     std::vector<FeFrame> ffr(1);
     std::vector<FePart> parts(FS_PART_CAP);
     std::vector<FeSprite> sprites(FS_SPRITE_CAP);
@@ -573,11 +572,11 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     P.sectors = sc.fs_sectors.data(); P.anims = sc.fs_anims.data(); P.bitmaps = sc.fs_bitmaps.data(); P.flat_sky = sc.flat_sky.data();
     P.mobjs = sc.fs_mobjs.data(); P.sframes = sc.sprite_frames_fs();
     P.nodes = sc.fs_nodes.data(); P.anc_off = sc.fs_anc_off.data(); P.anc = sc.fs_anc.data();
-    P.cand_cap = FS_CAND_CAP_MAX;
     P.n_segs = (uint32_t)sc.segs.size(); P.n_leaves = (uint32_t)sc.subsectors.size(); P.n_mobjs = (uint32_t)sc.mobjs.size();
     P.sector_light = lights.data(); P.mobj_state = mstate.data();
     P.views = &view; P.n_frames = 1;
-    P.leaf_base = leaf_base.data(); P.ord = ord.data(); P.cand_cnt = cand_cnt.data(); P.cands = cands.data(); P.cand_lite = cand_lite.data(); P.flags = flags.data();
+    std::vector<uint32_t> slice_cnt(FS_LANES, 0);
+    P.leaf_base = leaf_base.data(); P.lite = lite.data(); P.slice_cnt = slice_cnt.data(); P.flags = flags.data();
     P.fframes = ffr.data(); P.parts = parts.data(); P.sprites = sprites.data(); P.behind = behind.data(); P.sky_parts = sky_parts.data();
     P.bin_off = bin_off.data(); P.bin_parts = bin_parts.data(); P.sbin_off = sbin_off.data(); P.sbin_sprites = sbin_sprites.data();
 
@@ -588,10 +587,7 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     uint32_t bin_cnt[2][256];
 #define LANES(body) for (int lane = 0; lane < FS_LANES; lane++) { body; }
     fs_ph_init(S);
-    LANES(fs_ph_count(P, S, 0, lane))
-    LANES(fs_ph_block_sums(S, lane))
-    LANES(fs_ph_gather(P, S, 0, lane))
-    LANES(fs_ph_cand_count(S, lane))
+    LANES(fs_ph_cand_count(P, S, 0, lane))
     LANES(fs_ph_block_sums(S, lane))
     LANES(fs_ph_cand_stage(P, S, 0, lane))
     LANES(fs_ph_first_clear(P, S, lane))
@@ -599,7 +595,7 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     LANES(fs_ph_keep(S, lane))
     LANES(fs_ph_kept_count(S, lane))
     LANES(fs_ph_block_sums(S, lane))
-    LANES(fs_ph_kept_place(S, lane))
+    LANES(fs_ph_kept_place(P, S, 0, lane))
     LANES(fs_ph_emit(P, S, 0, lane))
     for (uint32_t base = 0; base < P.n_mobjs; base += FS_LANES) {
         const uint32_t n_before = S.n_sprites;
@@ -617,7 +613,7 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     fs_ph_header(P, S, 0);
 #undef LANES
     const FeFrame &ff = ffr[0];
-    if (stats) { stats[0] = ff.n_parts; stats[1] = ff.n_sprites; stats[2] = ff.n_sky_slots; stats[3] = flags[0]; stats[4] = S.n_vis; stats[5] = cand_cnt[0]; }
+    if (stats) { stats[0] = ff.n_parts; stats[1] = ff.n_sprites; stats[2] = ff.n_sky_slots; stats[3] = flags[0]; stats[4] = 0; stats[5] = S.n_cl; }
     if (host_rc) {                                    // the host walker refuses the frame: the device walk must have given it up too
         if (!(flags[0] & FE_OVF_SEGS)) { g_err = "host walker fails (" + g_err + ") but the device seg walk did not flag the frame"; return -1; }
         return 1;
