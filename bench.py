@@ -255,7 +255,7 @@ class DoomGpuBackend:
             self.path = self.cp.make_camera_path(seeded_route(route, path_seed), lambda x, y, d: self.scene.floor_height_at(x, y, d), PATH_FRAMES)
         B = a.batch
         self.n_slots = max(1, a.slots)                # (with fewer batches per step than slots, a slot holds the same batch every other step)
-        fe = {"host": self.dg.DG_FE_HOST, "device": self.dg.DG_FE_DEVICE, "segs": self.dg.DG_FE_DEVICE_SEGS}[a.front_end]
+        fe = {"host": self.dg.DG_FE_HOST, "device": self.dg.DG_FE_DEVICE, "segs": self.dg.DG_FE_DEVICE_SEGS, "auto": self.dg.DG_FE_AUTO}[a.front_end]
         self.ctx = self.dg.Context(a.width, a.height, max_batch=B, slots=self.n_slots, device=self.device, host_threads=a.host_threads or default_host_threads(getattr(a, "local_world", 1)), front_end=fe)
         self.ctx.upload_scene(self.scene)
         loop = np.concatenate([self.path, self.path])
@@ -343,6 +343,7 @@ def run(args, backend_factory=DoomGpuBackend):
     sync_all()
     raster_ms, setup_ms, host_ms, alg_bytes = [], [], [], []
     stats = {}
+    fe_used = {}
 
     def collect(slot):
         t = ctx.timing(slot)
@@ -351,7 +352,9 @@ def run(args, backend_factory=DoomGpuBackend):
         host_ms.append(t["host_ms"])
         nf = t["n_frames"]
         alg_bytes.append(nf * (3 * W * H + W * H + 4 * (W + 1)) + 32 * t["n_spans"])
-        stats.update(t)
+        fe_used[t.get("front_end", 2)] = fe_used.get(t.get("front_end", 2), 0) + 1
+        if t.get("front_end", 2) != 3 or "host_ms" not in stats:
+            stats.update(t)
 
     t0 = time.perf_counter()
     step_end = []
@@ -449,7 +452,8 @@ def run(args, backend_factory=DoomGpuBackend):
 
     line = None
     if rank == 0:
-        fe_name = {1: "host span lists", 2: "device column walk (per-seg half on the host)", 3: "device seg walk + device column walk (nothing on the host)"}[stats.get("front_end", 2)]
+        names = {1: "host span lists", 2: "device column walk (per-seg half on the host)", 3: "device seg walk + device column walk (nothing on the host)"}
+        fe_name = "; ".join(f"{names[k]}: {v} batch(es)" for k, v in sorted(fe_used.items())) or names[2]
         line = {
             "metric": "frames/sec (fixed e1m1 camera path)", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -638,8 +642,9 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="frames per batch; must divide the 1000-frame path")
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--host-threads", type=int, default=0)
-    ap.add_argument("--front-end", choices=["device", "host", "segs"], default="device",
-                    help="host: everything of the front end on the host; device: the per-column half on the GPU (DG_FE_DEVICE); segs: the per-seg half too (DG_FE_DEVICE_SEGS)")
+    ap.add_argument("--front-end", choices=["auto", "device", "host", "segs"], default="auto",
+                    help="host: everything of the front end on the host; device: the per-column half on the GPU (DG_FE_DEVICE); segs: the per-seg half too "
+                         "(DG_FE_DEVICE_SEGS); auto (default, DG_FE_AUTO): device or segs per batch, whichever the library measures to be faster")
     ap.add_argument("--cpu-sample", type=int, default=4, help="cpu_baseline renders every n-th path frame")
     ap.add_argument("--wad", default=None, help="IWAD file to render instead of the synthetic one (e.g. doom1.wad); the camera path is derived from the map")
     ap.add_argument("--map", default="e1m1")

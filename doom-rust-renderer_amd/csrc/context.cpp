@@ -137,6 +137,7 @@ struct Slot {
     FeParams FP{};
     FsParams FSP{};               // DG_FE_DEVICE_SEGS: the device seg walk in front of the column walk
     bool fs_mode = false;         // the last submission's per-seg half ran on the GPU too
+    bool harvested = true;        // DG_FE_AUTO has read this submission's GPU time
     bool fe_mode = false;         // the last submission went through the device column walk
     bool fe_check = false;        // ... and its overflow flags have not been looked at yet
     std::vector<dg_view> views;   // the views of that submission (to redo it on the host if a capacity overflowed)
@@ -191,6 +192,13 @@ struct dg_ctx {
     bool fe_scene_ok = false;           // ... and the uploaded scene allows it (sky bitmap >= 256x128, see bin_frame)
     // device seg walk (DG_FE_DEVICE_SEGS): the scene's per-seg tables + BSP tables in one allocation, per-batch scratch sized by the scene
     bool fs_enabled = false, fs_scene_ok = false;
+    bool preparing = false;             // inside dg_prepare_views: the records are built once and replayed — host time is not in the loop
+    bool fs_forced = false;             // DG_FE_DEVICE_SEGS: always; DG_FE_AUTO: when it is the faster way for the batch at hand (choose_fs)
+    // what DG_FE_AUTO decides by (running means over batches of >= 64 frames, ms per frame): the host's per-seg half, and the whole of the
+    // GPU work of a batch with / without the seg walk in it
+    double ema_host = -1.0, ema_gpu_dev = -1.0, ema_gpu_fs = -1.0;
+    int host_samples = 0;               // batches the host walker was timed on (the first one pays for cold caches and arena growth: not counted)
+    int since_probe = 0;                // seg-walk batches since the host walker was last timed (it is timed again every 32 batches)
     uint8_t *d_fs_scene = nullptr;
     uint8_t *d_fs_scratch = nullptr;    // candidate rows F x n_segs x 5 x 8 B (zeroed per batch) | leaf_base F x n_leaves
     size_t fs_zero_bytes = 0;
@@ -422,7 +430,7 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_vie
     F.sprites = reinterpret_cast<const FeSprite *>(s.d_fe + off_sprites);
     F.behind = reinterpret_cast<const uint32_t *>(s.d_fe + off_behind);
     F.sky_parts = reinterpret_cast<const uint32_t *>(s.d_fe + off_sky);
-    F.max_sky_slots = max_sky;
+    F.max_sky_slots = max_sky; F.gap_waves = 0;
     F.bin_off = reinterpret_cast<const uint32_t *>(s.d_fe + off_boff);
     F.sbin_off = reinterpret_cast<const uint32_t *>(s.d_fe + off_sboff);
     F.bin_parts = reinterpret_cast<const uint16_t *>(s.d_fe + off_bins);
@@ -449,6 +457,10 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_vie
     s.views.assign(views, views + n);
     s.keep_states(states, n);
     s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (n >= 64 && !states && c->host_samples++ > 0) {        // DG_FE_AUTO's measurement of the host side (the first batch pays for cold caches: not counted)
+        const double v = (double)s.host_ms / n;
+        c->ema_host = c->host_samples == 2 ? v : 0.75 * c->ema_host + 0.25 * v;
+    }
     HIP_TRY(hipMemcpyAsync(s.d_fe, s.h_fe, total, hipMemcpyHostToDevice, s.stream));
     return DG_OK;
 }
@@ -498,6 +510,41 @@ int upload_fs_scene(dg_ctx *c, const Scene &sc) {
     P.leaf_base = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_leaf);
     c->fs_scene_ok = true;
     return DG_OK;
+}
+
+// DG_FE_AUTO: should this batch's per-seg half run on the GPU?  The host does it for free as long as it is done before the GPU has
+// finished the batches queued ahead (its time hides under theirs); the GPU pays for it (dg_fs_*: ~0.1 ms per 1 000 frames) but needs
+// no host time.  So: when nothing is in flight the host's time would be exposed in full — the GPU does it, unless the batch is so small
+// that the kernels' fixed latency exceeds the host's few microseconds per frame; in a filled pipeline the GPU does it when the host has
+// been measured to be the slower of the two (few host threads, small frames).  Small batches (< 64 frames) always go to the host walker.
+void harvest_gpu_time(dg_ctx *c, Slot &s);
+// First guess of the host walker's speed without spending a whole batch on it: a dozen of the batch's views on the calling thread
+// (four untimed ones first), scaled by the pool size.  Whole batches that do go through the host walker refine it (build_batch_fe).
+void calibrate_host(dg_ctx *c, const dg_view *views, int n) {
+    const Scene &sc = *c->scene;
+    FrameArena &A = *c->arenas[0];
+    std::string err;
+    const int warm = std::min(4, n), timed = std::min(8, n);
+    for (int i = 0; i < warm; i++) { dg_view v = views[i]; fill_view_trig(v); (void)build_frame_parts(sc, c->cfg.width, c->cfg.height, v, A, err); }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < timed; i++) { dg_view v = views[n - 1 - i]; fill_view_trig(v); (void)build_frame_parts(sc, c->cfg.width, c->cfg.height, v, A, err); }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c->ema_host = ms / timed / std::max(1, c->n_threads) * 1.25;     // (the pool does not scale perfectly)
+    c->host_samples = std::max(c->host_samples, 2);
+}
+bool choose_fs(dg_ctx *c, const dg_view *views, int n) {
+    if (c->fs_forced) return true;
+    if (n < 64 || c->preparing) return false;
+    if (c->ema_host < 0.0) calibrate_host(c, views, n);
+    bool in_flight = false;
+    for (Slot &s : c->slots) { harvest_gpu_time(c, s); in_flight |= s.busy; }
+    if (!in_flight) return true;
+    bool fs = c->ema_gpu_fs < 0.0 ? (c->ema_gpu_dev > 0.0 && c->ema_host > c->ema_gpu_dev)   // host slower than the GPU's own share: try the seg walk
+                                  : c->ema_host > c->ema_gpu_fs;
+    // time the host walker again now and then (its speed depends on who else uses the CPUs); rarely when it was far behind
+    if (fs && ++c->since_probe >= (c->ema_gpu_fs > 0.0 && c->ema_host > 2.0 * c->ema_gpu_fs ? 256 : 32)) fs = false;
+    if (!fs) c->since_probe = 0;
+    return fs;
 }
 
 // DG_FE_DEVICE_SEGS: nothing of the front end runs on the host.  Per frame it ships the view (trig filled) and the DevFrame header,
@@ -565,7 +612,7 @@ int build_batch_fs(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     F.k = c->dk;
     F.frames = reinterpret_cast<const DevFrame *>(s.d_fe + off_frames);
     F.fframes = Q.fframes; F.parts = Q.parts; F.sprites = Q.sprites; F.behind = Q.behind; F.sky_parts = Q.sky_parts;
-    F.max_sky_slots = FS_SKY_CAP;
+    F.max_sky_slots = FS_SKY_CAP; F.gap_waves = 12;
     F.bin_off = Q.bin_off; F.sbin_off = Q.sbin_off; F.bin_parts = Q.bin_parts; F.sbin_sprites = Q.sbin_sprites;
     F.cspans = c->d_fe_cspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt;
     F.events = s.d_events;
@@ -593,7 +640,7 @@ int build_batch_fs(dg_ctx *c, Slot &s, const dg_view *views, int n) {
 }
 
 int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *given, int n, const dg_view_state *states = nullptr) {
-    if (!given && !states && c->fs_enabled && c->fs_scene_ok) {
+    if (!given && !states && c->fs_enabled && c->fs_scene_ok && choose_fs(c, views, n)) {
         const int rc = build_batch_fs(c, s, views, n);
         if (rc != kPartsUnsupported) return rc;
     }
@@ -637,6 +684,7 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
     }
     HIP_TRY(launch_raster(s.P, ks, s.ev_rstart, s.ev_raster));
     guard.armed = false;
+    s.harvested = false;
     s.fe_check = fe_mode;
     s.raster_recorded = true;
     s.busy = true; s.timed = true;
@@ -736,10 +784,23 @@ int enqueue_copy(dg_ctx *c, Slot &s) {
     return DG_OK;
 }
 
+// DG_FE_AUTO's measurement of the GPU side: the span of a finished submission's kernels (never waits)
+void harvest_gpu_time(dg_ctx *c, Slot &s) {
+    if (s.harvested || !s.timed || !s.fe_mode || s.n_frames < 64 || c->fs_forced || !c->fs_enabled) return;
+    if (hipEventQuery(s.ev_raster) != hipSuccess) return;
+    s.harvested = true;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, s.ev_start, s.ev_raster) != hipSuccess || !(ms > 0.0f)) return;
+    double &ema = s.fs_mode ? c->ema_gpu_fs : c->ema_gpu_dev;
+    const double v = (double)ms / s.n_frames;
+    ema = ema < 0.0 ? v : 0.75 * ema + 0.25 * v;
+}
+
 // Everything queued for the slot has finished: kernels, capacity checks (a batch that overflowed is redone here) and a
 // pending asynchronous readback (re-issued after a redo: its first copy took frames of the overflowed run).
 int finish_slot(dg_ctx *c, Slot &s) {
     HIP_TRY(slot_sync(s));
+    harvest_gpu_time(c, s);
     s.busy = false;
     const uint64_t redone = c->fallbacks_fe;
     int rc = settle_slot(c, s);
@@ -876,7 +937,8 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
                              align_up(c->wall_cap_per_batch * sizeof(DevWallRec), 256) +
                              align_up(c->plane_cap_per_batch * sizeof(DevPlaneRec), 256) + c->span_cap_per_batch * sizeof(DevSpan) + 1024;
     c->fe_enabled = cfg->front_end != DG_FE_HOST;
-    c->fs_enabled = cfg->front_end == DG_FE_DEVICE_SEGS;
+    c->fs_enabled = cfg->front_end == DG_FE_DEVICE_SEGS || cfg->front_end == DG_FE_AUTO;
+    c->fs_forced = cfg->front_end == DG_FE_DEVICE_SEGS;
     if (c->fe_enabled) {
         // Scratch slots per screen column (spans and wall-record columns).  A column that needs more sends its batch through
         // the host list path; DOOMGPU_FE_COLUMN_SLOTS trades scratch HBM (24 B x slots x width x max_batch) against that.
@@ -1135,7 +1197,9 @@ int dg_prepare_views(dg_ctx *c, int slot, const dg_view *views, int n) {
     if (s.busy || s.copy_pending) { rc = finish_slot(c, s); if (rc) return rc; }   // incl. a readback still copying out of the slot's framebuffer
     HIP_TRY(slot_sync(s));
     s.busy = false; s.fe_check = false;
+    c->preparing = true;
     rc = build_batch(c, s, views, nullptr, n);
+    c->preparing = false;
     if (rc) return rc;
     if (s.fe_mode) {              // run the column walk once so that a batch that has to go through the host list path as a whole
         rc = enqueue_kernels(c, s);   // is re-prepared that way now, not on a replay

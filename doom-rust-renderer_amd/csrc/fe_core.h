@@ -50,7 +50,8 @@ struct FeParams {
     int32_t n_frames;
     uint32_t span_stride;         // rspans reserved per frame
     uint32_t w64;                 // (W + 63) / 64 = number of column bins
-    uint32_t max_sky_slots;       // max n_sky_slots over the frames of the batch (grid of dg_fe_gaps)
+    uint32_t max_sky_slots;       // max n_sky_slots over the frames of the batch (grid of dg_fe_gaps; stride of the event rows)
+    uint32_t gap_waves;           // 0: one wave of dg_fe_gaps per sky slot; else this many per frame, striding over its slots (the bound is loose)
     uint32_t col_slots;           // span slots and wall-record slots per screen column in the scratch arrays (<= FE_MAX_COL_SLOTS)
 };
 

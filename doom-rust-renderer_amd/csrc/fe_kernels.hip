@@ -121,10 +121,11 @@ __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
 __global__ __launch_bounds__(64) void dg_fe_gaps(FeParams P) {
     const int f = blockIdx.y;
     const FeFrame ff = P.fframes[f];
-    const uint32_t si = blockIdx.x;
-    if (si >= ff.n_sky_slots) return;
     const int W = P.k.W;
     const int lane = (int)threadIdx.x;
+    // (the grid's x extent is the batch's largest sky slot count when the host knows it; the device seg walk only knows a bound, and
+    // launches FE_GAP_WAVES waves per frame that stride over the frame's slots)
+    for (uint32_t si = blockIdx.x; si < ff.n_sky_slots; si += gridDim.x) {
     const uint32_t pi = P.sky_parts[ff.sky_base + si];
     const FePart &p = P.parts[ff.part_base + pi];
     const int sx = p.sx, ex = p.ex;
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(64) void dg_fe_gaps(FeParams P) {
             P.cspans[((size_t)f * P.col_slots + slot) * (size_t)W + (size_t)x] =
                 FeU4{FE_KEY_PLANE | (pi << 2) | (uint32_t)kind, 0u, 0u, (uint32_t)SPAN_SKY << FES_KIND_SHIFT};
         }
+    }
     }
 }
 
@@ -246,7 +248,7 @@ hipError_t launch_fe(const FeParams &P, hipStream_t stream, hipEvent_t start, hi
     }
     dim3 grid((unsigned)((P.k.W + FE_COL_THREADS - 1) / FE_COL_THREADS), (unsigned)P.n_frames);
     hipExtLaunchKernelGGL(dg_fe_columns, grid, dim3(FE_COL_THREADS), 0, stream, start, nullptr, 0, P);
-    if (P.max_sky_slots) hipLaunchKernelGGL(dg_fe_gaps, dim3(P.max_sky_slots, (unsigned)P.n_frames), dim3(64), 0, stream, P);
+    if (P.max_sky_slots) hipLaunchKernelGGL(dg_fe_gaps, dim3(P.gap_waves ? std::min(P.gap_waves, P.max_sky_slots) : P.max_sky_slots, (unsigned)P.n_frames), dim3(64), 0, stream, P);
     hipLaunchKernelGGL(dg_fe_scan, dim3((unsigned)P.n_frames), dim3(FE_SCAN_THREADS), 0, stream, P);
     hipExtLaunchKernelGGL(dg_fe_scatter, dim3((unsigned)((P.k.W + 63) / 64), (unsigned)P.n_frames), dim3(64 * FE_SCATTER_GROUPS),
                           (uint32_t)((size_t)FE_SCATTER_STAGE * 32 + (size_t)P.col_slots * 64 * 4), stream, nullptr, stop, 0, P);

@@ -110,7 +110,10 @@ typedef struct dg_config {
  *                      the BSP order): the host ships 88 bytes per view and nothing else.  Frames it cannot judge (a reference panic,
  *                      a capacity), batches with per-view game state (dg_submit_views_state) and maps in which a texture / flat lookup
  *                      would panic fall back to DG_FE_DEVICE / DG_FE_HOST transparently.
- *   DG_FE_AUTO         = DG_FE_DEVICE */
+ *   DG_FE_AUTO         DG_FE_DEVICE or DG_FE_DEVICE_SEGS per batch, whichever is the faster way for it: the GPU takes the per-seg half when
+ *                      nothing is in flight (the host's time would be exposed) or when the host has been measured to be the slower
+ *                      side (few host threads, small frames); batches of fewer than 64 views always use the host walker.  The pixels
+ *                      are the same whichever is picked; dg_timing.front_end says which one it was. */
 enum { DG_FE_AUTO = 0, DG_FE_HOST = 1, DG_FE_DEVICE = 2, DG_FE_DEVICE_SEGS = 3 };
 
 int dg_create(const dg_config *cfg, dg_ctx **out);

@@ -238,7 +238,7 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
     P.behind = arena.behind.data(); P.bin_off = arena.bin_off.data(); P.bin_parts = arena.bin_parts.data();
     P.sbin_off = arena.sbin_off.data(); P.sbin_sprites = arena.sbin_sprites.data(); P.cspans = cspans.data(); P.recs = recs.data(); P.cnt = cnt.data();
     P.events = events.data(); P.flags = flags.data(); P.totals = nullptr; P.col_off = col_off.data(); P.rspans = rspans.data();
-    P.n_frames = 1; P.max_sky_slots = arena.n_sky_slots; P.span_stride = (uint32_t)rspans.size(); P.w64 = w64; P.col_slots = FE_DEFAULT_COL_SLOTS;
+    P.n_frames = 1; P.max_sky_slots = arena.n_sky_slots; P.gap_waves = 0; P.span_stride = (uint32_t)rspans.size(); P.w64 = w64; P.col_slots = FE_DEFAULT_COL_SLOTS;
 
     // dg_fe_columns, one "lane" at a time
     for (int x = 0; x < W; x++) {
