@@ -192,6 +192,7 @@ struct dg_ctx {
     bool fe_scene_ok = false;           // ... and the uploaded scene allows it (sky bitmap >= 256x128, see bin_frame)
     // device seg walk (DG_FE_DEVICE_SEGS): the scene's per-seg tables + BSP tables in one allocation, per-batch scratch sized by the scene
     bool fs_enabled = false, fs_scene_ok = false;
+    bool fs_rows_dirty = true;          // the seg walk's candidate rows may hold entries (fresh allocation, or a launch that failed half way)
     bool preparing = false;             // inside dg_prepare_views: the records are built once and replayed — host time is not in the loop
     bool fs_forced = false;             // DG_FE_DEVICE_SEGS: always; DG_FE_AUTO: when it is the faster way for the batch at hand (choose_fs)
     // what DG_FE_AUTO decides by (running means over batches of >= 64 frames, ms per frame): the host's per-seg half, and the whole of the
@@ -505,6 +506,7 @@ int upload_fs_scene(dg_ctx *c, const Scene &sc) {
     c->fs_zero_bytes = off_lite + F * (size_t)P.n_segs * FS_CALLS * sizeof(uint2);
     const size_t off_leaf = align_up(c->fs_zero_bytes, 256);
     HIP_TRY(hipMalloc((void **)&c->d_fs_scratch, off_leaf + F * P.n_leaves * 4));
+    c->fs_rows_dirty = true;
     P.slice_cnt = reinterpret_cast<uint32_t *>(c->d_fs_scratch);
     P.lite = reinterpret_cast<uint2 *>(c->d_fs_scratch + off_lite);
     P.leaf_base = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_leaf);
@@ -675,8 +677,10 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
         const size_t ev_bytes = (size_t)3 * (size_t)s.FP.n_frames * s.FP.max_sky_slots * s.FP.w64 * 8;   // all three event kinds (fe_event_words)
         HIP_TRY(hipMemsetAsync(s.d_flags, 0, s.flags_bytes + ev_bytes, ks));                            // the overflow flags and the event bits behind them
         if (s.fs_mode) {                                                                                // the seg walk writes what the column walk reads
-            HIP_TRY(hipMemsetAsync(c->d_fs_scratch, 0, (size_t)(reinterpret_cast<uint8_t *>(s.FSP.lite) - c->d_fs_scratch) + (size_t)s.FSP.n_frames * s.FSP.n_segs * FS_CALLS * sizeof(uint2), ks));   // slice counters + candidate rows
+            if (c->fs_rows_dirty) HIP_TRY(hipMemsetAsync(c->d_fs_scratch, 0, c->fs_zero_bytes, ks));    // (dg_fs_frame leaves its rows clean)
+            c->fs_rows_dirty = true;
             HIP_TRY(launch_fs(s.FSP, ks, s.ev_start));
+            c->fs_rows_dirty = false;
         }
         HIP_TRY(launch_fe(s.FP, ks, s.fs_mode ? nullptr : s.ev_start, s.ev_setup));
     } else {

@@ -392,42 +392,73 @@ DG_HD void fs_ph_seq(const FsParams &P, FsShared &S, int f, int lane) {
         P.parts[(size_t)f * FS_PART_CAP + r].seq = (t == 0xffffu ? S.n_sprites : t) + earlier;
     }
 }
-// phases 9a / 9b / 9c: the column bins (frontend.cpp bin_by_columns).  9a: bin b's counts; 9b (lane 0): offsets; 9c: the lists, in order.
-DG_HD void fs_ph_bin_count(const FsParams &P, FsShared &S, int lane, uint32_t *cnt_parts, uint32_t *cnt_sprites) {
+// phases 9a .. 9e: the column bins (frontend.cpp bin_by_columns: for every FE_BIN_W-column strip the parts, and the sprites, that touch
+// it, in order).  A bin's members are a bit mask over the part (sprite) indices — set by one lane per part, counted per bin, and a
+// member's place in its bin's list is the number of mask bits below its own.  The masks live in first[], which is dead by now.
+constexpr uint32_t FS_MASK_WORDS = 8;          // 256 parts / sprites
+static_assert(FS_PART_CAP <= 32 * FS_MASK_WORDS && FS_SPRITE_CAP <= 32 * FS_MASK_WORDS, "bin masks");
+static_assert((FS_MAX_W / FE_BIN_W) * (2 * FS_MASK_WORDS + 2) <= FS_MAX_W, "bin masks fit first[]");
+DG_HD uint32_t *fs_bin_mask(FsShared &S, uint32_t nb, uint32_t kind, uint32_t b) { return S.first + (kind * nb + b) * FS_MASK_WORDS; }   // kind 0 parts, 1 sprites
+DG_HD uint32_t *fs_bin_off(FsShared &S, uint32_t nb, uint32_t kind) { return S.first + 2 * nb * FS_MASK_WORDS + kind * nb; }
+DG_HD uint32_t fs_popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+DG_HD void fs_ph_bin_clear(const FsParams &P, FsShared &S, int lane) {
     const uint32_t nb = (uint32_t)(P.k.W + FE_BIN_W - 1) / FE_BIN_W;
-    for (uint32_t b = (uint32_t)lane; b < nb; b += FS_LANES) {
-        uint32_t np = 0, ns = 0;
-        if (!S.fail) {
-            for (uint32_t r = 0; r < S.n_parts; r++) np += (uint32_t)(S.kept_sx[r] / FE_BIN_W) <= b && b <= (uint32_t)(S.kept_ex[r] / FE_BIN_W);
-            for (uint32_t s = 0; s < S.n_sprites; s++) ns += S.s_x0b[s] <= b && b <= S.s_x1b[s];
-        }
-        cnt_parts[b] = np; cnt_sprites[b] = ns;
+    for (uint32_t i = (uint32_t)lane; i < nb * (2 * FS_MASK_WORDS + 2); i += FS_LANES) S.first[i] = 0u;
+}
+DG_HD void fs_ph_bin_mark(const FsParams &P, FsShared &S, int lane) {
+    if (S.fail) return;
+    const uint32_t nb = (uint32_t)(P.k.W + FE_BIN_W - 1) / FE_BIN_W;
+    for (uint32_t r = (uint32_t)lane; r < S.n_parts; r += FS_LANES)
+        for (uint32_t b = (uint32_t)S.kept_sx[r] / FE_BIN_W; b <= (uint32_t)S.kept_ex[r] / FE_BIN_W; b++) fs_or_u32(&fs_bin_mask(S, nb, 0, b)[r >> 5], 1u << (r & 31u));
+    for (uint32_t q = (uint32_t)lane; q < S.n_sprites; q += FS_LANES)
+        for (uint32_t b = S.s_x0b[q]; b <= S.s_x1b[q] && b < nb; b++) fs_or_u32(&fs_bin_mask(S, nb, 1, b)[q >> 5], 1u << (q & 31u));
+}
+DG_HD void fs_ph_bin_count(const FsParams &P, FsShared &S, int lane) {
+    const uint32_t nb = (uint32_t)(P.k.W + FE_BIN_W - 1) / FE_BIN_W;
+    for (uint32_t i = (uint32_t)lane; i < 2 * nb; i += FS_LANES) {
+        const uint32_t *m = fs_bin_mask(S, nb, i / nb, i % nb);
+        uint32_t c = 0;
+        for (uint32_t w = 0; w < FS_MASK_WORDS; w++) c += fs_popc(m[w]);
+        fs_bin_off(S, nb, i / nb)[i % nb] = c;
     }
 }
-DG_HD void fs_ph_bin_prefix(const FsParams &P, FsShared &S, int f, uint32_t *cnt_parts, uint32_t *cnt_sprites) {      // lane 0
+DG_HD void fs_ph_bin_prefix(const FsParams &P, FsShared &S, int f) {      // lane 0
     const uint32_t nb = (uint32_t)(P.k.W + FE_BIN_W - 1) / FE_BIN_W;
     uint32_t *bo = P.bin_off + (size_t)f * (nb + 1), *so = P.sbin_off + (size_t)f * (nb + 1);
+    uint32_t *cp = fs_bin_off(S, nb, 0), *cs = fs_bin_off(S, nb, 1);
     uint32_t rp = 0, rs = 0;
     for (uint32_t b = 0; b < nb; b++) {
-        const uint32_t np = cnt_parts[b], ns = cnt_sprites[b];
+        const uint32_t np = cp[b], ns = cs[b];
         bo[b] = rp; so[b] = rs;
-        cnt_parts[b] = rp; cnt_sprites[b] = rs;
+        cp[b] = rp; cs[b] = rs;
         rp += np; rs += ns;
     }
     bo[nb] = rp; so[nb] = rs;
     if (rp > FS_BIN_CAP || rs > FS_SBIN_CAP) S.fail = 1;
 }
-DG_HD void fs_ph_bin_fill(const FsParams &P, FsShared &S, int f, int lane, const uint32_t *off_parts, const uint32_t *off_sprites) {
+DG_HD void fs_ph_bin_fill(const FsParams &P, FsShared &S, int f, int lane) {
     if (S.fail) return;
     const uint32_t nb = (uint32_t)(P.k.W + FE_BIN_W - 1) / FE_BIN_W;
-    for (uint32_t b = (uint32_t)lane; b < nb; b += FS_LANES) {
-        uint16_t *bp = P.bin_parts + (size_t)f * FS_BIN_CAP + off_parts[b];
-        for (uint32_t r = 0; r < S.n_parts; r++)
-            if ((uint32_t)(S.kept_sx[r] / FE_BIN_W) <= b && b <= (uint32_t)(S.kept_ex[r] / FE_BIN_W)) *bp++ = (uint16_t)r;
-        uint16_t *sp = P.sbin_sprites + (size_t)f * FS_SBIN_CAP + off_sprites[b];
-        for (uint32_t s = 0; s < S.n_sprites; s++)
-            if (S.s_x0b[s] <= b && b <= S.s_x1b[s]) *sp++ = (uint16_t)s;
-    }
+    auto place = [&](uint32_t kind, uint32_t i, uint32_t b) {
+        const uint32_t *m = fs_bin_mask(S, nb, kind, b);
+        uint32_t rank = fs_popc(m[i >> 5] & ((1u << (i & 31u)) - 1u));
+        for (uint32_t w = 0; w < (i >> 5); w++) rank += fs_popc(m[w]);
+        return fs_bin_off(S, nb, kind)[b] + rank;
+    };
+    for (uint32_t r = (uint32_t)lane; r < S.n_parts; r += FS_LANES)
+        for (uint32_t b = (uint32_t)S.kept_sx[r] / FE_BIN_W; b <= (uint32_t)S.kept_ex[r] / FE_BIN_W; b++)
+            P.bin_parts[(size_t)f * FS_BIN_CAP + place(0, r, b)] = (uint16_t)r;
+    for (uint32_t q = (uint32_t)lane; q < S.n_sprites; q += FS_LANES)
+        for (uint32_t b = S.s_x0b[q]; b <= S.s_x1b[q] && b < nb; b++)
+            P.sbin_sprites[(size_t)f * FS_SBIN_CAP + place(1, q, b)] = (uint16_t)q;
+}
+// phase 10a: the frame's candidate row and slice counters go back to zero for the next batch (the rows are zeroed once, at upload: a
+// memset of all rows per batch is a 28 MB fill kernel plus a launch in front of every walk)
+DG_HD void fs_ph_clean(const FsParams &P, int f, int lane) {
+    const uint32_t n = P.n_segs * FS_CALLS;
+    uint2 *row = P.lite + (size_t)f * n;
+    for (uint32_t i = (uint32_t)lane; i < n; i += FS_LANES) row[i] = uint2{0u, 0u};
+    P.slice_cnt[(size_t)f * FS_LANES + lane] = 0u;
 }
 // phase 10 (lane 0): the frame header the column walk reads; a frame that was given up carries nothing and is flagged for the host
 DG_HD void fs_ph_header(const FsParams &P, FsShared &S, int f) {

@@ -24,7 +24,6 @@ __global__ __launch_bounds__(64) void dg_fs_segs(FsParams P) {
 // read shared memory only and meet nothing but the few candidates that survived the parallel tests.
 __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
     __shared__ FsShared S;
-    __shared__ uint32_t bin_cnt[2][256];                 // W <= 16384: at most 256 column bins
     const int f = (int)blockIdx.x, lane = (int)threadIdx.x;
 #ifdef DG_FS_TIMING
     unsigned long long tm[12], tp = wall_clock64(); int tk = 0;
@@ -76,13 +75,18 @@ __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
     FS_T()
     fs_ph_seq(P, S, f, lane);
     FS_T()
-    fs_ph_bin_count(P, S, lane, bin_cnt[0], bin_cnt[1]);
+    fs_ph_bin_clear(P, S, lane);
     __syncthreads();
-    if (lane == 0) fs_ph_bin_prefix(P, S, f, bin_cnt[0], bin_cnt[1]);
+    fs_ph_bin_mark(P, S, lane);
     __syncthreads();
-    fs_ph_bin_fill(P, S, f, lane, bin_cnt[0], bin_cnt[1]);
+    fs_ph_bin_count(P, S, lane);
+    __syncthreads();
+    if (lane == 0) fs_ph_bin_prefix(P, S, f);
+    __syncthreads();
+    fs_ph_bin_fill(P, S, f, lane);
     __syncthreads();
     FS_T()
+    fs_ph_clean(P, f, lane);
     if (lane == 0) fs_ph_header(P, S, f);
 #ifdef DG_FS_TIMING
     FS_T()

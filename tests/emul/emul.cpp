@@ -584,7 +584,6 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     for (uint32_t s = 0; s < P.n_segs; s++) if (P.seg_leaf[s] != 0xffffu) fs_seg_lane(P, 0, s);             // dg_fs_segs
     static thread_local FsShared S;                                                                        // dg_fs_frame
     static thread_local FsSpriteTmp T[FS_LANES];
-    uint32_t bin_cnt[2][256];
 #define LANES(body) for (int lane = 0; lane < FS_LANES; lane++) { body; }
     fs_ph_init(S);
     LANES(fs_ph_cand_count(P, S, 0, lane))
@@ -607,11 +606,16 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     LANES(fs_ph_sprite_order(S, lane))
     LANES(fs_ph_masked_when(S, lane))
     LANES(fs_ph_seq(P, S, 0, lane))
-    LANES(fs_ph_bin_count(P, S, lane, bin_cnt[0], bin_cnt[1]))
-    fs_ph_bin_prefix(P, S, 0, bin_cnt[0], bin_cnt[1]);
-    LANES(fs_ph_bin_fill(P, S, 0, lane, bin_cnt[0], bin_cnt[1]))
+    LANES(fs_ph_bin_clear(P, S, lane))
+    LANES(fs_ph_bin_mark(P, S, lane))
+    LANES(fs_ph_bin_count(P, S, lane))
+    fs_ph_bin_prefix(P, S, 0);
+    LANES(fs_ph_bin_fill(P, S, 0, lane))
+    LANES(fs_ph_clean(P, 0, lane))
     fs_ph_header(P, S, 0);
 #undef LANES
+    for (const uint2 &q : lite) if (q.x | q.y) { g_err = "dg_fs_frame left a candidate row dirty"; return -3; }
+    for (uint32_t v : slice_cnt) if (v) { g_err = "dg_fs_frame left a slice counter dirty"; return -3; }
     const FeFrame &ff = ffr[0];
     if (stats) { stats[0] = ff.n_parts; stats[1] = ff.n_sprites; stats[2] = ff.n_sky_slots; stats[3] = flags[0]; stats[4] = 0; stats[5] = S.n_cl; }
     if (host_rc) {                                    // the host walker refuses the frame: the device walk must have given it up too
