@@ -1059,7 +1059,13 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     c->fs_scene_ok = false;
     if (c->fs_enabled && c->fe_scene_ok && sc.fs_ok && c->cfg.width <= FS_MAX_W) {
         const int rc = upload_fs_scene(c, sc);
-        if (rc) return rc;
+        if (rc && c->fs_forced) return rc;                 // (DG_FE_AUTO simply keeps the host walker when the seg walk's memory cannot be had)
+        if (rc) {
+            if (c->d_fs_scene) { (void)hipFree(c->d_fs_scene); c->d_fs_scene = nullptr; }
+            if (c->d_fs_scratch) { (void)hipFree(c->d_fs_scratch); c->d_fs_scratch = nullptr; }
+            c->fs_scene_ok = false;
+            (void)hipGetLastError();
+        }
     }
     return DG_OK;
 }

@@ -720,3 +720,33 @@ def test_the_eight_rank_paths_of_config_4_on_one_gpu(dg, synth, campath_mod, ora
     for scene, osc, _ in scenes.values():
         scene.close()
         osc.close()
+
+
+def test_auto_front_end_picks_per_batch(dg, scene1993, oracle_scene1993, path1993):
+    """DG_FE_AUTO: the GPU takes the per-seg half when nothing is in flight (the host's time would be exposed) and when the host is the
+    slower side — here one host thread at 320x200, where the host walker needs ~4 ms per 256 frames against ~0.15 ms of kernels — and
+    never for batches of fewer than 64 views; whatever it picks, the frames are the oracle's."""
+    W, H, B = 320, 200, 256
+    ctx = dg.Context(W, H, max_batch=B, slots=2, host_threads=1, front_end=dg.DG_FE_AUTO)
+    ctx.upload_scene(scene1993)
+    used = []
+    for it in range(8):
+        s = it % 2
+        b0 = (it * B) % 768
+        ctx.submit(s, dg.make_views(path1993[b0:b0 + B]))
+        if it >= 1:                                              # look at the batch before (it has had time to finish), keep this one in flight
+            p = (it - 1) % 2
+            ctx.wait(p)
+            used.append(ctx.timing(p)["front_end"])
+            got = ctx.readback(p, 0, B)
+            pb0 = ((it - 1) * B) % 768
+            for k in range(0, B, 37):
+                assert np.array_equal(got[k], np.frombuffer(oracle_scene1993.render(W, H, path1993[pb0 + k]), dtype=np.uint8).reshape(H, W, 3)), (it, k)
+    ctx.wait(1)
+    assert used[0] == dg.DG_FE_DEVICE_SEGS, used              # the first batch found nothing in flight
+    assert used.count(dg.DG_FE_DEVICE_SEGS) >= 5, used         # ... and the slow host loses the later ones too
+    ctx.wait(0)
+    small = ctx.render(dg.make_views(path1993[100:132]))         # 32 views: always the host walker
+    assert ctx.timing(0)["front_end"] == dg.DG_FE_DEVICE
+    assert np.array_equal(small[7], np.frombuffer(oracle_scene1993.render(W, H, path1993[107]), dtype=np.uint8).reshape(H, W, 3))
+    ctx.close()
