@@ -59,14 +59,35 @@ struct FeColumn {                 // what one lane carries through the walk
     int32_t x;
     int32_t hor, fo, co;          // horizontal_ocl / floor_ver_ocl / ceiling_ver_ocl of this column (segs.rs:70-74)
     uint32_t nsp, nrec, ovf;
-    size_t sp_at, rec_at;         // element index of the column's next free slot in cspans / recs (advances by W per slot)
+    size_t sp_at;                 // element index of the column's next free slot in cspans (advances by W per slot)
 };
 
 DG_HD FeColumn fe_column_start(const FeParams &P, int f, int32_t x) {         // Segs::new, segs.rs:97-99
     FeColumn c;
     c.x = x; c.hor = 0; c.fo = P.k.H; c.co = -1; c.nsp = 0; c.nrec = 0; c.ovf = 0;
-    c.sp_at = c.rec_at = (size_t)f * P.col_slots * (size_t)P.k.W + (size_t)x;
+    c.sp_at = (size_t)f * P.col_slots * (size_t)P.k.W + (size_t)x;
     return c;
+}
+
+// Where a column's wall records live between the walk of the parts and the clipping of the sprites.  The first FE_NEAR_RECS of a
+// column sit next to the walker — on the GPU in the wavefront's LDS, [slot][lane] — because a sprite column reads ALL of them, and
+// a round trip to the global scratch per eight records and sprite was half the life of the longest waves of dg_fe_columns (the ones
+// its duration is made of: profiles/r04_column_walk.md); only records beyond that go to the global rows (slot = record number).
+constexpr uint32_t FE_NEAR_RECS = 9;
+struct FeRecStore {
+    uint32_t *near_cand;          // [FE_NEAR_RECS][64]  top_cand | bottom_cand << 16 of the bin's 64 columns
+    uint16_t *near_part;          // [FE_NEAR_RECS][64]
+};
+DG_HD void fe_put_rec(const FeParams &P, int f, FeColumn &c, const FeRecStore &st, const FeColRec &r) {
+    if (c.nrec >= P.col_slots) { c.ovf |= FE_OVF_RECS; return; }
+    if (c.nrec < FE_NEAR_RECS) {
+        const uint32_t at = c.nrec * (uint32_t)FE_BIN_W + ((uint32_t)c.x & (uint32_t)(FE_BIN_W - 1));
+        st.near_cand[at] = (uint32_t)(uint16_t)r.top_cand | ((uint32_t)(uint16_t)r.bottom_cand << 16);
+        st.near_part[at] = r.part;
+    } else {
+        P.recs[((size_t)f * P.col_slots + c.nrec) * (size_t)P.k.W + (size_t)c.x] = r;
+    }
+    c.nrec++;
 }
 
 DG_HD int32_t fe_min(int32_t a, int32_t b) { return a < b ? a : b; }
@@ -122,7 +143,7 @@ DG_HD void fe_occlude(const FeParams &P, FeColumn &c) {                        /
 }
 
 // Column c.x of part `pi` (sx <= x <= ex).  Returns FE_EV_* bits.
-DG_HD uint32_t fe_part_column(const FeParams &P, int f, const FePart &p, uint32_t pi, FeColumn &c) {
+DG_HD uint32_t fe_part_column(const FeParams &P, int f, const FePart &p, uint32_t pi, FeColumn &c, const FeRecStore &st) {
     const int32_t hm1 = P.k.H - 1, x = c.x;
     const uint32_t fl = p.flags;
     const bool two = (fl & FEP_TWO_SIDED_MID) != 0, only = (fl & FEP_ONLY_OCCL) != 0, lower = (fl & FEP_LOWER) != 0, upper = (fl & FEP_UPPER) != 0;
@@ -140,21 +161,16 @@ DG_HD uint32_t fe_part_column(const FeParams &P, int f, const FePart &p, uint32_
         if (vis) {
             const bool ext_b = lower || (!two && full), ext_t = upper || (!two && full);
             if (two || ext_b || ext_t) {                                       // the records draw_map_objects clips against
-                if (c.nrec >= P.col_slots) c.ovf |= FE_OVF_RECS;
-                else {
-                    FeColRec r;
-                    r.part = (uint16_t)pi; r.pad = 0;
-                    if (two) {                                                 // ST_TWOSIDED branch, map_objects.rs:152-163
-                        r.top_cand = (int16_t)(drawc ? top_y : -32768);
-                        r.bottom_cand = (int16_t)bottom_y;
-                    } else {                                                   // solid: map_objects.rs:141-151
-                        r.top_cand = (int16_t)(ext_t ? cb : -32768);
-                        r.bottom_cand = (int16_t)(ext_b ? ct : 32767);
-                    }
-                    P.recs[c.rec_at] = r;
-                    c.rec_at += (size_t)P.k.W;
-                    c.nrec++;
+                FeColRec r;
+                r.part = (uint16_t)pi; r.pad = 0;
+                if (two) {                                                     // ST_TWOSIDED branch, map_objects.rs:152-163
+                    r.top_cand = (int16_t)(drawc ? top_y : -32768);
+                    r.bottom_cand = (int16_t)bottom_y;
+                } else {                                                       // solid: map_objects.rs:141-151
+                    r.top_cand = (int16_t)(ext_t ? cb : -32768);
+                    r.bottom_cand = (int16_t)(ext_b ? ct : 32767);
                 }
+                fe_put_rec(P, f, c, st, r);
             }
             if ((fl & FEP_HAS_BITMAP) && (two || !only)) {                     // inline draw (segs.rs:231-258) or masked replay (segs.rs:593-597)
                 const uint32_t key = two ? (FE_KEY_LATE | (p.seq << 2)) : (FE_KEY_WALL | (pi << 2));
@@ -200,19 +216,34 @@ DG_HD uint32_t fe_part_column(const FeParams &P, int f, const FePart &p, uint32_
 }
 
 // Column c.x of one sprite (x0 <= x < x1): clip arrays from the wall records of this column that are not behind the
-// sprite's centre, then the clipped column (map_objects.rs:130-209).
-DG_HD void fe_sprite_column(const FeParams &P, int f, const FeFrame &ff, const FeSprite &s, uint32_t si, FeColumn &c) {
+// sprite's centre, then the clipped column (map_objects.rs:130-209).  `row(w)` = word w of the sprite's behind-bit row (the GPU
+// stages the rows of the sprites it is about to walk next to their records).
+template <typename Row>
+DG_HD void fe_sprite_column(const FeParams &P, int f, const FeFrame &ff, const FeSprite &s, uint32_t si, FeColumn &c, const FeRecStore &st, Row row) {
     const int32_t H = P.k.H, x = c.x;
     int32_t top_clip = -1, bottom_clip = H;
-    const uint32_t *row = P.behind + ff.behind_base + s.behind_off;
+    const uint32_t n_near = c.nrec < FE_NEAR_RECS ? c.nrec : FE_NEAR_RECS, lane = (uint32_t)x & (uint32_t)(FE_BIN_W - 1);
+    // eight records (then their eight behind-bit words) are read before any is used: independent reads, two round trips per eight records
+    for (uint32_t i0 = 0; i0 < n_near; i0 += 8) {
+        uint32_t cand[8], part[8], w[8];
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t at = (i0 + k < n_near ? i0 + k : n_near - 1) * (uint32_t)FE_BIN_W + lane;
+            cand[k] = st.near_cand[at];
+            part[k] = st.near_part[at];
+        }
+        for (uint32_t k = 0; k < 8; k++) w[k] = row(part[k] >> 5);
+        for (uint32_t k = 0; k < 8; k++) {
+            if (i0 + k >= n_near || ((w[k] >> (part[k] & 31)) & 1u)) continue;
+            top_clip = fe_max(top_clip, (int32_t)(int16_t)(cand[k] & 0xffffu));
+            bottom_clip = fe_min(bottom_clip, (int32_t)(int16_t)(cand[k] >> 16));
+        }
+    }
     const size_t at0 = (size_t)f * P.col_slots * (size_t)P.k.W + (size_t)x, W = (size_t)P.k.W;
-    // eight records (then their eight behind-bit words) are loaded before any is used: independent loads, two round trips
-    // per eight records instead of two per record
-    for (uint32_t i0 = 0; i0 < c.nrec; i0 += 8) {
+    for (uint32_t i0 = FE_NEAR_RECS; i0 < c.nrec; i0 += 8) {                  // the far ones: global scratch rows
         FeColRec r[8];
         uint32_t w[8];
         for (uint32_t k = 0; k < 8; k++) r[k] = P.recs[at0 + (size_t)(i0 + k < c.nrec ? i0 + k : c.nrec - 1) * W];
-        for (uint32_t k = 0; k < 8; k++) w[k] = row[r[k].part >> 5];
+        for (uint32_t k = 0; k < 8; k++) w[k] = row(r[k].part >> 5);
         for (uint32_t k = 0; k < 8; k++) {
             if (i0 + k >= c.nrec || ((w[k] >> (r[k].part & 31)) & 1u)) continue;
             top_clip = fe_max(top_clip, r[k].top_cand);
@@ -226,6 +257,12 @@ DG_HD void fe_sprite_column(const FeParams &P, int f, const FeFrame &ff, const F
     if (ct > cb) return;
     fe_emit(P, f, c, FE_KEY_LATE | (s.seq << 2), ct, cb, top_y, bottom_y, ((uint32_t)SPAN_WALL << FES_KIND_SHIFT) | FES_SPRITE | si);
 }
+// The sprite's behind-bit row straight from the batch's array (the CPU emulation; on the GPU rows of more than FE_NEAR_BEHIND words).
+struct FeBehindGlobal {
+    const uint32_t *row;
+    DG_HD uint32_t operator()(uint32_t w) const { return row[w]; }
+};
+DG_HD FeBehindGlobal fe_behind_row(const FeParams &P, const FeFrame &ff, const FeSprite &s) { return FeBehindGlobal{P.behind + ff.behind_base + s.behind_off}; }
 
 // Is column x a zero-filled entry of a visplane of this part: no add and no flush at x, and the nearest event on
 // either side inside [sx, ex] is an add (the visplane was opened before x and extended after it).  `open` holds the

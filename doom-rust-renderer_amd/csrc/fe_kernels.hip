@@ -29,49 +29,94 @@ constexpr int FE_SCAN_THREADS = 256;       // small workgroups find a free CU sl
 constexpr int FE_SCATTER_GROUPS = 4;      // slot groups per screen column in dg_fe_scatter
 
 // A record is wave-uniform: it is staged as dwords across lanes (one coalesced load instead of a chain of scalar-cache
-// misses: a frame's records do not fit the 16 KB scalar cache) and every field is then broadcast with v_readlane.
+// misses: a frame's records do not fit the 16 KB scalar cache) and every field is then broadcast with v_readlane.  The column walk
+// reads only the first FE_HEAD_WORDS dwords of a FePart / FeSprite (what follows are the texture-mapping constants dg_fe_scatter
+// resolves spans with), so only those travel: sixteen lanes per record, four records per load instruction.
+constexpr uint32_t FE_HEAD_WORDS = 12;
+static_assert(offsetof(FePart, wall) == FE_HEAD_WORDS * 4 && offsetof(FeSprite, wall) == FE_HEAD_WORDS * 4, "head of a record");
+
 template <typename T>
-__device__ __forceinline__ T unpack_words(uint32_t v) {
-    constexpr int N = (int)(sizeof(T) / 4);
-    union { T t; uint32_t w[N]; } u;
+__device__ __forceinline__ T unpack_head(uint32_t v) {
+    union U { T t; uint32_t w[sizeof(T) / 4]; __device__ U() {} } u;
 #pragma unroll
-    for (int k = 0; k < N; k++) u.w[k] = (uint32_t)__builtin_amdgcn_readlane((int)v, k);
-    return u.t;
+    for (uint32_t k = 0; k < FE_HEAD_WORDS; k++) u.w[k] = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)k);
+    return u.t;       // (the tail is never read)
 }
 
-// Walks one column bin: `n` record indices (BSP / array order) at `list`, records at `recs`.  64 indices are read with
-// one load; then up to 16 records at a time travel HBM -> registers -> LDS with eight independent loads in flight (a
-// record is at most 32 dwords: lanes 0-31 fetch an even entry, lanes 32-63 the odd one), so the ~1 us load latency is
-// paid once per 16 records instead of once per record; fn(index, record) is then called for each, in order, with the
-// record broadcast from LDS into scalar registers, until it returns false (wave-uniform).
-template <typename T, typename Fn>
-__device__ __forceinline__ void walk_bin(const uint16_t *list, uint32_t n, const T *recs, uint32_t *lrec, int lane, Fn fn) {
-    constexpr uint32_t NW = (uint32_t)(sizeof(T) / 4);
-    static_assert(NW <= 32, "record larger than half a wave");
-    for (uint32_t g64 = 0; g64 < n; g64 += 64) {
-        const uint32_t m = min(64u, n - g64);
-        const int my = (uint32_t)lane < m ? (int)list[g64 + (uint32_t)lane] : 0;
-        for (uint32_t g = 0; g < m; g += 16) {
-            uint32_t v[8];
+// The heads of 4 * LOADS records, list positions g .. of the m indices held one per lane in `my`, into lrec[record * STRIDE + word]:
+// lane (r, j) = (lane >> 4, lane & 15) fetches word j of records g + r, g + 4 + r, ...; all loads are issued before any is used.
+template <typename T, uint32_t STRIDE, uint32_t LOADS>
+__device__ __forceinline__ void stage_heads(const T *recs, int my, uint32_t g, uint32_t m, uint32_t *lrec, int lane) {
+    const uint32_t j = (uint32_t)(lane & 15), r = (uint32_t)(lane >> 4);
+    uint32_t v[LOADS];
 #pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const uint32_t ja = (uint32_t)__builtin_amdgcn_readlane(my, (int)min(g + 2 * k, m - 1));
-                const uint32_t jb = (uint32_t)__builtin_amdgcn_readlane(my, (int)min(g + 2 * k + 1, m - 1));
-                v[k] = reinterpret_cast<const uint32_t *>(recs + (lane < 32 ? ja : jb))[(uint32_t)(lane & 31) < NW ? (lane & 31) : 0];
-            }
+    for (uint32_t k = 0; k < LOADS; k++) {
+        const uint32_t idx = (uint32_t)__shfl(my, (int)min(g + 4 * k + r, m - 1));
+        v[k] = reinterpret_cast<const uint32_t *>(recs + idx)[min(j, FE_HEAD_WORDS - 1)];
+    }
+    if (j < FE_HEAD_WORDS) {
 #pragma unroll
-            for (uint32_t k = 0; k < 8; k++) lrec[k * 64 + (uint32_t)lane] = v[k];
-            const uint32_t nh = min(16u, m - g);
-            for (uint32_t h = 0; h < nh; h++) {
-                const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane(my, (int)(g + h));
-                if (!fn(idx, unpack_words<T>(lrec[h * 32 + (uint32_t)(lane & 31)]))) return;
-            }
-        }
+        for (uint32_t k = 0; k < LOADS; k++) lrec[(4 * k + r) * STRIDE + j] = v[k];
     }
 }
 
+#ifdef DG_EXP_FE_WAVETIME
+// per-wave record (life in core clocks, start / end in 100 MHz ticks), written with plain stores; dg_wt_report (one wave, after the
+// launch) prints the launch's span, when its last wave started, and the histogram of lives
+constexpr unsigned WT_CAP = 1u << 18;
+__device__ uint4 g_wt_rec[2][WT_CAP];
+__device__ __forceinline__ void wavetime_report(int which, unsigned long long t0, unsigned long long r0, unsigned widx, int f, int bin, unsigned a, unsigned b) {
+    if ((threadIdx.x & 63) != 0 || widx >= WT_CAP) return;
+    const unsigned long long dt = clock64() - t0, r1 = wall_clock64();
+    g_wt_rec[which][widx] = uint4{(unsigned)dt, (unsigned)r0, (unsigned)r1, a | b << 16};
+}
+__global__ void dg_wt_report(unsigned n0, unsigned n1) {
+    __shared__ unsigned hist[64];
+    for (int which = 0; which < 2; which++) {
+        const unsigned n = min(which ? n1 : n0, WT_CAP);
+        if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned t0 = ~0u, t1 = 0, s1 = 0, mx = 0; unsigned long long sum = 0;
+        if (threadIdx.x == 0) {
+            for (unsigned i = 0; i < n; i++) {
+                const uint4 r = g_wt_rec[which][i];
+                t0 = min(t0, r.y); s1 = max(s1, r.y); t1 = max(t1, r.z); sum += r.x; mx = max(mx, r.x);
+                hist[min(63u, r.x >> 11)]++;
+            }
+            printf("[wt%d] span %u ticks (10 ns), last wave started at +%u, waves %u, mean life %llu clk, longest %u clk, hist(2048-clk buckets):", which, t1 - t0, s1 - t0, n, sum / max(1u, n), mx);
+            for (int i = 0; i < 64; i++) printf(" %u", hist[i]);
+            printf("\n");
+            // the ten longest lives: when they started, what they had to do
+            for (int k = 0; k < 10; k++) {
+                unsigned best = 0, bi = 0;
+                for (unsigned i = 0; i < n; i++) if (g_wt_rec[which][i].x > best) { best = g_wt_rec[which][i].x; bi = i; }
+                const uint4 r = g_wt_rec[which][bi];
+                printf("[wt%d]   wave %u life %u clk started +%u ended +%u  a %u,%u b %u, parts phase %u clk\n", which, bi, r.x, r.y - t0, r.z - t0, r.w & 0xffu, (r.w >> 8) & 0xffu, (r.w >> 16) & 63u, (r.w >> 22) << 8);
+                g_wt_rec[which][bi].x = 0;
+            }
+        }
+        __syncthreads();
+    }
+}
+#endif
+
+constexpr uint32_t FE_NEAR_BEHIND = 8;     // a behind-bit row of at most this many words (256 parts) is staged in LDS with its sprite's record
+constexpr uint32_t FE_PART_ROUND = 32, FE_SPRITE_ROUND = 16;                  // records per staging round
+constexpr uint32_t FE_SPRITE_STRIDE = FE_HEAD_WORDS + FE_NEAR_BEHIND;         // a staged sprite: its head, then its behind-bit row
+
+struct ColumnsLds {                         // per wavefront: 4 992 bytes, so that eight workgroups share a CU
+    uint32_t rec[FE_PART_ROUND * FE_HEAD_WORDS];       // the staged heads (sprites: FE_SPRITE_ROUND x FE_SPRITE_STRIDE words)
+    uint32_t near_cand[FE_NEAR_RECS * 64];  // FeRecStore
+    uint16_t near_part[FE_NEAR_RECS * 64];
+};
+static_assert(FE_SPRITE_ROUND * FE_SPRITE_STRIDE <= FE_PART_ROUND * FE_HEAD_WORDS, "sprite round fits the staging area");
+static_assert(sizeof(ColumnsLds) * (FE_COL_THREADS / 64) * 8 <= 160 * 1024, "eight workgroups per CU");
+
 __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
-    __shared__ uint32_t lrec_all[(FE_COL_THREADS / 64) * 16 * 32];
+    __shared__ ColumnsLds lds_all[FE_COL_THREADS / 64];
+#ifdef DG_EXP_FE_WAVETIME
+    const unsigned long long wt_t0 = clock64(), wt_r0 = wall_clock64();
+#endif
     const int f = blockIdx.y;
     const int W = P.k.W;
     const int x = (int)(blockIdx.x * FE_COL_THREADS + threadIdx.x);
@@ -80,39 +125,96 @@ __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
     const int wx0 = __builtin_amdgcn_readfirstlane(x - lane);
     if (wx0 >= W) return;                                                               // whole wave past the right edge
     const uint32_t bin = (uint32_t)wx0 / FE_BIN_W;                                      // this wave's column bin
-    uint32_t *lrec = lrec_all + (threadIdx.x >> 6) * (16 * 32);                         // this wave's 16-record staging area
+    ColumnsLds &L = lds_all[threadIdx.x >> 6];
+    uint32_t *lrec = L.rec;                                                             // this wave's staging area
+    const FeRecStore st{L.near_cand, L.near_part};
     const FeFrame ff = P.fframes[f];
     const uint32_t *boff = P.bin_off + (size_t)f * (P.w64 + 1) + bin, *sboff = P.sbin_off + (size_t)f * (P.w64 + 1) + bin;
     const uint32_t b0 = __builtin_amdgcn_readfirstlane(boff[0]), b1 = __builtin_amdgcn_readfirstlane(boff[1]);
     const uint32_t s0 = __builtin_amdgcn_readfirstlane(sboff[0]), s1 = __builtin_amdgcn_readfirstlane(sboff[1]);
     const uint32_t part_base = __builtin_amdgcn_readfirstlane(ff.part_base), sprite_base = __builtin_amdgcn_readfirstlane(ff.sprite_base);
+    {
+        FeColumn c = fe_column_start(P, f, x);
 
-    FeColumn c = fe_column_start(P, f, x);
-
-    // parts in BSP order: the ones whose column range touches this wave's 64 columns (listed by the host)
-    walk_bin(P.bin_parts + ff.bin_base + b0, b1 - b0, P.parts + part_base, lrec, lane, [&](uint32_t pi, const FePart &p) {
-        uint32_t ev = 0;
-        const bool walked = active && x >= p.sx && x <= p.ex;
-        if (walked) ev = fe_part_column(P, f, p, pi, c);
-        if (p.sky_slot >= 0) {                                                          // wave-uniform: all 64 lanes reach the ballots
-            const uint64_t bf = __ballot((ev & FE_EV_FADD) != 0), bc = __ballot((ev & FE_EV_CADD) != 0), bl = __ballot(walked && !(ev & FE_EV_FLUSH));
-            if (lane == 0) {
-                fe_event_words(P, f, p.sky_slot, 0)[bin] = bf;
-                fe_event_words(P, f, p.sky_slot, 1)[bin] = bc;
-                fe_event_words(P, f, p.sky_slot, 2)[bin] = bl;
+        // parts in BSP order: the ones whose column range touches the bin (listed by the host / by dg_fs_frame); 64 list entries per
+        // load, 32 heads per staging round, then one part after the other with its head broadcast into scalar registers
+        {
+            const uint16_t *list = P.bin_parts + ff.bin_base + b0;
+            const FePart *recs = P.parts + part_base;
+            const uint32_t n = b1 - b0;
+            bool open = true;                                                           // some column of the walk is not horizontally occluded yet
+            for (uint32_t g64 = 0; open && g64 < n; g64 += 64) {
+                const uint32_t m = min(64u, n - g64);
+                const int my = (uint32_t)lane < m ? (int)list[g64 + (uint32_t)lane] : 0;
+                for (uint32_t g = 0; open && g < m; g += FE_PART_ROUND) {
+                    stage_heads<FePart, FE_HEAD_WORDS, FE_PART_ROUND / 4>(recs, my, g, m, lrec, lane);
+                    const uint32_t nh = min(FE_PART_ROUND, m - g);
+                    for (uint32_t h = 0; open && h < nh; h++) {
+                        const uint32_t pi = (uint32_t)__builtin_amdgcn_readlane(my, (int)(g + h));
+                        const FePart p = unpack_head<FePart>(lrec[h * FE_HEAD_WORDS + min((uint32_t)(lane & 15), FE_HEAD_WORDS - 1)]);
+                        uint32_t ev = 0;
+                        const bool walked = active && x >= p.sx && x <= p.ex;
+                        if (walked) ev = fe_part_column(P, f, p, pi, c, st);
+                        if (p.sky_slot >= 0) {                                          // wave-uniform: all 64 lanes reach the ballots
+                            const uint64_t bf = __ballot((ev & FE_EV_FADD) != 0), bc = __ballot((ev & FE_EV_CADD) != 0), bl = __ballot(walked && !(ev & FE_EV_FLUSH));
+                            if (lane == 0) {
+                                uint64_t *wf = fe_event_words(P, f, p.sky_slot, 0) + bin, *wc = fe_event_words(P, f, p.sky_slot, 1) + bin, *wl = fe_event_words(P, f, p.sky_slot, 2) + bin;
+                                *wf = bf; *wc = bc; *wl = bl;
+                            }
+                        }
+                        // Once every column of the walk is horizontally occluded nothing behind can draw, clip or add a visplane entry
+                        // (segs.rs:211,337-341): the rest of the bin only yields flush events, which is what the event words are preset to.
+                        open = __ballot(active && !c.hor) != 0;
+                    }
+                }
             }
         }
-        // Once every column of the wave is horizontally occluded nothing behind can draw, clip or add a visplane entry
-        // (segs.rs:211,337-341): the rest of the bin only yields flush events, which is what the event words are preset to.
-        return __ballot(active && !c.hor) != 0;
-    });
-    // then the sprites (their clip arrays need the finished wall-record columns of this screen column)
-    walk_bin(P.sbin_sprites + ff.sbin_base + s0, s1 - s0, P.sprites + sprite_base, lrec, lane, [&](uint32_t si, const FeSprite &s) {
-        if (active && x >= s.x0 && x < s.x1) fe_sprite_column(P, f, ff, s, si, c);
-        return true;
-    });
-    if (active) P.cnt[(size_t)f * (size_t)W + (size_t)x] = c.nsp;
-    if (c.ovf) atomicOr(&P.flags[f], c.ovf);
+        // then the sprites (their clip arrays need the finished wall-record columns of this screen column).  The behind-bit rows of the
+        // staged sprites travel with their heads (row of sprite i = words [i * behind_words, ..) of the frame's array, fe_dev.h), so that
+        // clipping a sprite column is LDS reads only.
+        {
+            const uint16_t *list = P.sbin_sprites + ff.sbin_base + s0;
+            const FeSprite *recs = P.sprites + sprite_base;
+            const uint32_t n = s1 - s0, bw = __builtin_amdgcn_readfirstlane(ff.behind_words);
+            const bool near_rows = bw <= FE_NEAR_BEHIND;
+            for (uint32_t g64 = 0; g64 < n; g64 += 64) {
+                const uint32_t m = min(64u, n - g64);
+                const int my = (uint32_t)lane < m ? (int)list[g64 + (uint32_t)lane] : 0;
+                for (uint32_t g = 0; g < m; g += FE_SPRITE_ROUND) {
+                    uint32_t r0 = 0, r1 = 0;                                            // lane (h, j) = (lane >> 2, lane & 3): words 2j, 2j + 1 of sprite h's row
+                    if (near_rows) {
+                        const uint32_t sidx = (uint32_t)__shfl(my, (int)min(g + (uint32_t)(lane >> 2), m - 1));
+                        const uint32_t *brow = P.behind + ff.behind_base + (size_t)sidx * bw;
+                        const uint32_t w = 2u * (uint32_t)(lane & 3);
+                        if (w < bw) r0 = brow[w];
+                        if (w + 1 < bw) r1 = brow[w + 1];
+                    }
+                    stage_heads<FeSprite, FE_SPRITE_STRIDE, FE_SPRITE_ROUND / 4>(recs, my, g, m, lrec, lane);
+                    if (near_rows) {
+                        uint32_t *to = lrec + (uint32_t)(lane >> 2) * FE_SPRITE_STRIDE + FE_HEAD_WORDS + 2u * (uint32_t)(lane & 3);
+                        to[0] = r0; to[1] = r1;
+                    }
+                    const uint32_t nh = min(FE_SPRITE_ROUND, m - g);
+                    for (uint32_t h = 0; h < nh; h++) {
+                        const uint32_t si = (uint32_t)__builtin_amdgcn_readlane(my, (int)(g + h));
+                        const FeSprite s = unpack_head<FeSprite>(lrec[h * FE_SPRITE_STRIDE + min((uint32_t)(lane & 15), FE_HEAD_WORDS - 1)]);
+                        if (!(active && x >= s.x0 && x < s.x1)) continue;
+                        if (near_rows) {
+                            const uint32_t *brow = lrec + h * FE_SPRITE_STRIDE + FE_HEAD_WORDS;
+                            fe_sprite_column(P, f, ff, s, si, c, st, [brow](uint32_t w) { return brow[w]; });
+                        } else {
+                            fe_sprite_column(P, f, ff, s, si, c, st, fe_behind_row(P, ff, s));
+                        }
+                    }
+                }
+            }
+        }
+        if (active) P.cnt[(size_t)f * (size_t)W + (size_t)x] = c.nsp;
+        if (active && c.ovf) atomicOr(&P.flags[f], c.ovf);
+    }
+#ifdef DG_EXP_FE_WAVETIME
+    wavetime_report(0, wt_t0, wt_r0, (unsigned)f * (unsigned)((W + 63) / 64) + bin, f, (int)bin, (b1 - b0) | (s1 - s0) << 8, 0);
+#endif
 }
 
 // One wave per (frame, sky part): the zero-filled entries of sky visplanes draw one sky pixel at row 0
@@ -204,6 +306,9 @@ __global__ __launch_bounds__(64 * FE_SCATTER_GROUPS) void dg_fe_scatter(FeParams
                                               // launch (12 KB at the default 48 slots), so that LDS does not cap the resident workgroups
     FeU4 *lout = reinterpret_cast<FeU4 *>(lds_dyn);
     uint32_t *lkeys = lds_dyn + FE_SCATTER_STAGE * 8;
+#ifdef DG_EXP_FE_WAVETIME
+    const unsigned long long wt_t0 = clock64(), wt_r0 = wall_clock64();
+#endif
     const int f = blockIdx.y;
     const int W = P.k.W;
     const int lx = (int)(threadIdx.x & 63);
@@ -232,9 +337,16 @@ __global__ __launch_bounds__(64 * FE_SCATTER_GROUPS) void dg_fe_scatter(FeParams
         to[0] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
         to[1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};
     }
+#ifdef DG_EXP_FE_WAVETIME
+    if (!staged) { wavetime_report(1, wt_t0, wt_r0, ((unsigned)f * gridDim.x + blockIdx.x) * FE_SCATTER_GROUPS + g, f, (int)blockIdx.x, t_last - t_first, g); return; }
+#else
     if (!staged) return;
+#endif
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 2 * (t_last - t_first); i += 64 * FE_SCATTER_GROUPS) out[2 * (size_t)t_first + i] = lout[i];
+#ifdef DG_EXP_FE_WAVETIME
+    wavetime_report(1, wt_t0, wt_r0, ((unsigned)f * gridDim.x + blockIdx.x) * FE_SCATTER_GROUPS + g, f, (int)blockIdx.x, t_last - t_first, g);
+#endif
 }
 
 }  // namespace
@@ -252,6 +364,9 @@ hipError_t launch_fe(const FeParams &P, hipStream_t stream, hipEvent_t start, hi
     hipLaunchKernelGGL(dg_fe_scan, dim3((unsigned)P.n_frames), dim3(FE_SCAN_THREADS), 0, stream, P);
     hipExtLaunchKernelGGL(dg_fe_scatter, dim3((unsigned)((P.k.W + 63) / 64), (unsigned)P.n_frames), dim3(64 * FE_SCATTER_GROUPS),
                           (uint32_t)((size_t)FE_SCATTER_STAGE * 32 + (size_t)P.col_slots * 64 * 4), stream, nullptr, stop, 0, P);
+#ifdef DG_EXP_FE_WAVETIME
+    hipLaunchKernelGGL(dg_wt_report, dim3(1), dim3(64), 0, stream, (unsigned)((P.k.W + 63) / 64) * (unsigned)P.n_frames, (unsigned)((P.k.W + 63) / 64) * (unsigned)P.n_frames * FE_SCATTER_GROUPS);
+#endif
     return hipGetLastError();
 }
 

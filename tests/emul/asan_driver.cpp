@@ -57,6 +57,9 @@ static int walk_parts_on_host(const Scene &sc, int W, int H, const dg_view &v, F
     P.cspans = cspans.data(); P.recs = recs.data(); P.cnt = cnt.data(); P.events = events.data(); P.flags = flags.data();
     P.n_frames = 1; P.max_sky_slots = A.n_sky_slots; P.w64 = w64; P.col_slots = slots;
     if (A.bin_off.size() != (size_t)w64 + 1 || A.sbin_off.size() != (size_t)w64 + 1) return -100;
+    std::vector<uint32_t> near_cand((size_t)FE_NEAR_RECS * FE_BIN_W);
+    std::vector<uint16_t> near_part((size_t)FE_NEAR_RECS * FE_BIN_W);
+    const FeRecStore st{near_cand.data(), near_part.data()};
     for (int x = 0; x < W; x++) {
         FeColumn c = fe_column_start(P, 0, x);
         const uint32_t bin = (uint32_t)x / FE_BIN_W;
@@ -64,14 +67,14 @@ static int walk_parts_on_host(const Scene &sc, int W, int H, const dg_view &v, F
             const uint32_t pi = A.bin_parts.at(bi);
             const FePart &p = A.parts.at(pi);
             if (x < p.sx || x > p.ex) continue;
-            const uint32_t ev = fe_part_column(P, 0, p, pi, c);
+            const uint32_t ev = fe_part_column(P, 0, p, pi, c, st);
             if (p.sky_slot >= 0 && (ev & FE_EV_FADD)) fe_event_words(P, 0, p.sky_slot, 0)[x >> 6] |= 1ull << (x & 63);
             if (c.hor) break;
         }
         for (uint32_t bi = A.sbin_off[bin]; bi < A.sbin_off[bin + 1]; bi++) {
             const uint32_t si = A.sbin_sprites.at(bi);
             const FeSprite &sp = A.sprites.at(si);
-            if (x >= sp.x0 && x < sp.x1) fe_sprite_column(P, 0, ff, sp, si, c);
+            if (x >= sp.x0 && x < sp.x1) fe_sprite_column(P, 0, ff, sp, si, c, st, fe_behind_row(P, ff, sp));
         }
         for (uint32_t i = 0; i < c.nsp; i++) (void)fe_resolve(P, fr, ff, x, cspans[(size_t)i * W + (size_t)x]);
     }

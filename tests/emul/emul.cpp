@@ -240,7 +240,10 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
     P.events = events.data(); P.flags = flags.data(); P.totals = nullptr; P.col_off = col_off.data(); P.rspans = rspans.data();
     P.n_frames = 1; P.max_sky_slots = arena.n_sky_slots; P.gap_waves = 0; P.span_stride = (uint32_t)rspans.size(); P.w64 = w64; P.col_slots = FE_DEFAULT_COL_SLOTS;
 
-    // dg_fe_columns, one "lane" at a time
+    // dg_fe_columns, one "lane" at a time (each bin's near records in their own little arrays, like a wave's LDS)
+    std::vector<uint32_t> near_cand((size_t)FE_NEAR_RECS * FE_BIN_W);
+    std::vector<uint16_t> near_part((size_t)FE_NEAR_RECS * FE_BIN_W);
+    const FeRecStore st{near_cand.data(), near_part.data()};
     for (int x = 0; x < W; x++) {
         FeColumn c = fe_column_start(P, 0, x);
         const uint32_t bin = (uint32_t)x / FE_BIN_W;                       // the wave that owns this column walks its bin's lists
@@ -248,7 +251,7 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
             const uint32_t pi = arena.bin_parts[bi];
             const FePart &p = P.parts[pi];
             if (x < p.sx || x > p.ex) continue;
-            uint32_t ev = fe_part_column(P, 0, p, pi, c);
+            uint32_t ev = fe_part_column(P, 0, p, pi, c, st);
             if (p.sky_slot >= 0) {
                 const uint64_t bit = 1ull << (x & 63);
                 for (int kind = 0; kind < 3; kind++) {                 // kind 2 stores "walked and not flushed"
@@ -262,7 +265,8 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
         for (uint32_t bi = arena.sbin_off[bin]; bi < arena.sbin_off[bin + 1]; bi++) {
             const uint32_t si = arena.sbin_sprites[bi];
             const FeSprite &s = P.sprites[si];
-            if (x >= s.x0 && x < s.x1) fe_sprite_column(P, 0, ff, s, si, c);
+            if (s.behind_off != si * ff.behind_words) { g_err = "behind row of sprite i is not row i"; return DG_ERR_INVALID; }   // dg_fe_columns stages rows by index
+            if (x >= s.x0 && x < s.x1) fe_sprite_column(P, 0, ff, s, si, c, st, fe_behind_row(P, ff, s));
         }
         cnt[(size_t)x] = c.nsp;
         flags[0] |= c.ovf;
