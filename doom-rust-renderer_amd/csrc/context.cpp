@@ -133,6 +133,7 @@ struct Slot {
     uint32_t *h_status = nullptr;               // pinned host memory the walk's kernels write: [F] overflow flags, [F] spans per frame
     uint64_t *d_events = nullptr;               // sky event bits (fe_event_words), zeroed before every walk
     size_t flags_bytes = 0;
+    uint32_t *d_order = nullptr;                // dg_fe_columns' launch-order lists as dg_fs_frame builds them (FsParams::order_list)
     uint32_t *d_flags = nullptr;                // [F] overflow flags the walk's kernels OR into; sits in front of d_events (one memset clears both)
     FeParams FP{};
     FsParams FSP{};               // DG_FE_DEVICE_SEGS: the device seg walk in front of the column walk
@@ -254,6 +255,7 @@ void free_ctx(dg_ctx *c) {
         if (s.h_fe) (void)hipHostFree(s.h_fe);
         if (s.d_fe) (void)hipFree(s.d_fe);
         if (s.d_fe_coloff) (void)hipFree(s.d_fe_coloff);
+        if (s.d_order) (void)hipFree(s.d_order);
         if (s.d_flags) (void)hipFree(s.d_flags);    // (d_events lies inside this allocation)
         if (s.h_status) (void)hipHostFree(s.h_status);
         if (s.ev_start) (void)hipEventDestroy(s.ev_start);
@@ -405,8 +407,27 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_vie
     const size_t off_sboff = align_up(off_boff + (size_t)n * nb1 * 4, 256);
     const size_t off_bins = align_up(off_sboff + (size_t)n * nb1 * 4, 256);
     const size_t off_sbins = align_up(off_bins + bins * 2, 256);
-    const size_t total = off_sbins + sbins * 2;
+    const size_t groups = (size_t)(W + 255) / 256;                  // dg_fe_columns: one workgroup per (frame, 256 columns)
+    const size_t off_order = align_up(off_sbins + sbins * 2, 256);
+    const size_t total = off_order + (size_t)n * groups * 4;
     if (total > c->fe_slab_cap) return kPartsUnsupported;
+    {   // launch order of dg_fe_columns: heaviest workgroup first (weight = its longest bin: parts + 2 x sprites), counting sort
+        std::vector<uint32_t> weight((size_t)n * groups), start(258, 0);
+        for (int i = 0; i < n; i++) {
+            const FeFrameOut &o = c->fe_out[(size_t)i];
+            for (size_t g = 0; g < groups; g++) {
+                uint32_t w = 0;
+                for (size_t b = 4 * g; b < std::min(4 * g + 4, nb1 - 1); b++)
+                    w = std::max(w, (o.bin_off[b + 1] - o.bin_off[b]) + 2u * (o.sbin_off[b + 1] - o.sbin_off[b]));
+                w = 255u - std::min(w, 255u);                        // heaviest = smallest key
+                weight[(size_t)i * groups + g] = w;
+                start[w + 1]++;
+            }
+        }
+        for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
+        uint32_t *order = reinterpret_cast<uint32_t *>(s.h_fe + off_order);
+        for (size_t it = 0; it < weight.size(); it++) order[start[weight[it]]++] = (uint32_t)it;
+    }
     c->pool->parallel_for(n, [&](int i, int) {
         FeFrameOut &o = c->fe_out[(size_t)i];
         const FeFrame &ff = ffs[(size_t)i];
@@ -436,6 +457,7 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_vie
     F.sbin_off = reinterpret_cast<const uint32_t *>(s.d_fe + off_sboff);
     F.bin_parts = reinterpret_cast<const uint16_t *>(s.d_fe + off_bins);
     F.sbin_sprites = reinterpret_cast<const uint16_t *>(s.d_fe + off_sbins);
+    F.order = reinterpret_cast<const uint32_t *>(s.d_fe + off_order); F.order_cnt = nullptr;
     F.cspans = c->d_fe_cspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt;
     F.events = s.d_events;
     F.flags = s.d_flags;
@@ -616,6 +638,10 @@ int build_batch_fs(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     F.fframes = Q.fframes; F.parts = Q.parts; F.sprites = Q.sprites; F.behind = Q.behind; F.sky_parts = Q.sky_parts;
     F.max_sky_slots = FS_SKY_CAP; F.gap_waves = 12;
     F.bin_off = Q.bin_off; F.sbin_off = Q.sbin_off; F.bin_parts = Q.bin_parts; F.sbin_sprites = Q.sbin_sprites;
+    Q.order_cnt = s.d_flags + c->cfg.max_batch;            // zeroed with the flags (enqueue_kernels)
+    Q.order_list = s.d_order;
+    Q.n_items = (uint32_t)n * (uint32_t)((W + 255) / 256);
+    F.order = s.d_order; F.order_cnt = Q.order_cnt;
     F.cspans = c->d_fe_cspans; F.recs = c->d_fe_recs; F.cnt = c->d_fe_cnt;
     F.events = s.d_events;
     F.flags = s.d_flags;
@@ -963,7 +989,8 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         c->fe_sbin_cap = F * 2048;
         c->fe_slab_cap = align_up(F * sizeof(DevFrame), 256) + align_up(F * sizeof(FeFrame), 256) + align_up(c->fe_part_cap * sizeof(FePart), 256) +
                          align_up(c->fe_sprite_cap * sizeof(FeSprite), 256) + align_up(c->fe_behind_cap * 4, 256) + align_up(F * FE_MAX_SKY_SLOTS * 4, 256) +
-                         2 * align_up(F * ((W + FE_BIN_W - 1) / FE_BIN_W + 1) * 4, 256) + align_up(c->fe_bin_cap * 2, 256) + c->fe_sbin_cap * 2 + 1024;
+                         2 * align_up(F * ((W + FE_BIN_W - 1) / FE_BIN_W + 1) * 4, 256) + align_up(c->fe_bin_cap * 2, 256) + align_up(c->fe_sbin_cap * 2, 256) +
+                         F * ((W + 255) / 256) * 4 + 1024;
     }
     c->slots.resize((size_t)cfg->slots);
     hipError_t e;
@@ -995,7 +1022,8 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
             CTX_TRY(hipHostMalloc((void **)&s.h_fe, c->fe_slab_cap, hipHostMallocDefault));
             CTX_TRY(hipMalloc((void **)&s.d_fe, c->fe_slab_cap));
             CTX_TRY(hipMalloc((void **)&s.d_fe_coloff, F * (W + 1) * 4));
-            s.flags_bytes = align_up(F * 4, 256);
+            s.flags_bytes = align_up(F * 4 + FS_ORDER_CLASSES * 4, 256);       // the flag words, then the seg walk's launch-order counters
+            CTX_TRY(hipMalloc((void **)&s.d_order, FS_ORDER_CLASSES * F * ((W + 255) / 256) * 4));
             CTX_TRY(hipMalloc((void **)&s.d_flags, s.flags_bytes + F * FE_MAX_SKY_SLOTS * 3 * ((W + 63) / 64) * 8));
             s.d_events = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(s.d_flags) + s.flags_bytes);
             CTX_TRY(hipHostMalloc((void **)&s.h_status, 2 * F * 4, hipHostMallocDefault));

@@ -53,6 +53,12 @@ struct FeParams {
     uint32_t max_sky_slots;       // max n_sky_slots over the frames of the batch (grid of dg_fe_gaps; stride of the event rows)
     uint32_t gap_waves;           // 0: one wave of dg_fe_gaps per sky slot; else this many per frame, striding over its slots (the bound is loose)
     uint32_t col_slots;           // span slots and wall-record slots per screen column in the scratch arrays (<= FE_MAX_COL_SLOTS)
+    // launch order of dg_fe_columns: workgroup i takes item order[i] = frame * ceil(W / 256) + 256-column group, heaviest first (the kernel
+    // lasts as long as its longest bin, and a long bin that starts late ends late); nullptr = natural order.  order_cnt == nullptr: one
+    // list, sorted by the host.  Else (lists built by dg_fs_frame, fs_frame.h): FS_ORDER_CLASSES lists of order_cnt[k] entries each,
+    // list k at order + k * n_items, heaviest class first.
+    const uint32_t *order;
+    const uint32_t *order_cnt;
 };
 
 struct FeColumn {                 // what one lane carries through the walk

@@ -18,6 +18,7 @@
 #include <hip/hip_ext.h>
 
 #include "fe_core.h"
+#include "fs_frame.h"
 #include "fe_kernels.hpp"
 
 namespace dg {
@@ -117,9 +118,20 @@ __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
 #ifdef DG_EXP_FE_WAVETIME
     const unsigned long long wt_t0 = clock64(), wt_r0 = wall_clock64();
 #endif
-    const int f = blockIdx.y;
     const int W = P.k.W;
-    const int x = (int)(blockIdx.x * FE_COL_THREADS + threadIdx.x);
+    const uint32_t groups = (uint32_t)(W + FE_COL_THREADS - 1) / FE_COL_THREADS;
+    uint32_t item = blockIdx.x;                                                         // (frame, 256-column group): fe_core.h
+    if (P.order) {
+        uint32_t at = blockIdx.x;
+        if (P.order_cnt) {                                                              // class lists: skip the classes in front of this workgroup
+            uint32_t k = 0, i = blockIdx.x;
+            for (; k + 1 < FS_ORDER_CLASSES && i >= P.order_cnt[k]; k++) i -= P.order_cnt[k];
+            at = k * gridDim.x + i;
+        }
+        item = P.order[at];
+    }
+    const int f = (int)(item / groups);
+    const int x = (int)((item % groups) * FE_COL_THREADS + threadIdx.x);
     const bool active = x < W;
     const int lane = (int)(threadIdx.x & 63);
     const int wx0 = __builtin_amdgcn_readfirstlane(x - lane);
@@ -358,7 +370,7 @@ hipError_t launch_fe(const FeParams &P, hipStream_t stream, hipEvent_t start, hi
         if (e == hipSuccess && stop) e = hipEventRecord(stop, stream);
         return e;
     }
-    dim3 grid((unsigned)((P.k.W + FE_COL_THREADS - 1) / FE_COL_THREADS), (unsigned)P.n_frames);
+    dim3 grid((unsigned)((P.k.W + FE_COL_THREADS - 1) / FE_COL_THREADS) * (unsigned)P.n_frames);
     hipExtLaunchKernelGGL(dg_fe_columns, grid, dim3(FE_COL_THREADS), 0, stream, start, nullptr, 0, P);
     if (P.max_sky_slots) hipLaunchKernelGGL(dg_fe_gaps, dim3(P.gap_waves ? std::min(P.gap_waves, P.max_sky_slots) : P.max_sky_slots, (unsigned)P.n_frames), dim3(64), 0, stream, P);
     hipLaunchKernelGGL(dg_fe_scan, dim3((unsigned)P.n_frames), dim3(FE_SCAN_THREADS), 0, stream, P);

@@ -70,7 +70,13 @@ struct FsParams {
     // outputs: the DG_FE_DEVICE record arrays with fixed per-frame strides
     FeFrame *fframes; FePart *parts; FeSprite *sprites; uint32_t *behind; uint32_t *sky_parts;
     uint32_t *bin_off; uint16_t *bin_parts; uint32_t *sbin_off; uint16_t *sbin_sprites;
+    // launch order of dg_fe_columns (fe_core.h FeParams::order), built here because only the GPU knows the bins: every (frame, 256-column
+    // group) is appended to the list of its weight class, heaviest class first; order_cnt zeroed per batch; nullptr: no lists wanted
+    uint32_t *order_cnt;                       // [FS_ORDER_CLASSES]
+    uint32_t *order_list;                      // [FS_ORDER_CLASSES][n_items]
+    uint32_t n_items;                          // n_frames x ceil(W / 256)
 };
+constexpr uint32_t FS_ORDER_CLASSES = 4;       // longest bin of the group (parts + 2 x sprites): > 32, > 16, > 8, the rest
 
 // ---- dg_fs_order: one (frame, leaf) --------------------------------------------------------------------------------------------------
 DG_HD void fs_leaf_order(const FsParams &P, int f, uint32_t leaf) {
@@ -166,6 +172,7 @@ struct FsShared {                              // LDS on the GPU
     uint16_t s_order[FS_SPRITE_CAP], s_x0b[FS_SPRITE_CAP], s_x1b[FS_SPRITE_CAP];   // place in the far-to-near order; first / last column bin (x0b > x1b: no columns)
     uint32_t n_sprites;
     uint32_t fail;
+    uint32_t bins_total, sbins_total;          // entries of the frame's two bin tables (fs_ph_bin_prefix)
 };
 
 // phase 0 (lane 0): reset
@@ -213,6 +220,15 @@ DG_HD void fs_or_u32(uint32_t *p, uint32_t v) {
     atomicOr(p, v);
 #else
     *p |= v;
+#endif
+}
+DG_HD uint32_t fs_add_u32(uint32_t *p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p, v);
+#else
+    const uint32_t old = *p;
+    *p = old + v;
+    return old;
 #endif
 }
 DG_HD void fs_min_u32(uint32_t *p, uint32_t v) {
@@ -434,6 +450,7 @@ DG_HD void fs_ph_bin_prefix(const FsParams &P, FsShared &S, int f) {      // lan
         rp += np; rs += ns;
     }
     bo[nb] = rp; so[nb] = rs;
+    S.bins_total = rp; S.sbins_total = rs;
     if (rp > FS_BIN_CAP || rs > FS_SBIN_CAP) S.fail = 1;
 }
 DG_HD void fs_ph_bin_fill(const FsParams &P, FsShared &S, int f, int lane) {
@@ -479,6 +496,23 @@ DG_HD void fs_ph_header(const FsParams &P, FsShared &S, int f) {
         uint32_t *bo = P.bin_off + (size_t)f * (nb + 1), *so = P.sbin_off + (size_t)f * (nb + 1);
         for (uint32_t b = 0; b <= nb; b++) { bo[b] = 0; so[b] = 0; }
         if (S.fail) fs_flag(P, f, FE_OVF_SEGS);
+    }
+    if (P.order_cnt) {                                                         // this frame's workgroups of dg_fe_columns, by weight class
+        constexpr uint32_t MAX_GROUPS = FS_MAX_W / 256;
+        const uint32_t groups = (uint32_t)(P.k.W + 255) / 256;
+        const uint32_t *cp = fs_bin_off(S, nb, 0), *cs = fs_bin_off(S, nb, 1);   // exclusive prefixes (fs_ph_bin_prefix)
+        uint32_t cls_of[MAX_GROUPS], cls_n[FS_ORDER_CLASSES] = {0, 0, 0, 0}, at[FS_ORDER_CLASSES];
+        for (uint32_t g = 0; g < groups; g++) {
+            uint32_t w = 0;
+            for (uint32_t b = 4 * g; b < 4 * g + 4 && b < nb && !bad; b++) {
+                const uint32_t np = (b + 1 < nb ? cp[b + 1] : S.bins_total) - cp[b], ns = (b + 1 < nb ? cs[b + 1] : S.sbins_total) - cs[b];
+                w = w > np + 2 * ns ? w : np + 2 * ns;
+            }
+            cls_of[g] = w > 32 ? 0u : w > 16 ? 1u : w > 8 ? 2u : 3u;
+            cls_n[cls_of[g]]++;
+        }
+        for (uint32_t k = 0; k < FS_ORDER_CLASSES; k++) at[k] = cls_n[k] ? fs_add_u32(&P.order_cnt[k], cls_n[k]) : 0u;
+        for (uint32_t g = 0; g < groups; g++) P.order_list[(size_t)cls_of[g] * P.n_items + at[cls_of[g]]++] = (uint32_t)f * groups + g;
     }
 }
 

@@ -233,7 +233,7 @@ int emul_render_fe(void *scene, int W, int H, const dg_view *view_in, uint8_t *r
     const size_t ev_kind = (size_t)arena.n_sky_slots * w64;               // zeroed like the product: no add, flushed
     std::vector<uint64_t> events(3 * ev_kind + 1, 0);
     std::vector<DevRSpan> rspans((size_t)W * FE_DEFAULT_COL_SLOTS);
-    FeParams P;
+    FeParams P{};
     P.scene = ds; P.k = k; P.frames = &fr; P.fframes = &ff; P.parts = arena.parts.data(); P.sprites = arena.sprites.data();
     P.behind = arena.behind.data(); P.bin_off = arena.bin_off.data(); P.bin_parts = arena.bin_parts.data();
     P.sbin_off = arena.sbin_off.data(); P.sbin_sprites = arena.sbin_sprites.data(); P.cspans = cspans.data(); P.recs = recs.data(); P.cnt = cnt.data();
@@ -570,7 +570,7 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     std::vector<FeSprite> sprites(FS_SPRITE_CAP);
     std::vector<uint32_t> behind((size_t)FS_SPRITE_CAP * FS_BEHIND_WORDS, 0), sky_parts(FS_SKY_CAP), bin_off(nb + 1), sbin_off(nb + 1);
     std::vector<uint16_t> bin_parts(FS_BIN_CAP), sbin_sprites(FS_SBIN_CAP);
-    FsParams P;
+    FsParams P{};
     P.k = DevConsts{fk.ARC, fk.GCFX, fk.CFX, fk.CFY, W, H};
     P.segs = sc.fs_segs.data(); P.seg_leaf = sc.fs_seg_leaf.data(); P.leaf_first = sc.fs_leaf_first.data();
     P.sectors = sc.fs_sectors.data(); P.anims = sc.fs_anims.data(); P.bitmaps = sc.fs_bitmaps.data(); P.flat_sky = sc.flat_sky.data();
