@@ -82,13 +82,7 @@ VERT = {"a0": (0, 0), "a1": (-64, 320), "p1": (384, 96), "p2": (320, 400), "b1":
 VORDER = ["a0", "a1", "p1", "p2", "b1", "b2"]
 
 
-def build_hand_iwad() -> bytes:
-    vi = {n: i for i, n in enumerate(VORDER)}
-    A, B = ["a0", "p1", "p2", "a1"], ["p1", "b1", "b2", "p2"]
-    for poly in (A, B):                                       # convex and counter-clockwise, so each is one BSP leaf
-        for i in range(4):
-            assert _cross(VERT[poly[i]], VERT[poly[(i + 1) % 4]], VERT[poly[(i + 2) % 4]]) > 0
-    # ---- graphics ------------------------------------------------------------------------------------------------------------------
+def _graphics():
     playpal = bytes(v for i in range(256) for v in ((i * 7 + 3) % 256, (i * 13 + 40) % 256, (255 - i * 5) % 256))
     patches = {
         "PWALL": _picture(64, 128, 0, 0, lambda x, y: (x * 3 + y * 5) % 251 + 1),
@@ -117,6 +111,30 @@ def build_hand_iwad() -> bytes:
     for rot in range(1, 9):                                   # a rotating sprite: eight different pictures (sprites.rs:35-57)
         sprites["TROOA%d" % rot] = _picture(24, 40, 12, 38, lambda x, y, r=rot: None if (x - 12) ** 2 + (y - 20) ** 2 > 150 + 10 * r else (x * r + y) % 60 + 10 * r)
     sprites["BAR1A0"] = _picture(20, 30, 10, 28, lambda x, y: None if (x in (0, 19) and y < 6) else (x + y) % 40 + 180)
+    return playpal, pnames, texture1, patches, flats, sprites
+
+
+def _pack_iwad(playpal, pnames, texture1, patches, flats, sprites, map_lumps) -> bytes:
+    lumps = [("PLAYPAL", playpal), ("PNAMES", pnames), ("TEXTURE1", texture1)]
+    lumps += [("P_START", b"")] + list(patches.items()) + [("P_END", b"")]
+    lumps += [("F_START", b"")] + list(flats.items()) + [("F_END", b"")]
+    lumps += [("S_START", b"")] + list(sprites.items()) + [("S_END", b"")]
+    lumps += map_lumps
+    # header (12 B: "IWAD", lump count, directory offset), lumps, directory (16 B: offset, size, name[8])
+    body, directory = b"", b""
+    for (name, data) in lumps:
+        directory += struct.pack("<II", 12 + len(body), len(data)) + _name8(name)
+        body += data
+    return b"IWAD" + struct.pack("<II", len(lumps), 12 + len(body)) + body + directory
+
+
+def build_hand_iwad() -> bytes:
+    vi = {n: i for i, n in enumerate(VORDER)}
+    A, B = ["a0", "p1", "p2", "a1"], ["p1", "b1", "b2", "p2"]
+    for poly in (A, B):                                       # convex and counter-clockwise, so each is one BSP leaf
+        for i in range(4):
+            assert _cross(VERT[poly[i]], VERT[poly[(i + 1) % 4]], VERT[poly[(i + 2) % 4]]) > 0
+    playpal, pnames, texture1, patches, flats, sprites = _graphics()
     # ---- the map -------------------------------------------------------------------------------------------------------------------
     # sectors (26 B: floor, ceiling, floor flat[8], ceiling flat[8], light, special, tag)
     sectors = struct.pack("<hh", 0, 128) + _name8("FLOORA") + _name8("CEILA") + struct.pack("<hhh", 160, 0, 0) + \
@@ -155,18 +173,52 @@ def build_hand_iwad() -> bytes:
     # things (10 B: x, y, angle in degrees, type, flags): player 1 start, an imp in each room (3001, rotating), a barrel (2035)
     things = struct.pack("<hhhhh", 96, 180, 0, 1, 7) + struct.pack("<hhhhh", 600, 250, 135, 3001, 7) + struct.pack("<hhhhh", 250, 300, 270, 3001, 7) + \
         struct.pack("<hhhhh", 200, 120, 0, 2035, 7) + struct.pack("<hhhhh", 700, 120, 90, 2035, 7)
-    lumps = [("PLAYPAL", playpal), ("PNAMES", pnames), ("TEXTURE1", texture1)]
-    lumps += [("P_START", b"")] + list(patches.items()) + [("P_END", b"")]
-    lumps += [("F_START", b"")] + list(flats.items()) + [("F_END", b"")]
-    lumps += [("S_START", b"")] + list(sprites.items()) + [("S_END", b"")]
-    lumps += [("E1M1", b""), ("THINGS", things), ("LINEDEFS", linedefs), ("SIDEDEFS", b"".join(sd)), ("VERTEXES", vertexes), ("SEGS", segs),
-              ("SSECTORS", ssectors), ("NODES", nodes), ("SECTORS", sectors), ("REJECT", b"\0"), ("BLOCKMAP", b"\0\0\0\0\0\0\0\0")]
-    # header (12 B: "IWAD", lump count, directory offset), lumps, directory (16 B: offset, size, name[8])
-    body, directory = b"", b""
-    for (name, data) in lumps:
-        directory += struct.pack("<II", 12 + len(body), len(data)) + _name8(name)
-        body += data
-    return b"IWAD" + struct.pack("<II", len(lumps), 12 + len(body)) + body + directory
+    return _pack_iwad(playpal, pnames, texture1, patches, flats, sprites,
+                      [("E1M1", b""), ("THINGS", things), ("LINEDEFS", linedefs), ("SIDEDEFS", b"".join(sd)), ("VERTEXES", vertexes), ("SEGS", segs),
+                       ("SSECTORS", ssectors), ("NODES", nodes), ("SECTORS", sectors), ("REJECT", b"\0"), ("BLOCKMAP", b"\0\0\0\0\0\0\0\0")])
+
+
+def build_polygon_iwad(n_walls: int = 1200, radius: int = 3000) -> bytes:
+    """One round room of n_walls one-sided walls (two BSP leaves: the halves above and below the x axis) with a ring of sprites: from
+    a point next to the wall, looking across, several hundred walls are in view at once — more than 256 wall records in one frame, which
+    is where the device column walk stops staging a sprite's behind-bit row (eight words) next to its record and the device seg walk
+    hands the frame back to the host (FS_PART_CAP)."""
+    playpal, pnames, texture1, patches, flats, sprites = _graphics()
+    V = []
+    for i in range(n_walls):                                  # counter-clockwise, integer coordinates, all distinct
+        a = 2.0 * math.pi * i / n_walls                      # vertices 0 and n / 2 lie on the x axis: no wall straddles the partition
+        V.append((int(round(radius * math.cos(a))), int(round(radius * math.sin(a)))))
+    assert len(set(V)) == n_walls and n_walls % 2 == 0
+    sectors = struct.pack("<hh", 0, 128) + _name8("FLOORA") + _name8("CEILA") + struct.pack("<hhh", 176, 0, 0)
+    sidedefs, linedefs, upper, lower = b"", b"", [], []
+    for i in range(n_walls):                                  # wall i runs clockwise: V[i + 1] -> V[i], the room on its right
+        sidedefs += struct.pack("<hh", (i * 7) % 64, (i * 3) % 32) + _name8("-") + _name8("-") + _name8("WALLA" if i % 3 else "TWOP") + struct.pack("<h", 0)
+        v1, v2 = (i + 1) % n_walls, i
+        linedefs += struct.pack("<hhhhhhh", v1, v2, 1, 0, 0, i, -1)
+        mid_y = V[v1][1] + V[v2][1]
+        (upper if mid_y > 0 else lower).append((v1, v2, i, 0))
+    assert len(upper) == len(lower) == n_walls // 2
+    segs = b"".join(struct.pack("<hhhhhh", v1, v2, 0, ld, d, 0) for (v1, v2, ld, d) in upper + lower)
+    ssectors = struct.pack("<hh", len(upper), 0) + struct.pack("<hh", len(lower), len(upper))
+    # one node: partition along the x axis, direction +x: its right side is y < 0 (subsector 1), its left side y > 0 (subsector 0)
+    r = radius + 1
+    nodes = struct.pack("<hhhh", -r, 0, 2 * r, 0) + struct.pack("<hhhh", 0, -r, -r, r) + struct.pack("<hhhh", r, 0, -r, r) + struct.pack("<HH", 0x8000 | 1, 0x8000 | 0)
+    vertexes = b"".join(struct.pack("<hh", *v) for v in V)
+    things = struct.pack("<hhhhh", 0, 0, 0, 1, 7)
+    for k in range(24):                                       # a ring of imps and barrels half way out, and a second one further out
+        a = 2.0 * math.pi * k / 24
+        rr = radius // 2 if k % 2 else (3 * radius) // 4
+        things += struct.pack("<hhhhh", int(rr * math.cos(a)), int(rr * math.sin(a)), (k * 45) % 360, 3001 if k % 3 else 2035, 7)
+    return _pack_iwad(playpal, pnames, texture1, patches, flats, sprites,
+                      [("E1M1", b""), ("THINGS", things), ("LINEDEFS", linedefs), ("SIDEDEFS", sidedefs), ("VERTEXES", vertexes), ("SEGS", segs),
+                       ("SSECTORS", ssectors), ("NODES", nodes), ("SECTORS", sectors), ("REJECT", b"\0"), ("BLOCKMAP", b"\0\0\0\0\0\0\0\0")])
+
+
+def _polygon_views(campath_mod, osc, radius: int = 3000):
+    """Next to the wall looking across the room (half the walls in view), from the centre, and two oblique ones."""
+    pts = [(-radius + 40.0, 10.0, 0.02), (radius - 60.0, -25.0, math.pi - 0.1), (0.0, 0.0, 0.7), (100.0, -radius + 50.0, math.pi / 2 + 0.3), (-1500.0, 900.0, -0.4)]
+    return [np.concatenate([campath_mod.view_record(np.float32(x), np.float32(y), np.float32(a), np.float32(osc.floor_height_at(x, y, 0.0))), np.zeros(1, dtype=np.float32)])
+            for (x, y, a) in pts]
 
 
 def _views(campath_mod, osc):
@@ -249,3 +301,45 @@ def test_hand_assembled_wad_on_the_gpu(dg, campath_mod, front_end):
             ref = np.frombuffer(osc.render(W, H, rec), dtype=np.uint8).reshape(H, W, 3)
             assert np.array_equal(out[k], ref), f"{W}x{H} view {k} t={ts}"
         ctx.close()
+
+
+def test_round_room_of_1200_walls_on_the_cpu(campath_mod):
+    """More wall records in one frame than a sprite's staged behind-bit row holds (256): oracle == product loader + host front end +
+    the column walk's bodies on the CPU; the frames really are that crowded."""
+    import doomref
+    import emul_bind
+    wad = build_polygon_iwad()
+    osc = doomref.Scene(wad, "e1m1")
+    assert osc.sector_count() == 1 and osc.mobj_count() == 24
+    es = emul_bind.EmulScene(wad)
+    W, H = 1280, 96
+    most = 0
+    for rec in _polygon_views(campath_mod, osc):
+        ref = osc.render(W, H, rec)
+        assert es.render(W, H, rec, 0.0)[0] == ref, rec[:3]
+        got, st = es.render_fe(W, H, rec, 0.0)
+        assert got == ref and st[3] == 0 and st[4] == 1, (rec[:3], st)
+        most = max(most, st[1])
+    assert most > 256, most
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("front_end", [1, 2, 3], ids=["host-lists", "device-column-walk", "device-seg-walk"])
+def test_round_room_of_1200_walls_on_the_gpu(dg, campath_mod, front_end):
+    """The same on the GPU.  With the device column walk the sprites' behind-bit rows are read from the batch's array (ten words: too long
+    to stage); the device seg walk flags the crowded frames (more than FS_PART_CAP parts) and they are redone through the host path."""
+    import doomref
+    wad = build_polygon_iwad()
+    osc = doomref.Scene(wad, "e1m1")
+    sc = dg.Scene(wad, "e1m1")
+    views = _polygon_views(campath_mod, osc)
+    W, H = 1280, 96
+    ctx = dg.Context(W, H, max_batch=len(views), slots=1, front_end=front_end)
+    ctx.upload_scene(sc)
+    out = ctx.render(dg.make_views(np.stack([r[:8] for r in views])))
+    for k, rec in enumerate(views):
+        ref = np.frombuffer(osc.render(W, H, rec), dtype=np.uint8).reshape(H, W, 3)
+        assert np.array_equal(out[k], ref), f"view {k}"
+    if front_end == 3:
+        assert ctx.fallbacks()["redone_frames"] >= 2
+    ctx.close()
