@@ -312,15 +312,15 @@ def test_round_room_of_1200_walls_on_the_cpu(campath_mod):
     osc = doomref.Scene(wad, "e1m1")
     assert osc.sector_count() == 1 and osc.mobj_count() == 24
     es = emul_bind.EmulScene(wad)
-    W, H = 1280, 96
-    most = 0
-    for rec in _polygon_views(campath_mod, osc):
-        ref = osc.render(W, H, rec)
-        assert es.render(W, H, rec, 0.0)[0] == ref, rec[:3]
-        got, st = es.render_fe(W, H, rec, 0.0)
-        assert got == ref and st[3] == 0 and st[4] == 1, (rec[:3], st)
-        most = max(most, st[1])
-    assert most > 256, most
+    for (W, H) in ((1280, 96), (320, 64)):                    # 320 wide: a part per column, 64 and more in every 64-column bin
+        most = 0
+        for rec in _polygon_views(campath_mod, osc):
+            ref = osc.render(W, H, rec)
+            assert es.render(W, H, rec, 0.0)[0] == ref, (W, rec[:3])
+            got, st = es.render_fe(W, H, rec, 0.0)
+            assert got == ref and st[3] == 0 and st[4] == 1, (W, rec[:3], st)
+            most = max(most, st[1])
+        assert most > 256, (W, most)
 
 
 @pytest.mark.gpu
@@ -333,13 +333,13 @@ def test_round_room_of_1200_walls_on_the_gpu(dg, campath_mod, front_end):
     osc = doomref.Scene(wad, "e1m1")
     sc = dg.Scene(wad, "e1m1")
     views = _polygon_views(campath_mod, osc)
-    W, H = 1280, 96
-    ctx = dg.Context(W, H, max_batch=len(views), slots=1, front_end=front_end)
-    ctx.upload_scene(sc)
-    out = ctx.render(dg.make_views(np.stack([r[:8] for r in views])))
-    for k, rec in enumerate(views):
-        ref = np.frombuffer(osc.render(W, H, rec), dtype=np.uint8).reshape(H, W, 3)
-        assert np.array_equal(out[k], ref), f"view {k}"
-    if front_end == 3:
-        assert ctx.fallbacks()["redone_frames"] >= 2
-    ctx.close()
+    for (W, H) in ((1280, 96), (320, 64)):                    # 320 wide: a part per column, 64 and more in every 64-column bin
+        ctx = dg.Context(W, H, max_batch=len(views), slots=1, front_end=front_end)
+        ctx.upload_scene(sc)
+        out = ctx.render(dg.make_views(np.stack([r[:8] for r in views])))
+        for k, rec in enumerate(views):
+            ref = np.frombuffer(osc.render(W, H, rec), dtype=np.uint8).reshape(H, W, 3)
+            assert np.array_equal(out[k], ref), f"{W}x{H} view {k}"
+        if front_end == 3:
+            assert ctx.fallbacks()["redone_frames"] >= 2
+        ctx.close()
