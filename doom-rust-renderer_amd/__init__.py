@@ -334,8 +334,11 @@ class Context:
 
 
 def frame_checksum(rgb24) -> int:
-    """dg_frame_checksums' formula on the host, for one frame given as bytes / uint8 array of length 3*W*H (W % 4 == 0)."""
-    d = np.frombuffer(rgb24, dtype="<u4") if not isinstance(rgb24, np.ndarray) else np.ascontiguousarray(rgb24).reshape(-1).view("<u4")
+    """dg_frame_checksums' formula on the host, for one frame given as bytes / uint8 array of length 3*W*H (a byte count that is not a
+    multiple of 4 ends in a zero-extended partial dword)."""
+    raw = bytes(rgb24) if not isinstance(rgb24, np.ndarray) else np.ascontiguousarray(rgb24).reshape(-1).tobytes()
+    raw += b"\0" * (-len(raw) % 4)
+    d = np.frombuffer(raw, dtype="<u4")
     with np.errstate(over="ignore"):
         i = np.arange(d.size, dtype=np.uint64)
         m = (d.astype(np.uint64) ^ (i * np.uint64(0x9E3779B97F4A7C15))) * np.uint64(0xBF58476D1CE4E5B9)

@@ -924,8 +924,8 @@ int dg_build_lists(const dg_scene *s, int width, int height, const dg_view *view
 
 int dg_create(const dg_config *cfg, dg_ctx **out) {
     if (!cfg || !out) return set_err(DG_ERR_INVALID, "null argument");
-    if (cfg->width <= 0 || cfg->height <= 0 || cfg->width % 4 != 0 || cfg->width > 16384 || cfg->height > 16384)
-        return set_err(DG_ERR_INVALID, "width/height must be positive, width % 4 == 0, both <= 16384");
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->width > 16384 || cfg->height > 16384)
+        return set_err(DG_ERR_INVALID, "width/height must be positive, both <= 16384");
     if (cfg->max_batch <= 0 || cfg->max_batch > 65535 || cfg->slots <= 0 || cfg->slots > 16)
         return set_err(DG_ERR_INVALID, "max_batch must be in [1, 65535], slots in [1, 16]");
     if (cfg->front_end < DG_FE_AUTO || cfg->front_end > DG_FE_DEVICE_SEGS) return set_err(DG_ERR_INVALID, "front_end must be DG_FE_AUTO, DG_FE_HOST, DG_FE_DEVICE or DG_FE_DEVICE_SEGS");

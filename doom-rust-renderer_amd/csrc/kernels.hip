@@ -305,6 +305,9 @@ struct TileLds {
 // offsets are staged ONCE, then the 64 x 64 tiles are rendered one after another out of the same staging area.  What a tile costs
 // besides its pixels — the load -> LDS -> barrier chain in front, the workgroup launch and drain around it — is paid once per strip
 // segment instead of once per tile (profiles/r03_raster_tiles.md: that fixed part was two thirds of the kernel's time).
+// W4: the frame width is a multiple of 4 (every BASELINE size, the reference's native 1024): a group of four pixels never straddles the
+// right edge and every row starts on a dword — the read-out stores dwords.  Any other width takes byte stores (dg_raster_tiles_anyw).
+template <bool W4>
 __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, int f, int x0, int ty_begin, int ty_end) {
 #ifdef DG_EXP_T_TIMING
     unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -552,13 +555,23 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
 #endif
         const int row = pass * 4 * WAVES + wave * 4 + rsub;
         const int yy = y0 + row, xx = x0 + 4 * gc;
-        if (yy < H && xx < W) {   // W % 4 == 0 (checked at dg_create), so a group never straddles the right edge
+        if (yy < H && xx < W) {
             const uint32_t p0 = L.tile[(4 * gc + 0) * TILE_TS + row], p1 = L.tile[(4 * gc + 1) * TILE_TS + row];
             const uint32_t p2 = L.tile[(4 * gc + 2) * TILE_TS + row], p3 = L.tile[(4 * gc + 3) * TILE_TS + row];
-            uint32_t *dst = reinterpret_cast<uint32_t *>(fb + ((size_t)yy * (size_t)W + (size_t)xx) * 3);
-            dst[0] = (p0 & 0xffffffu) | (p1 << 24);
-            dst[1] = ((p1 >> 8) & 0xffffu) | (p2 << 16);
-            dst[2] = ((p2 >> 16) & 0xffu) | (p3 << 8);
+            if constexpr (W4) {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(fb + ((size_t)yy * (size_t)W + (size_t)xx) * 3);
+                dst[0] = (p0 & 0xffffffu) | (p1 << 24);
+                dst[1] = ((p1 >> 8) & 0xffffu) | (p2 << 16);
+                dst[2] = ((p2 >> 16) & 0xffu) | (p3 << 8);
+            } else {
+                uint8_t *dst = fb + ((size_t)yy * (size_t)W + (size_t)xx) * 3;
+                const uint32_t px[4] = {p0, p1, p2, p3};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (xx + j >= W) break;
+                    dst[3 * j + 0] = (uint8_t)px[j]; dst[3 * j + 1] = (uint8_t)(px[j] >> 8); dst[3 * j + 2] = (uint8_t)(px[j] >> 16);
+                }
+            }
         }
     }
     if (ty + 1 < ty_end) __syncthreads();     // the LDS tile (and, when the spans did not fit, the staging area) is written again
@@ -577,7 +590,14 @@ __global__ __launch_bounds__(THREADS, 8) void dg_raster_tiles(RasterParams P) {
     __shared__ __attribute__((aligned(16))) TileLds L;
     const int n_tile_rows = (P.k.H + TILE_H - 1) / TILE_H;
     const int ty_begin = (int)blockIdx.y * P.tile_rows_per_wg;
-    strip_body(P, L, (int)blockIdx.z, (int)blockIdx.x * TILE_W, ty_begin, min(n_tile_rows, ty_begin + P.tile_rows_per_wg));
+    strip_body<true>(P, L, (int)blockIdx.z, (int)blockIdx.x * TILE_W, ty_begin, min(n_tile_rows, ty_begin + P.tile_rows_per_wg));
+}
+// The same for a frame width that is not a multiple of 4 (constants.rs:3-17 makes any width legal).
+__global__ __launch_bounds__(THREADS, 8) void dg_raster_tiles_anyw(RasterParams P) {
+    __shared__ __attribute__((aligned(16))) TileLds L;
+    const int n_tile_rows = (P.k.H + TILE_H - 1) / TILE_H;
+    const int ty_begin = (int)blockIdx.y * P.tile_rows_per_wg;
+    strip_body<false>(P, L, (int)blockIdx.z, (int)blockIdx.x * TILE_W, ty_begin, min(n_tile_rows, ty_begin + P.tile_rows_per_wg));
 }
 
 // Per-row constants of the flat and sky mappers for one frame size: vy = CFY - y (visplanes.rs:109), its prepared reciprocal, the
@@ -594,12 +614,22 @@ __global__ void dg_row_table(DevScene scene, DevConsts k, uint4 *row_tab) {
 
 // Order-independent per-frame checksum (dg_frame_checksums): every dword is mixed with its index, the mixes are summed.
 // Pure streaming read: 256 dwords per lane-iteration are coalesced, one 64-bit atomic add per wave.
+// (A frame whose byte count is not a multiple of 4 — a width that is not — ends in a partial dword, zero-extended, and its frames do not
+// start on dwords: bytes are loaded one by one then.)
 __global__ __launch_bounds__(256) void dg_checksum(const uint8_t *fb, size_t frame_bytes, unsigned long long *out) {
-    const uint32_t *d = reinterpret_cast<const uint32_t *>(fb + (size_t)blockIdx.y * frame_bytes);
-    const size_t n = frame_bytes / 4;
+    const uint8_t *b = fb + (size_t)blockIdx.y * frame_bytes;
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(b);
+    const bool dwords = (frame_bytes & 3) == 0;
+    const size_t n = (frame_bytes + 3) / 4;
     unsigned long long acc = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        unsigned long long m = ((unsigned long long)d[i] ^ (i * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull;
+        uint32_t v;
+        if (dwords) v = d[i];
+        else {
+            v = 0;
+            for (size_t k = 0; k < 4 && 4 * i + k < frame_bytes; k++) v |= (uint32_t)b[4 * i + k] << (8 * k);
+        }
+        unsigned long long m = ((unsigned long long)v ^ (i * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull;
         acc += m ^ (m >> 32);
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
@@ -608,7 +638,7 @@ __global__ __launch_bounds__(256) void dg_checksum(const uint8_t *fb, size_t fra
 
 hipError_t launch_checksums(const uint8_t *fb, size_t frame_bytes, int count, unsigned long long *out, hipStream_t stream) {
     if (count <= 0) return hipSuccess;
-    const unsigned blocks = (unsigned)std::min<size_t>(256, (frame_bytes / 4 + 255) / 256);
+    const unsigned blocks = (unsigned)std::min<size_t>(256, ((frame_bytes + 3) / 4 + 255) / 256);
     hipLaunchKernelGGL(dg_checksum, dim3(blocks, (unsigned)count), dim3(256), 0, stream, fb, frame_bytes, out);
     return hipGetLastError();
 }
@@ -658,7 +688,8 @@ hipError_t launch_raster(const RasterParams &P_in, hipStream_t stream, hipEvent_
     const int n_tile_rows = (P.k.H + TILE_H - 1) / TILE_H;
     if (P.tile_rows_per_wg <= 0) P.tile_rows_per_wg = raster_tile_rows_per_wg(P.k.W, P.k.H, P.n_frames);
     dim3 grid((unsigned)((P.k.W + TILE_W - 1) / TILE_W), (unsigned)((n_tile_rows + P.tile_rows_per_wg - 1) / P.tile_rows_per_wg), (unsigned)P.n_frames);
-    hipExtLaunchKernelGGL(dg_raster_tiles, grid, dim3(THREADS), 0, stream, start, stop, 0, P);
+    if (P.k.W % 4 == 0) hipExtLaunchKernelGGL(dg_raster_tiles, grid, dim3(THREADS), 0, stream, start, stop, 0, P);
+    else hipExtLaunchKernelGGL(dg_raster_tiles_anyw, grid, dim3(THREADS), 0, stream, start, stop, 0, P);
     return hipGetLastError();
 }
 

@@ -91,7 +91,7 @@ int dg_scene_sprite_frame(dg_scene *s, const char *sprite, uint8_t frame);
 /* ---- context ------------------------------------------------------------------------------------------------ */
 typedef struct dg_config {
     int32_t device;        /* HIP device ordinal */
-    int32_t width, height; /* frame size (the reference's SCREEN_WIDTH/HEIGHT, src/game.rs:28-29); width % 4 == 0 */
+    int32_t width, height; /* frame size (the reference's SCREEN_WIDTH/HEIGHT, src/game.rs:28-29); any width (a multiple of 4 takes the faster read-out) */
     int32_t max_batch;     /* frames per submission */
     int32_t slots;         /* in-flight submissions (>= 1); each owns a framebuffer slab of max_batch frames */
     int32_t host_threads;  /* list-generation threads for dg_render_views / dg_submit_views (0 = the process's CPU share: affinity mask and cgroup CPU quota, capped at 16).
@@ -158,7 +158,7 @@ int dg_readback(dg_ctx *ctx, int slot, int first, int count, uint8_t *rgb24_out)
  * complete it first, so the copy never sees a half-overwritten frame.  One readback in flight per slot. */
 int dg_readback_async(dg_ctx *ctx, int slot, int first, int count, uint8_t *rgb24_out);
 /* Frame sink without the PCIe copy: one 64-bit checksum per frame of a finished slot, computed on the GPU over the frame's
- * RGB24 bytes taken as little-endian dwords d[0 .. 3*W*H/4):
+ * RGB24 bytes taken as little-endian dwords d[0 .. ceil(3*W*H/4)) (a last partial dword is zero-extended):
  *     sum over i of  m ^ (m >> 32),   m = (d[i] ^ (i * 0x9E3779B97F4A7C15)) * 0xBF58476D1CE4E5B9    (all mod 2^64)
  * so a host that holds reference frames (e.g. `pixels.pixels` dumps of the reference, src/game.rs:521-525) can compare
  * thousands of large frames by 8 bytes each.  Waits for the slot like dg_readback. */

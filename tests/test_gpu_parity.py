@@ -467,6 +467,24 @@ def test_random_views_device_walk_equals_host_lists(dg, synth, campath_mod, orac
     scene.close()
 
 
+@pytest.mark.parametrize("front_end", [1, 2, 3], ids=["host-lists", "device-column-walk", "device-seg-walk"])
+@pytest.mark.parametrize("W,H", [(322, 200), (131, 67), (1283, 97), (5, 9)])
+def test_widths_that_are_not_multiples_of_four(dg, scene1993, oracle_scene1993, path1993, W, H, front_end):
+    """constants.rs:3-17 makes any SCREEN_WIDTH legal: the read-out then stores bytes (dg_raster_tiles_anyw), frames do not start on
+    dwords, and a frame's checksum ends in a partial dword."""
+    idx = list(range(0, 1000, 125))
+    ctx = make_ctx(dg, scene1993, W, H, len(idx), slots=1, front_end=front_end)
+    out = ctx.render(dg.make_views(path1993[idx]))
+    sums = ctx.frame_checksums(0, 0, len(idx))
+    for k, i in enumerate(idx):
+        ref = oracle_scene1993.render(W, H, path1993[i])
+        assert np.array_equal(out[k], np.frombuffer(ref, dtype=np.uint8).reshape(H, W, 3)), f"frame {i} at {W}x{H}"
+        assert int(sums[k]) == dg.frame_checksum(ref), f"checksum of frame {i} at {W}x{H}"
+    one = ctx.readback(0, 3, 2)                                       # a readback that starts at an odd byte offset of the slot's buffer
+    assert np.array_equal(one, out[3:5])
+    ctx.close()
+
+
 def test_device_frame_checksums(dg, scene1993, oracle_scene1993, path1993):
     """dg_frame_checksums == the same formula on the host, for GPU frames and (through them) for oracle frames."""
     W, H = 320, 200
