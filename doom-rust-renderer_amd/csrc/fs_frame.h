@@ -172,7 +172,6 @@ struct FsShared {                              // LDS on the GPU
     uint16_t s_order[FS_SPRITE_CAP], s_x0b[FS_SPRITE_CAP], s_x1b[FS_SPRITE_CAP];   // place in the far-to-near order; first / last column bin (x0b > x1b: no columns)
     uint32_t n_sprites;
     uint32_t fail;
-    uint32_t bins_total, sbins_total;          // entries of the frame's two bin tables (fs_ph_bin_prefix)
 };
 
 // phase 0 (lane 0): reset
@@ -442,16 +441,31 @@ DG_HD void fs_ph_bin_prefix(const FsParams &P, FsShared &S, int f) {      // lan
     const uint32_t nb = (uint32_t)(P.k.W + FE_BIN_W - 1) / FE_BIN_W;
     uint32_t *bo = P.bin_off + (size_t)f * (nb + 1), *so = P.sbin_off + (size_t)f * (nb + 1);
     uint32_t *cp = fs_bin_off(S, nb, 0), *cs = fs_bin_off(S, nb, 1);
-    uint32_t rp = 0, rs = 0;
+    // (the frame's workgroups of dg_fe_columns — 256 columns = four bins each — are appended to the launch-order list of their weight
+    // class here rather than with the header: the atomics' round trip then overlaps the other lanes' filling of the bin lists)
+    constexpr uint32_t MAX_GROUPS = FS_MAX_W / 256;
+    uint32_t cls_of[MAX_GROUPS], cls_n[FS_ORDER_CLASSES] = {0, 0, 0, 0}, at[FS_ORDER_CLASSES];
+    uint32_t rp = 0, rs = 0, w = 0;
     for (uint32_t b = 0; b < nb; b++) {
         const uint32_t np = cp[b], ns = cs[b];
         bo[b] = rp; so[b] = rs;
         cp[b] = rp; cs[b] = rs;
         rp += np; rs += ns;
+        w = w > np + 2 * ns ? w : np + 2 * ns;
+        if ((b & 3u) == 3u || b + 1 == nb) {
+            const uint32_t cls = w > 32 ? 0u : w > 16 ? 1u : w > 8 ? 2u : 3u;
+            cls_of[b >> 2] = cls;
+            cls_n[cls]++;
+            w = 0;
+        }
     }
     bo[nb] = rp; so[nb] = rs;
-    S.bins_total = rp; S.sbins_total = rs;
     if (rp > FS_BIN_CAP || rs > FS_SBIN_CAP) S.fail = 1;
+    if (P.order_cnt) {
+        const uint32_t groups = (nb + 3) / 4;
+        for (uint32_t k = 0; k < FS_ORDER_CLASSES; k++) at[k] = cls_n[k] ? fs_add_u32(&P.order_cnt[k], cls_n[k]) : 0u;
+        for (uint32_t g = 0; g < groups; g++) P.order_list[(size_t)cls_of[g] * P.n_items + at[cls_of[g]]++] = (uint32_t)f * groups + g;
+    }
 }
 DG_HD void fs_ph_bin_fill(const FsParams &P, FsShared &S, int f, int lane) {
     if (S.fail) return;
@@ -496,23 +510,6 @@ DG_HD void fs_ph_header(const FsParams &P, FsShared &S, int f) {
         uint32_t *bo = P.bin_off + (size_t)f * (nb + 1), *so = P.sbin_off + (size_t)f * (nb + 1);
         for (uint32_t b = 0; b <= nb; b++) { bo[b] = 0; so[b] = 0; }
         if (S.fail) fs_flag(P, f, FE_OVF_SEGS);
-    }
-    if (P.order_cnt) {                                                         // this frame's workgroups of dg_fe_columns, by weight class
-        constexpr uint32_t MAX_GROUPS = FS_MAX_W / 256;
-        const uint32_t groups = (uint32_t)(P.k.W + 255) / 256;
-        const uint32_t *cp = fs_bin_off(S, nb, 0), *cs = fs_bin_off(S, nb, 1);   // exclusive prefixes (fs_ph_bin_prefix)
-        uint32_t cls_of[MAX_GROUPS], cls_n[FS_ORDER_CLASSES] = {0, 0, 0, 0}, at[FS_ORDER_CLASSES];
-        for (uint32_t g = 0; g < groups; g++) {
-            uint32_t w = 0;
-            for (uint32_t b = 4 * g; b < 4 * g + 4 && b < nb && !bad; b++) {
-                const uint32_t np = (b + 1 < nb ? cp[b + 1] : S.bins_total) - cp[b], ns = (b + 1 < nb ? cs[b + 1] : S.sbins_total) - cs[b];
-                w = w > np + 2 * ns ? w : np + 2 * ns;
-            }
-            cls_of[g] = w > 32 ? 0u : w > 16 ? 1u : w > 8 ? 2u : 3u;
-            cls_n[cls_of[g]]++;
-        }
-        for (uint32_t k = 0; k < FS_ORDER_CLASSES; k++) at[k] = cls_n[k] ? fs_add_u32(&P.order_cnt[k], cls_n[k]) : 0u;
-        for (uint32_t g = 0; g < groups; g++) P.order_list[(size_t)cls_of[g] * P.n_items + at[cls_of[g]]++] = (uint32_t)f * groups + g;
     }
 }
 

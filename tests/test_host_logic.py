@@ -34,7 +34,7 @@ def test_no_cpu_fallback(dg, gpu_available):
 
 
 def test_create_argument_checks(dg):
-    for (w, h, b, s) in [(0, 200, 1, 1), (322, 200, 1, 1), (320, 0, 1, 1), (320, 200, 0, 1), (320, 200, 1, 0), (320, 200, 1, 99)]:
+    for (w, h, b, s) in [(0, 200, 1, 1), (16388, 200, 1, 1), (320, 0, 1, 1), (320, 200, 0, 1), (320, 200, 1, 0), (320, 200, 1, 99)]:
         with pytest.raises(dg.DoomGpuError) as e:
             dg.Context(w, h, max_batch=b, slots=s)
         assert e.value.code == dg.DG_ERR_INVALID
