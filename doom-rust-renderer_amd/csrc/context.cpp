@@ -132,7 +132,8 @@ struct Slot {
     uint32_t *d_fe_coloff = nullptr;
     uint32_t *h_status = nullptr;               // pinned host memory the walk's kernels write: [F] overflow flags, [F] spans per frame
     uint64_t *d_events = nullptr;               // sky event bits (fe_event_words), zeroed before every walk
-    size_t flags_bytes = 0;
+    size_t flags_bytes = 0, walk_state_bytes = 0;   // the flag words + order counters; the whole allocation with the event bits
+    bool walk_state_clean = false;              // d_flags .. is all zero (dg_fe_scan cleans up after the walk; enqueue_kernels clears a slot that is not)
     uint32_t *d_order = nullptr;                // dg_fe_columns' launch-order lists as dg_fs_frame builds them (FsParams::order_list)
     uint32_t *d_flags = nullptr;                // [F] overflow flags the walk's kernels OR into; sits in front of d_events (one memset clears both)
     FeParams FP{};
@@ -700,8 +701,10 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
     HIP_TRY(hipStreamWaitEvent(ks, s.ev_h2d, 0));
     if (fe_mode) {
         std::memset(s.h_status, 0, (size_t)2 * (size_t)c->cfg.max_batch * 4);
-        const size_t ev_bytes = (size_t)3 * (size_t)s.FP.n_frames * s.FP.max_sky_slots * s.FP.w64 * 8;   // all three event kinds (fe_event_words)
-        HIP_TRY(hipMemsetAsync(s.d_flags, 0, s.flags_bytes + ev_bytes, ks));                            // the overflow flags and the event bits behind them
+        // the overflow flags, the launch-order counters and the event bits behind them start from zero: dg_fe_scan leaves them so (its
+        // last lines), and only a slot that is new or whose last enqueue failed half way is cleared here, whole
+        if (!s.walk_state_clean) HIP_TRY(hipMemsetAsync(s.d_flags, 0, s.walk_state_bytes, ks));
+        s.walk_state_clean = false;
         if (s.fs_mode) {                                                                                // the seg walk writes what the column walk reads
             if (c->fs_rows_dirty) HIP_TRY(hipMemsetAsync(c->d_fs_scratch, 0, c->fs_zero_bytes, ks));    // (dg_fs_frame leaves its rows clean)
             c->fs_rows_dirty = true;
@@ -713,6 +716,7 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
         HIP_TRY(launch_setup(s.P, s.max_spans, ks, s.ev_start, s.ev_setup));
     }
     HIP_TRY(launch_raster(s.P, ks, s.ev_rstart, s.ev_raster));
+    if (fe_mode) s.walk_state_clean = true;               // everything was enqueued: dg_fe_scan will have cleaned up by the slot's next batch
     guard.armed = false;
     s.harvested = false;
     s.fe_check = fe_mode;
@@ -1024,7 +1028,8 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
             CTX_TRY(hipMalloc((void **)&s.d_fe_coloff, F * (W + 1) * 4));
             s.flags_bytes = align_up(F * 4 + FS_ORDER_CLASSES * 4, 256);       // the flag words, then the seg walk's launch-order counters
             CTX_TRY(hipMalloc((void **)&s.d_order, FS_ORDER_CLASSES * F * ((W + 255) / 256) * 4));
-            CTX_TRY(hipMalloc((void **)&s.d_flags, s.flags_bytes + F * FE_MAX_SKY_SLOTS * 3 * ((W + 63) / 64) * 8));
+            s.walk_state_bytes = s.flags_bytes + F * FE_MAX_SKY_SLOTS * 3 * ((W + 63) / 64) * 8;
+            CTX_TRY(hipMalloc((void **)&s.d_flags, s.walk_state_bytes));
             s.d_events = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(s.d_flags) + s.flags_bytes);
             CTX_TRY(hipHostMalloc((void **)&s.h_status, 2 * F * 4, hipHostMallocDefault));
         }

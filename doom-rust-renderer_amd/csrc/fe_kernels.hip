@@ -295,11 +295,21 @@ __global__ __launch_bounds__(FE_SCAN_THREADS) void dg_fe_scan(FeParams P) {
         P.totals[f] = total;
         // the frame's overflow word goes to the host here, with a plain store: dg_fe_columns and dg_fe_gaps have finished (same stream)
         P.host_flags[f] = P.flags[f] | (fits ? 0u : (uint32_t)FE_OVF_FRAME);
+        P.flags[f] = 0u;
     }
     for (int x = xa; x < xb; x++) {
         coff[x] = fits ? off : 0u;
         off += min(cnt[x], P.col_slots);
     }
+    // The walk's per-batch state goes back to zero here, after its last reader: the frame's flag word (above), its event words (read by
+    // dg_fe_gaps) and the launch-order counters (read by dg_fe_columns) — the next batch of this slot then needs no fill kernel in front of
+    // it (5 us plus a kernel boundary per batch; context.cpp clears everything once, and again after a failed enqueue).
+    const size_t ev_words = (size_t)P.max_sky_slots * (size_t)P.w64;
+    for (int kind = 0; kind < 3; kind++) {
+        uint64_t *ev = fe_event_words(P, f, 0, kind);
+        for (size_t i = (size_t)tid; i < ev_words; i += FE_SCAN_THREADS) ev[i] = 0ull;
+    }
+    if (f == 0 && P.order_cnt && tid < (int)FS_ORDER_CLASSES) const_cast<uint32_t *>(P.order_cnt)[tid] = 0u;
 }
 
 // Every column's spans into draw order and into the raster kernel's form: rank by key among the column's spans
