@@ -768,3 +768,23 @@ def test_auto_front_end_picks_per_batch(dg, scene1993, oracle_scene1993, path199
     assert ctx.timing(0)["front_end"] == dg.DG_FE_DEVICE
     assert np.array_equal(small[7], np.frombuffer(oracle_scene1993.render(W, H, path1993[107]), dtype=np.uint8).reshape(H, W, 3))
     ctx.close()
+
+
+def test_one_slot_alternating_front_ends_keeps_its_walk_state_clean(dg, scene1993, oracle_scene1993, path1993):
+    """The column walk zeroes its own per-batch state (flag words, sky event bits, launch-order counters) instead of a fill kernel in
+    front of every batch, and the layout of the event bits follows the batch (the seg walk reserves 64 sky slots per frame, the host
+    walker the batch's maximum): one slot taking seg-walk batches, host-walker batches and a host-list batch in turn, of different
+    lengths, every frame compared with the oracle — sky entries included (this map has sky sectors)."""
+    W, H = 320, 200
+    ctx = dg.Context(W, H, max_batch=200, slots=1, front_end=dg.DG_FE_AUTO)
+    ctx.upload_scene(scene1993)
+    plan = [(0, 200), (300, 40), (500, 128), (40, 7), (700, 200), (900, 63), (100, 64)]     # (first frame, count): >= 64 views -> seg walk (nothing in flight)
+    used = []
+    for (b0, n) in plan:
+        out = ctx.render(dg.make_views(path1993[b0:b0 + n]))
+        used.append(ctx.timing(0)["front_end"])
+        for k in range(0, n, 9):
+            assert np.array_equal(out[k], np.frombuffer(oracle_scene1993.render(W, H, path1993[b0 + k]), dtype=np.uint8).reshape(H, W, 3)), (b0, k)
+    assert used == [dg.DG_FE_DEVICE_SEGS if n >= 64 else dg.DG_FE_DEVICE for (_, n) in plan], used
+    assert ctx.fallbacks() == {"front_end": 0, "redone_frames": 0}
+    ctx.close()
