@@ -773,8 +773,8 @@ def test_auto_front_end_picks_per_batch(dg, scene1993, oracle_scene1993, path199
 def test_one_slot_alternating_front_ends_keeps_its_walk_state_clean(dg, scene1993, oracle_scene1993, path1993):
     """The column walk zeroes its own per-batch state (flag words, sky event bits, launch-order counters) instead of a fill kernel in
     front of every batch, and the layout of the event bits follows the batch (the seg walk reserves 64 sky slots per frame, the host
-    walker the batch's maximum): one slot taking seg-walk batches, host-walker batches and a host-list batch in turn, of different
-    lengths, every frame compared with the oracle — sky entries included (this map has sky sectors)."""
+    walker the batch's maximum): one slot taking seg-walk batches and host-walker batches in turn, of different lengths, sampled
+    frames compared with the oracle — sky entries included (this map has sky sectors)."""
     W, H = 320, 200
     ctx = dg.Context(W, H, max_batch=200, slots=1, front_end=dg.DG_FE_AUTO)
     ctx.upload_scene(scene1993)
