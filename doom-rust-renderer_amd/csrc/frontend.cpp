@@ -365,7 +365,8 @@ struct Walker {
         const int32_t st = fs_seg(k, sg, sc.fs_sectors.data(), sc.fs_anims.data(), ppos, view.cos_na, view.sin_na, player_height, view.timestamp, light, so);
         if (st == FS_SKIP) return;
         if (st != FS_OK) { fail(fs_message(st)); return; }
-        for (int i = 0; i < so.n_calls && !status; i++) process_sidedef(so, so.call[i]);
+        for (int i = 0; i < so.n_calls && !status; i++)
+            if ((so.call_mask >> i) & 1u) process_sidedef(so, so.call[i]);
     }
 
     // Renderer::render_node, mod.rs:69-104 — iterative, front child first, no culling (the reference has none)

@@ -171,9 +171,12 @@ struct FsSegOut {                            // process_seg up to its process_si
     int16_t seg_offset, floor_h, ceil_h, light;
     int32_t floor_flat, ceil_flat;
     float sd_xoff, sd_yoff;
-    int32_t n_calls;
-    FsCall call[5];
+    int32_t n_calls;                         // slots to look at: 1 (one-sided) or 4; call_mask says which of them hold a call.  The slots
+    uint32_t call_mask;                      // are fixed — only-occlusion, two-sided middle, lower, upper (the reference's order) — so that
+    FsCall call[4];                          // every index into call[] is a constant (an indexed array would live in scratch memory on the GPU)
 };
+// The call in slot i (a constant after unrolling).
+DG_HD FsCall fs_call(const FsSegOut &o, uint32_t i) { return i == 0u ? o.call[0] : i == 1u ? o.call[1] : i == 2u ? o.call[2] : o.call[3]; }
 
 // Segs::process_seg, segs.rs:353-590, for a viewer at ppos looking along (cos_na, sin_na) = (cos, sin)(-angle).  light: the front
 // sector's CURRENT light level.  Returns FS_OK with 1 .. 5 calls, FS_SKIP, or a failure.
@@ -216,22 +219,24 @@ DG_HD int32_t fs_seg(const K &k, const FsSeg &sg, const FsSector *sectors, const
     if (!two_sided) {
         const int32_t oy = bottom_unpegged ? f32_as_i32(floor_height - ceiling_height) : 0;
         o.call[0] = FsCall{floor_height - player_height, ceiling_height - player_height, oy, sg.tex_mid, dc};
-        o.n_calls = 1;
+        o.n_calls = 1; o.call_mask = 1u;
         return FS_OK;
     }
-    int n = 0;
-    o.call[n++] = FsCall{floor_height - player_height, ceiling_height - player_height, 0, sg.tex_mid, dc | FEP_ONLY_OCCL};
+    o.call[0] = FsCall{floor_height - player_height, ceiling_height - player_height, 0, sg.tex_mid, dc | FEP_ONLY_OCCL};
     const float mid_floor = has_pb ? pb_h : floor_height, mid_ceil = has_pt ? pt_h : ceiling_height;
-    o.call[n++] = FsCall{mid_floor - player_height, mid_ceil - player_height, 0, sg.tex_mid, dc | FEP_TWO_SIDED_MID};
+    o.call[1] = FsCall{mid_floor - player_height, mid_ceil - player_height, 0, sg.tex_mid, dc | FEP_TWO_SIDED_MID};
+    o.call_mask = 3u;
     if (has_pb) {
         const int32_t oy = bottom_unpegged ? f32_as_i32(ceiling_height - pb_h) : 0;
-        o.call[n++] = FsCall{floor_height - player_height, pb_h - player_height, oy, sg.tex_low, dc | FEP_LOWER};
+        o.call[2] = FsCall{floor_height - player_height, pb_h - player_height, oy, sg.tex_low, dc | FEP_LOWER};
+        o.call_mask |= 4u;
     }
     if (has_pt) {
         const int32_t oy = top_unpegged ? 0 : f32_as_i32(pt_h - ceiling_height);
-        o.call[n++] = FsCall{pt_h - player_height, ceiling_height - player_height, oy, sg.tex_up, dc | FEP_UPPER};
+        o.call[3] = FsCall{pt_h - player_height, ceiling_height - player_height, oy, sg.tex_up, dc | FEP_UPPER};
+        o.call_mask |= 8u;
     }
-    o.n_calls = n;
+    o.n_calls = 4;
     return FS_OK;
 }
 

@@ -140,7 +140,9 @@ DG_HD void fs_seg_lane(const FsParams &P, int f, uint32_t si) {
     const uint32_t leaf = P.seg_leaf[si];
     const uint32_t pos = P.leaf_base[(size_t)f * P.n_leaves + leaf] + (si - P.leaf_first[leaf]);
     uint2 *lite = P.lite + ((size_t)f * P.n_segs + pos) * FS_CALLS;
-    for (int i = 0; i < so.n_calls; i++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (!((so.call_mask >> i) & 1u)) continue;
         int32_t sx, ex;
         uint32_t flags;
         const int32_t ps = fs_part_head(P.k, so, so.call[i], P.bitmaps, P.flat_sky, sx, ex, flags);
@@ -172,6 +174,7 @@ struct FsShared {                              // LDS on the GPU
     uint16_t s_order[FS_SPRITE_CAP], s_x0b[FS_SPRITE_CAP], s_x1b[FS_SPRITE_CAP];   // place in the far-to-near order; first / last column bin (x0b > x1b: no columns)
     uint32_t n_sprites;
     uint32_t fail;
+    uint8_t group_cls[FS_MAX_W / 256 + 6];     // weight class of each 256-column group (fs_ph_bin_prefix)
 };
 
 // phase 0 (lane 0): reset
@@ -308,7 +311,7 @@ DG_HD void fs_ph_emit(const FsParams &P, FsShared &S, int f, int lane) {
         FsSegOut so;
         FePart p;
         const int32_t st = fs_seg(P.k, sg, P.sectors, P.anims, V2{v.x, v.y}, v.cos_na, v.sin_na, v.floor_height + 41.0f, v.timestamp, P.sector_light[sg.front_sector], so);
-        if (st != FS_OK || fs_part(P.k, so, so.call[src & 7u], P.bitmaps, P.flat_sky, v.floor_height, p) != FS_OK) { S.fail = 1; continue; }   // (cannot happen: dg_fs_segs passed it)
+        if (st != FS_OK || fs_part(P.k, so, fs_call(so, src & 7u), P.bitmaps, P.flat_sky, v.floor_height, p) != FS_OK) { S.fail = 1; continue; }   // (cannot happen: dg_fs_segs passed it)
         p.sky_slot = S.kept_sky[o];
         P.parts[(size_t)f * FS_PART_CAP + o] = p;
         S.kline[o][0] = so.cl.line.a.x; S.kline[o][1] = so.cl.line.a.y; S.kline[o][2] = so.cl.line.b.x; S.kline[o][3] = so.cl.line.b.y;
@@ -442,9 +445,9 @@ DG_HD void fs_ph_bin_prefix(const FsParams &P, FsShared &S, int f) {      // lan
     uint32_t *bo = P.bin_off + (size_t)f * (nb + 1), *so = P.sbin_off + (size_t)f * (nb + 1);
     uint32_t *cp = fs_bin_off(S, nb, 0), *cs = fs_bin_off(S, nb, 1);
     // (the frame's workgroups of dg_fe_columns — 256 columns = four bins each — are appended to the launch-order list of their weight
-    // class here rather than with the header: the atomics' round trip then overlaps the other lanes' filling of the bin lists)
-    constexpr uint32_t MAX_GROUPS = FS_MAX_W / 256;
-    uint32_t cls_of[MAX_GROUPS], cls_n[FS_ORDER_CLASSES] = {0, 0, 0, 0}, at[FS_ORDER_CLASSES];
+    // class here rather than with the header: the atomics' round trip then overlaps the other lanes' filling of the bin lists.  No
+    // indexed local arrays: they would live in scratch memory.)
+    uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
     uint32_t rp = 0, rs = 0, w = 0;
     for (uint32_t b = 0; b < nb; b++) {
         const uint32_t np = cp[b], ns = cs[b];
@@ -454,8 +457,8 @@ DG_HD void fs_ph_bin_prefix(const FsParams &P, FsShared &S, int f) {      // lan
         w = w > np + 2 * ns ? w : np + 2 * ns;
         if ((b & 3u) == 3u || b + 1 == nb) {
             const uint32_t cls = w > 32 ? 0u : w > 16 ? 1u : w > 8 ? 2u : 3u;
-            cls_of[b >> 2] = cls;
-            cls_n[cls]++;
+            S.group_cls[b >> 2] = (uint8_t)cls;
+            n0 += cls == 0u; n1 += cls == 1u; n2 += cls == 2u; n3 += cls == 3u;
             w = 0;
         }
     }
@@ -463,8 +466,13 @@ DG_HD void fs_ph_bin_prefix(const FsParams &P, FsShared &S, int f) {      // lan
     if (rp > FS_BIN_CAP || rs > FS_SBIN_CAP) S.fail = 1;
     if (P.order_cnt) {
         const uint32_t groups = (nb + 3) / 4;
-        for (uint32_t k = 0; k < FS_ORDER_CLASSES; k++) at[k] = cls_n[k] ? fs_add_u32(&P.order_cnt[k], cls_n[k]) : 0u;
-        for (uint32_t g = 0; g < groups; g++) P.order_list[(size_t)cls_of[g] * P.n_items + at[cls_of[g]]++] = (uint32_t)f * groups + g;
+        uint32_t a0 = n0 ? fs_add_u32(&P.order_cnt[0], n0) : 0u, a1 = n1 ? fs_add_u32(&P.order_cnt[1], n1) : 0u;
+        uint32_t a2 = n2 ? fs_add_u32(&P.order_cnt[2], n2) : 0u, a3 = n3 ? fs_add_u32(&P.order_cnt[3], n3) : 0u;
+        for (uint32_t g = 0; g < groups; g++) {
+            const uint32_t cls = S.group_cls[g];
+            const uint32_t at = cls == 0u ? a0++ : cls == 1u ? a1++ : cls == 2u ? a2++ : a3++;
+            P.order_list[(size_t)cls * P.n_items + at] = (uint32_t)f * groups + g;
+        }
     }
 }
 DG_HD void fs_ph_bin_fill(const FsParams &P, FsShared &S, int f, int lane) {

@@ -195,3 +195,25 @@ def test_tile_rasteriser_keeps_four_workgroups_per_cu():
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
         assert vgpr <= 64 and scratch == 0 and lds <= 40960, (name, vgpr, scratch, lds)
     assert seen == 2          # dg_raster_tiles and dg_raster_tiles_anyw (widths that are not multiples of 4)
+
+
+def test_column_walk_and_seg_walk_keep_their_workgroups_per_cu():
+    """dg_fe_columns is sized for eight 4-wave workgroups per CU: at most 20 KB of LDS per workgroup (the wall records of a column and the
+    staged record heads live there: profiles/r04_column_walk.md — with 34 KB the launch of 320x200 batches spread over twice the time) and
+    no scratch; dg_fs_frame for four 256-thread workgroups per CU (all 1 000 frames of a batch resident at once): at most 40 KB (its scratch —
+    the FePart / FeSprite records it assembles for the few survivors — is bounded, not zero); dg_fs_segs, one lane per (frame, seg), keeps the
+    calls of a seg in registers (fs_core.h: fixed call slots)."""
+    want = {"dg_fe_columns": ("fe_kernels.hip", 20 * 1024, 0), "dg_fs_frame": ("fs_kernels.hip", 40 * 1024 + 512, 160), "dg_fs_segs": ("fs_kernels.hip", 0, 16)}
+    for kernel, (src, lds_max, scratch_max) in want.items():
+        asm = subprocess.run([HIPCC, *FLAGS, "-S", "--cuda-device-only", "-o", "-", os.path.join(CSRC, src)], capture_output=True, text=True, check=True).stdout
+        seen = 0
+        for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm, re.S):
+            name, body = m.group(1), m.group(2)
+            if kernel not in name:
+                continue
+            seen += 1
+            lds = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
+            scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+            vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+            assert lds <= lds_max and scratch <= scratch_max and vgpr <= 128, (name, lds, scratch, vgpr)
+        assert seen == 1, kernel
