@@ -147,6 +147,31 @@ struct Slot {
     std::vector<dg_view_state> states;
     std::vector<dg_sector_light> state_lights;
     std::vector<dg_mobj_state> state_mobjs;
+    // The scene's own light levels and map-object states as they were when the batch was submitted: a frame that overflows a capacity is
+    // redone at dg_wait time from the host walker, and dg_scene_set_sector_light / _mobj_state may have moved the scene on by then
+    // (lights.rs:47-259 and map_objects.rs:63-121 run between two submissions of a pipelined caller).
+    const Scene *snap_scene = nullptr;
+    uint64_t snap_rev = 0;
+    std::vector<dg_sector_light> snap_lights;
+    std::vector<dg_mobj_state> snap_mobjs;
+    void snapshot_scene(const Scene &sc) {
+        if (snap_scene == &sc && snap_rev == sc.revision && snap_lights.size() == sc.sectors.size() && snap_mobjs.size() == sc.mobjs.size()) return;
+        snap_lights.resize(sc.sectors.size()); snap_mobjs.resize(sc.mobjs.size());
+        for (size_t i = 0; i < sc.sectors.size(); i++) snap_lights[i] = dg_sector_light{(int32_t)i, (int32_t)sc.sectors[i].light};
+        for (size_t i = 0; i < sc.mobjs.size(); i++) snap_mobjs[i] = dg_mobj_state{(int32_t)i, sc.mobjs[i].sprite_frame, sc.mobjs[i].full_bright ? 1 : 0, 0};
+        snap_scene = &sc; snap_rev = sc.revision;
+    }
+    // The game state frame i of the last submission was rendered with, for the host walker: nullptr = the scene as it is (unchanged since the
+    // submission, no per-view snapshot); else the submit-time scene state with the view's own entries on top (later entries win).
+    struct RedoState { std::vector<dg_sector_light> lights; std::vector<dg_mobj_state> mobjs; dg_view_state st{}; };
+    const dg_view_state *state_for_redo(const Scene &sc, int i, RedoState &tmp) const {
+        const dg_view_state *own = states.empty() ? nullptr : &states[(size_t)i];
+        if (snap_scene != &sc || snap_rev == sc.revision) return own;
+        tmp.lights = snap_lights; tmp.mobjs = snap_mobjs;
+        if (own) { tmp.lights.insert(tmp.lights.end(), own->lights, own->lights + own->n_lights); tmp.mobjs.insert(tmp.mobjs.end(), own->mobjs, own->mobjs + own->n_mobjs); }
+        tmp.st = dg_view_state{tmp.lights.data(), (uint32_t)tmp.lights.size(), tmp.mobjs.data(), (uint32_t)tmp.mobjs.size()};
+        return &tmp.st;
+    }
     void keep_states(const dg_view_state *st, int n) {
         states.clear(); state_lights.clear(); state_mobjs.clear();
         if (!st) return;
@@ -480,6 +505,7 @@ int build_batch_fe(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_vie
     s.fe_mode = true; s.fs_mode = false; s.fe_check = false;
     s.views.assign(views, views + n);
     s.keep_states(states, n);
+    s.snapshot_scene(sc);
     s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (n >= 64 && !states && c->host_samples++ > 0) {        // DG_FE_AUTO's measurement of the host side (the first batch pays for cold caches: not counted)
         const double v = (double)s.host_ms / n;
@@ -663,6 +689,7 @@ int build_batch_fs(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     s.list_bytes = upload;
     s.fe_mode = true; s.fs_mode = true; s.fe_check = false;
     s.keep_states(nullptr, n);
+    s.snapshot_scene(sc);
     s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIP_TRY(hipMemcpyAsync(s.d_fe, s.h_fe, upload, hipMemcpyHostToDevice, s.stream));
     return DG_OK;
@@ -737,7 +764,8 @@ int redo_frame_host(dg_ctx *c, Slot &s, int i) {
     dg_view v = s.views[(size_t)i];
     fill_view_trig(v);
     dg_frame_lists fl;
-    int rc = build_frame_lists(sc, W, H, v, *c->arenas[0], fl, err, s.states.empty() ? nullptr : &s.states[(size_t)i]);
+    Slot::RedoState redo_state;
+    int rc = build_frame_lists(sc, W, H, v, *c->arenas[0], fl, err, s.state_for_redo(sc, i, redo_state));
     if (!rc) rc = bin_frame(sc, c->fk, fl, bf, err);
     if (rc) return set_err(rc, "frame " + std::to_string(i) + ": " + err);
     bf.hdr.span_base = 0; bf.hdr.wall_base = 0; bf.hdr.plane_base = 0;
@@ -800,8 +828,17 @@ int settle_slot(dg_ctx *c, Slot &s) {
             }
         }
         if (whole_batch) {
+            // (the whole batch again, with every frame's submit-time state: build_batch_host reads the states while it runs and keeps nothing of them)
             const std::vector<dg_view> views = s.views;
-            int rc = build_batch_host(c, s, views.data(), nullptr, (int)views.size(), s.states.empty() ? nullptr : s.states.data());
+            std::vector<Slot::RedoState> redo_states(views.size());
+            std::vector<dg_view_state> sts;
+            bool any_state = false;
+            for (size_t i = 0; i < views.size(); i++) {
+                const dg_view_state *st = s.state_for_redo(*c->scene, (int)i, redo_states[i]);
+                any_state |= st != nullptr;
+                sts.push_back(st ? *st : dg_view_state{nullptr, 0, nullptr, 0});
+            }
+            int rc = build_batch_host(c, s, views.data(), nullptr, (int)views.size(), any_state ? sts.data() : nullptr);
             if (rc) return rc;
             rc = enqueue_kernels(c, s);
             if (rc) return rc;
@@ -897,6 +934,7 @@ int dg_scene_mobj_count(const dg_scene *s) { return s ? (int)s->sc->mobjs.size()
 int dg_scene_set_mobj_state(dg_scene *s, int mobj, const char *sprite, uint8_t frame, int full_bright) {
     if (!s || mobj < 0 || (size_t)mobj >= s->sc->mobjs.size()) return set_err(DG_ERR_INVALID, "bad map object");
     MapObjectRec &m = s->sc->mobjs[(size_t)mobj];
+    s->sc->revision++;
     if (!sprite) { m.sprite_frame = -1; return DG_OK; }
     std::string err;
     int sf = s->sc->find_or_add_sprite_frame(sprite, frame, err);

@@ -438,6 +438,42 @@ def test_device_front_end_capacity_falls_back_to_host_lists(dg, scene1994, oracl
     ctx.close()
 
 
+@pytest.mark.parametrize("front_end", [2, 3], ids=["device-column-walk", "device-seg-walk"])
+def test_redone_frames_see_the_scene_as_it_was_at_submit_time(dg, oracle, wad1994, path1994, monkeypatch, front_end):
+    """A pipelined caller moves the scene on between dg_submit_views and dg_wait (gpu::sync_state: lights.rs:47-259, map_objects.rs:63-121).
+    Frames that overflow a device capacity are redone by the host walker at dg_wait time: they must get the light levels and map-object
+    states of the submission, like their batch neighbours, not the next tick's."""
+    W, H = 320, 200
+    osc = oracle.Scene(wad1994, "e1m1")
+    sc = dg.Scene(wad1994, "e1m1")
+    idx = list(range(0, 1000, 50))
+    ref = [np.frombuffer(osc.render(W, H, path1994[i]), dtype=np.uint8).reshape(H, W, 3).copy() for i in idx]
+    monkeypatch.setenv("DOOMGPU_FE_COLUMN_SLOTS", "5")
+    ctx = make_ctx(dg, sc, W, H, len(idx), slots=2, front_end=front_end)
+    monkeypatch.delenv("DOOMGPU_FE_COLUMN_SLOTS")
+    views = dg.make_views(path1994[idx])
+    ctx.submit(0, views)
+    for s_ in range(osc.sector_count()):               # the next tick: every sector dark, every map object gone
+        sc.set_sector_light(s_, 40)
+    for m in range(osc.mobj_count()):
+        sc.set_mobj_state(m, None, 0, False)
+    ctx.wait(0)
+    out = ctx.readback(0, 0, len(idx))
+    assert ctx.fallbacks()["redone_frames"] >= 1
+    for k, i in enumerate(idx):
+        assert np.array_equal(out[k], ref[k]), f"frame {i} was redone with the scene of the next tick"
+    # ... and the next submission sees the new state, redone frames included
+    for s_ in range(osc.sector_count()):
+        osc.set_sector_light(s_, 40)
+    for m in range(osc.mobj_count()):
+        osc.set_mobj_state(m, None, 0, False)
+    out = ctx.render(views)
+    for k, i in enumerate(idx):
+        assert np.array_equal(out[k], np.frombuffer(osc.render(W, H, path1994[i]), dtype=np.uint8).reshape(H, W, 3)), f"frame {i}, second tick"
+    ctx.close()
+    sc.close()
+
+
 @pytest.mark.parametrize("seed,heavy,quirks", [(1993, False, False), (1994, True, False), (1993, False, True), (1995, False, False), (1996, True, False)])
 def test_random_views_device_walk_equals_host_lists(dg, synth, campath_mod, oracle, seed, heavy, quirks):
     """2 000 random viewpoints per map (inside and outside the map, any heading, several eye heights) through both front

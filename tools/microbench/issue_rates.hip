@@ -109,6 +109,55 @@ constexpr int UNROLL = 32;    // instruction copies per iteration
 #define OP_LDSR128B(i) "ds_read_b128 v[20:23], %14\n"   /* broadcast: same address in all lanes */
 #define OP_LDSW32(i) "ds_write_b32 %13, %11\n"
 
+
+// ---- round 5 additions: which instructions share the "simple" class (two per 4.25 clocks and SIMD), packed f32, mixes ----
+#define OP_SUBU(i) "v_sub_u32 %" #i ", %11, %12\n"
+#define OP_SUBREV(i) "v_subrev_u32 %" #i ", %11, %12\n"
+#define OP_OR(i) "v_or_b32 %" #i ", %11, %12\n"
+#define OP_XOR(i) "v_xor_b32 %" #i ", %11, %12\n"
+#define OP_SUBF(i) "v_sub_f32 %" #i ", %8, %9\n"
+#define OP_FMAC(i) "v_fmac_f32 %" #i ", %8, %9\n"
+#define OP_LSHLADD(i) "v_lshl_add_u32 %" #i ", %11, 4, %12\n"
+#define OP_ADD3(i) "v_add3_u32 %" #i ", %11, %12, %11\n"
+#define OP_ASHR(i) "v_ashrrev_i32 %" #i ", 16, %11\n"
+#define OP_LSHR(i) "v_lshrrev_b32 %" #i ", 16, %11\n"
+#define OP_MAXU(i) "v_max_u32 %" #i ", %11, %12\n"
+#define OP_MINF(i) "v_min_f32 %" #i ", %8, %9\n"
+#define OP_MULU24(i) "v_mul_u32_u24 %" #i ", %11, %12\n"
+#define OP_MADI24(i) "v_mad_i32_i24 %" #i ", %11, %12, %11\n"
+#define OP_FLOOR(i) "v_floor_f32 %" #i ", %8\n"
+#define OP_CVTU(i) "v_cvt_u32_f32 %" #i ", %8\n"
+#define OP_CVTFU(i) "v_cvt_f32_u32 %" #i ", %11\n"
+#define OP_CVTUB0(i) "v_cvt_f32_ubyte0 %" #i ", %11\n"
+#define OP_SDWA_SUB(i) "v_sub_u32_sdwa %" #i ", %11, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+#define OP_SDWA_ADD(i) "v_add_u32_sdwa %" #i ", %11, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n"
+#define OP_SDWA_CVTF(i) "v_cvt_f32_i32_sdwa %" #i ", sext(%11) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n"
+#define OP_CMPF(i) "v_cmp_gt_f32 vcc, %8, %9\n"
+#define OP_ADDCO(i) "v_add_co_u32 %" #i ", vcc, %11, %12\n"
+#define OP_MOVS(i) "v_mov_b32 %" #i ", s46\n"
+#define OP_ADDS(i) "v_add_u32 %" #i ", s46, %11\n"
+#define OP_MULS(i) "v_mul_f32 %" #i ", s46, %8\n"
+#define OP_FMAS(i) "v_fma_f32 %" #i ", %8, s46, %9\n"
+#define OP_ADDLIT(i) "v_add_u32 %" #i ", 0x12345, %11\n"
+#define OP_MBCNT(i) "v_mbcnt_lo_u32_b32 %" #i ", -1, 0\n"
+#define OP_BPERM(i) "ds_bpermute_b32 %" #i ", %13, %11\n"
+// packed f32 (register pairs named explicitly)
+#define P8(op) op("20:21") op("22:23") op("24:25") op("26:27") op("28:29") op("30:31") op("32:33") op("34:35")
+#define BODY32P(op) P8(op) P8(op) P8(op) P8(op)
+#define PKMUL(d) "v_pk_mul_f32 v[" d "], v[40:41], v[42:43]\n"
+#define PKFMA(d) "v_pk_fma_f32 v[" d "], v[40:41], v[42:43], v[44:45]\n"
+#define PKADD(d) "v_pk_add_f32 v[" d "], v[40:41], v[42:43]\n"
+#define PKMULCVT(d) "v_pk_mul_f32 v[" d "], v[40:41], v[42:43]\n v_cvt_i32_f32 v46, v40\n"
+#define PKMULFMA(d) "v_pk_mul_f32 v[" d "], v[40:41], v[42:43]\n v_fma_f32 v46, v40, v41, v42\n"
+#define PKCLOB "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v40", "v41", "v42", "v43", "v44", "v45", "v46"
+// mixes: how many simple instructions ride along with one complex one?
+#define OP_MIX21(i) "v_fma_f32 %" #i ", %8, %9, %10\n v_mul_f32 %" #i ", %8, %9\n v_cvt_i32_f32 %" #i ", %8\n"
+#define OP_MIX12(i) "v_fma_f32 %" #i ", %8, %9, %10\n v_cvt_i32_f32 %" #i ", %8\n v_med3_i32 %" #i ", %11, %12, %11\n"
+#define OP_MIXRL(i) "v_readlane_b32 s4" #i ", %11, 5\n v_fma_f32 %" #i ", %8, %9, %10\n"
+#define OP_MIXCVCV(i) "v_cvt_i32_f32 %" #i ", %8\n v_cndmask_b32 %" #i ", %11, %12, s[44:45]\n"
+#define OP_MIXLDS(i) "ds_read_b32 %" #i ", %13\n v_cvt_i32_f32 v46, %8\n v_fma_f32 v47, %8, %9, %10\n"
+#define OP_SNOP1(i) "v_fma_f32 %" #i ", %8, %9, %10\n s_nop 1\n"
+
 KERNEL(fma, BODY32(OP_FMA))
 KERNEL(mul, BODY32(OP_MUL))
 KERNEL(add, BODY32(OP_ADD))
@@ -164,6 +213,48 @@ KERNEL(ldsr32, BODY32(OP_LDSR32) "s_waitcnt lgkmcnt(0)\n")
 KERNEL(ldsr128b, BODY32(OP_LDSR128B) "s_waitcnt lgkmcnt(0)\n", "v20", "v21", "v22", "v23")
 KERNEL(ldsw32, BODY32(OP_LDSW32) "s_waitcnt lgkmcnt(0)\n")
 
+KERNEL(subu, BODY32(OP_SUBU))
+KERNEL(subrev, BODY32(OP_SUBREV))
+KERNEL(or, BODY32(OP_OR))
+KERNEL(xor, BODY32(OP_XOR))
+KERNEL(subf, BODY32(OP_SUBF))
+KERNEL(fmac, BODY32(OP_FMAC))
+KERNEL(lshladd, BODY32(OP_LSHLADD))
+KERNEL(add3, BODY32(OP_ADD3))
+KERNEL(ashr, BODY32(OP_ASHR))
+KERNEL(lshr, BODY32(OP_LSHR))
+KERNEL(maxu, BODY32(OP_MAXU))
+KERNEL(minf, BODY32(OP_MINF))
+KERNEL(mulu24, BODY32(OP_MULU24))
+KERNEL(madi24, BODY32(OP_MADI24))
+KERNEL(floor, BODY32(OP_FLOOR))
+KERNEL(cvtu, BODY32(OP_CVTU))
+KERNEL(cvtfu, BODY32(OP_CVTFU))
+KERNEL(cvtub0, BODY32(OP_CVTUB0))
+KERNEL(sdwa_sub, BODY32(OP_SDWA_SUB))
+KERNEL(sdwa_add, BODY32(OP_SDWA_ADD))
+KERNEL(sdwa_cvtf, BODY32(OP_SDWA_CVTF))
+KERNEL(cmpf, BODY32(OP_CMPF))
+KERNEL(addco, BODY32(OP_ADDCO))
+KERNEL(movs, BODY32(OP_MOVS))
+KERNEL(adds, BODY32(OP_ADDS))
+KERNEL(muls, BODY32(OP_MULS))
+KERNEL(fmas, BODY32(OP_FMAS))
+KERNEL(addlit, BODY32(OP_ADDLIT))
+KERNEL(mbcnt, BODY32(OP_MBCNT))
+KERNEL(bperm, BODY32(OP_BPERM) "s_waitcnt lgkmcnt(0)\n")
+KERNEL(pkmul, BODY32P(PKMUL), PKCLOB)
+KERNEL(pkfma, BODY32P(PKFMA), PKCLOB)
+KERNEL(pkadd, BODY32P(PKADD), PKCLOB)
+KERNEL(pkmulcvt, BODY32P(PKMULCVT), PKCLOB)
+KERNEL(pkmulfma, BODY32P(PKMULFMA), PKCLOB)
+KERNEL(mix21, BODY32(OP_MIX21))
+KERNEL(mix12, BODY32(OP_MIX12))
+KERNEL(mixrl, BODY32(OP_MIXRL))
+KERNEL(mixcvcv, BODY32(OP_MIXCVCV))
+KERNEL(mixlds, BODY32(OP_MIXLDS) "s_waitcnt lgkmcnt(0)\n", "v46", "v47")
+KERNEL(snop1, BODY32(OP_SNOP1))
+
 
 __global__ __launch_bounds__(256) void k_clock(unsigned long long *out, const float *in) {
     float a = in[threadIdx.x & 63], b = in[64 + (threadIdx.x & 63)], c = in[128 + (threadIdx.x & 63)];
@@ -194,6 +285,17 @@ static const Entry entries[] = {
     E(br_nt, 2, "s_cmp + s_cbranch_scc1 never taken, per instruction"), E(br_t, 2, "s_branch taken (+ skipped s_nop), per taken branch pair"),
     E(brv_nt, 1, "s_cbranch_vccz never taken"), E(brexecz, 1, "s_cbranch_execz never taken"),
     E(walk, 6, "span-walk skeleton: ff1, lshl, andn2, v_readlane, bitcmp, cbranch (not taken), per instruction"),
+    E(subu, 1, "v_sub_u32"), E(subrev, 1, "v_subrev_u32"), E(or, 1, "v_or_b32"), E(xor, 1, "v_xor_b32"), E(subf, 1, "v_sub_f32"), E(fmac, 1, "v_fmac_f32"),
+    E(lshladd, 1, "v_lshl_add_u32"), E(add3, 1, "v_add3_u32"), E(ashr, 1, "v_ashrrev_i32"), E(lshr, 1, "v_lshrrev_b32"), E(maxu, 1, "v_max_u32"), E(minf, 1, "v_min_f32"),
+    E(mulu24, 1, "v_mul_u32_u24"), E(madi24, 1, "v_mad_i32_i24"), E(floor, 1, "v_floor_f32"), E(cvtu, 1, "v_cvt_u32_f32"), E(cvtfu, 1, "v_cvt_f32_u32"), E(cvtub0, 1, "v_cvt_f32_ubyte0"),
+    E(sdwa_sub, 1, "v_sub_u32_sdwa src1 WORD_0"), E(sdwa_add, 1, "v_add_u32_sdwa src0 WORD_1"), E(sdwa_cvtf, 1, "v_cvt_f32_i32_sdwa sext WORD_0"), E(cmpf, 1, "v_cmp_gt_f32 vcc"),
+    E(addco, 1, "v_add_co_u32 vcc"), E(movs, 1, "v_mov_b32 v, s"), E(adds, 1, "v_add_u32 v, s, v"), E(muls, 1, "v_mul_f32 v, s, v"), E(fmas, 1, "v_fma_f32 v, v, s, v"),
+    E(addlit, 1, "v_add_u32 v, literal, v"), E(mbcnt, 1, "v_mbcnt_lo_u32_b32"), E(bperm, 1, "ds_bpermute_b32"),
+    E(pkmul, 1, "v_pk_mul_f32 (per instruction = 2 multiplies per lane)"), E(pkfma, 1, "v_pk_fma_f32"), E(pkadd, 1, "v_pk_add_f32"),
+    E(pkmulcvt, 2, "v_pk_mul_f32 + v_cvt_i32_f32 alternating, per instr"), E(pkmulfma, 2, "v_pk_mul_f32 + v_fma_f32 alternating, per instr"),
+    E(mix21, 3, "v_fma + v_mul + v_cvt_i32_f32 (2 simple : 1 complex), per instr"), E(mix12, 3, "v_fma + v_cvt + v_med3 (1 simple : 2 complex), per instr"),
+    E(mixrl, 2, "v_readlane + v_fma alternating, per instr"), E(mixcvcv, 2, "v_cvt + v_cndmask(sgpr) alternating (2 complex), per instr"),
+    E(mixlds, 3, "ds_read_b32 + v_cvt + v_fma, per instr"), E(snop1, 2, "v_fma + s_nop 1, per instr"),
     E(ldsr32, 1, "ds_read_b32 (lane-linear)"), E(ldsr128b, 1, "ds_read_b128 broadcast address"), E(ldsw32, 1, "ds_write_b32 (lane-linear)"),
 };
 

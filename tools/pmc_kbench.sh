@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes over tests/manual/gpu_kbench.py (one rocprofv3 run per counter set): tools/pmc_kbench.sh <tag> "<counters set 1>" "<set 2>" ...
 TAG=${1:-p}; shift
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r04/pmc_$TAG
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${ROUND:-r05}/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0

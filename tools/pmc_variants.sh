@@ -5,7 +5,7 @@
 SET=$1; shift
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
-  OUT=$GRAFT_REPO_ROOT/gpurun_out/r04/pmcv_$v; mkdir -p $OUT
+  OUT=$GRAFT_REPO_ROOT/gpurun_out/${ROUND:-r05}/pmcv_$v; mkdir -p $OUT
   if [ "$v" != base ]; then export DOOMGPU_LIB=$GRAFT_REPO_ROOT/build/variants/libdoomgpu_$v.so; else unset DOOMGPU_LIB; fi
   KBENCH_SIZES=${KBENCH_SIZES:-1280x800x250} rocprofv3 --pmc $SET --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tests/manual/gpu_kbench.py > $OUT/log.txt 2>&1 || echo "variant $v: rocprofv3 failed"
   echo "== $v"; python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT | grep raster_tiles
