@@ -95,83 +95,152 @@ __device__ __forceinline__ uint32_t shade_f(const float4 c, float factor) {
 }
 
 // ---- spans as the tile kernel keeps them in LDS: the DevRSpan words as dg_setup_spans / dg_fe_scatter wrote them (lists_dev.h) except
-// word 0, which is replaced (the row range lives in lw0); record 0 of the staging area is the "nothing" record that an unowned row
+// words 0 and 5 of a wall (the row range lives in lw0); record 0 of the staging area is the "nothing" record that an unowned row
 // points at (a sky span with factor 0 -> 0,0,0), records 1.. are the tile's spans ----------------------------------------------
-//   WALL  a.x = hm (< 0x4000_0000): h - 1 for a power-of-two bitmap height, else 0x8000 | h;  a.y = d;  a.z = start of the texture
-//         column (column-major planes);  a.w = light factor;  b.x = uy1;  b.y = top_y | off_y << 16;  b.z = h as f32, NEGATED when h
-//         is not a power of two;  b.w = prepared reciprocal of d
+//   WALL  a.x = off_y << 16 | hm:  hm = h - 1 for a power-of-two bitmap height, else 0x8000 | h;  a.y = d;  a.z = start of the texture
+//         column (column-major planes);  a.w = light factor;  b.x = uy1;  b.y = top_y AS F32;  b.z = h as f32, NEGATED when h is not a
+//         power of two (|b.z| >= 1 is what says "wall");  b.w = prepared reciprocal of d
 //   FLAT  a.x = 0x4000_0000 | ..;  a.y = wz * vx;  a.z = offset of the flat from texel_idx (flats sit behind the texel plane);
-//         b.x = gwz;  b.y = light_level / 255;  b.z = fast-divide-ok << 8
+//         b.x = gwz;  b.y = light_level / 255;  b.z = fast-divide-ok << 8 (as f32: below 1)
 //   SKY   a.x = 0x8000_0000 | .. (negative as i32);  a.z = offset of the sky texture column (0 when the reference would index outside
-//         the bitmap);  a.w = 1.0f (0.0f in that case)
+//         the bitmap);  a.w = 1.0f (0.0f in that case);  b.z = 0
+//
+// Issue cost is what this kernel is bound by, and on gfx950 it has two prices (tools/microbench/issue_rates.hip,
+// profiles/r05_issue_model.md): a SIMD issues ONE vector instruction per ~4.25 clocks, plus a second one in the same slot if that one is
+// of the simple class — v_fma / v_mul / v_add / v_sub_f32, v_mov, v_add / v_sub_u32, v_and / v_or / v_xor, right shifts — with VGPR,
+// inline-constant or literal operands only.  Conversions, compares, selects, left shifts, v_med3, v_readlane, SDWA forms and ANY
+// instruction with a scalar-register operand take a slot of their own.  Hence, below: rows and frame constants live in VGPRs as f32
+// (a row difference is a v_sub_f32, not an SDWA subtract + convert), records reach the lanes as LDS broadcasts into VGPRs, and the
+// plain mappers contain one conversion each where the reference has an `as i16`.
 struct RowConsts {              // per screen row = per lane, fixed for the tile (dg_row_table)
     int y;
-    float vy, r_vy;             // CFY - y (visplanes.rs:109) and its prepared reciprocal
-    uint32_t row_fast;          // 0x100 unless vy == 0 (that row takes the plain divide: x / 0)
-    uint32_t sky_row;           // sky texture row, 0 when outside the bitmap
-    float sky_fac;              // 1.0f, 0.0f when outside the bitmap
+    float yf;                   // y as f32: (y - top_y) as f32 == yf - top_y as f32 (both integers below 2^15: the difference is exact)
+    float vy, r_vy;             // CFY - y (visplanes.rs:109) and its prepared reciprocal; vy == 0 on the horizon row (that row takes the plain divide: x / 0)
+    uint32_t sky;               // sky texture row (0 when outside the bitmap) | bits of the sky factor (1.0f, 0.0f when outside): row < 2^16
+};
+__device__ __forceinline__ uint32_t sky_row_of(const RowConsts &R) { return R.sky & 0xffffu; }
+__device__ __forceinline__ float sky_fac_of(const RowConsts &R) { return bits_f32(R.sky & 0xffff0000u); }
+struct FrameVgprs {             // frame constants the flat mapper multiplies / adds per pixel, copied to VGPRs once per strip (a scalar operand halves the issue rate)
+    float cos_a, sin_a;
+    uint32_t pos_pk;            // (pos_x & 63) | (pos_y & 63) << 16
 };
 
-// Word 0 of a staged span from the record's words 0 and 6: walls get their height mask, the other kinds keep their kind bits.
-__device__ __forceinline__ uint32_t staged_w0(uint32_t w0, uint32_t w6) {
-    const float hs = bits_f32(w6);
+// Words 0 and 5 of a staged wall from the record's words 0, 5 and 6; the other kinds keep theirs.
+__device__ __forceinline__ void stage_words(uint4 &a, uint4 &b) {
+    if (w0_kind(a.x) != SPAN_WALL) return;
+    const float hs = bits_f32(b.z);
     const uint32_t h = (uint32_t)__builtin_fabsf(hs);
-    return w0_kind(w0) == SPAN_WALL ? (hs > 0.0f ? h - 1u : 0x8000u | h) : w0;
+    a.x = (hs > 0.0f ? h - 1u : 0x8000u | h) | (b.y & 0xffff0000u);
+    b.y = f32_bits((float)lo_i16(b.y));
 }
+__device__ __forceinline__ bool staged_is_wall(const uint4 b) { return __builtin_fabsf(bits_f32(b.z)) >= 1.0f; }
 
-// Texel offset of one wall pixel (bitmap_render.rs:256-263) from the staged words.  A wave in which some lane's bitmap height is not
-// a power of two takes the general modulus for every lane (it is right for all heights).
+// Texel offset of one wall pixel (bitmap_render.rs:256-263) from the staged words, any bitmap height, any extent.  A wave in which some
+// lane's bitmap height is not a power of two takes the general modulus for every lane (it is right for all heights).
 // `lanes`: the lanes whose span is a wall (the others compute garbage that is not used).
-__device__ __forceinline__ uint32_t wall_offset_tile(const uint4 a, const uint4 b, int y, unsigned long long lanes) {
+__device__ __forceinline__ uint32_t wall_offset_tile(const uint4 a, const uint4 b, const RowConsts &R, unsigned long long lanes) {
     const float d = bits_f32(a.y), hs = bits_f32(b.z), hf = __builtin_fabsf(hs);
-    const int32_t top_y = lo_i16(b.y), off_y = hi_i16(b.y);
-    const float ay = div_prepared_nofix((float)(y - top_y), d, bits_f32(b.w));   // d == 0: uy1 is NaN and so is the sum, whatever ay is
+    const float ay = div_prepared_nofix(R.yf - bits_f32(b.y), d, bits_f32(b.w));   // d == 0: uy1 is NaN and so is the sum, whatever ay is
     const int32_t ty = f32_as_i16(hf + ay * bits_f32(b.x));
-    if ((__builtin_amdgcn_ballot_w64(hs < 0.0f) & lanes) == 0ull) return a.z + ((uint32_t)(ty + off_y) & a.x);   // the wrap of the i16 add is above the mask
-    return a.z + (uint32_t)floor_mod_fast(wrap_i16(ty + off_y), (int32_t)hf, 0, approx_rcp(hf));
+    const uint32_t t = (uint32_t)ty + (a.x >> 16);                                 // + off_y: the low 16 bits are the wrapping i16 sum
+    if ((__builtin_amdgcn_ballot_w64(hs < 0.0f) & lanes) == 0ull) return a.z + (t & a.x & 0x7fffu);   // the wrap of the i16 add is above the mask
+    return a.z + (uint32_t)floor_mod_fast(wrap_i16((int32_t)t), (int32_t)hf, 0, approx_rcp(hf));
 }
 
 // Texel offset and light factor of one floor / ceiling pixel (visplanes.rs:108-126); see flat_texel_offset (raster_core.h) for the
 // scalar form.  The factor is left unclamped: `as u8` of (colour x negative) is 0, the same as with the reference's
 // `if factor < 0.0 { factor = 0.0 }`, and lightf - z / 4096 as one fma is exact because z / 4096 is.
-__device__ __forceinline__ uint32_t flat_offset_tile(const DevFrame &f, const uint4 a, const uint4 b, const RowConsts &R, unsigned long long lanes, float &factor) {
+// After the two quotients, the same arithmetic for every flat pixel: the rotation with the frame's cos / sin from VGPRs, ONE
+// v_cvt_pk_i16_i32 that does both `as i16` saturations of (rx, ry) and packs them (NaN has become 0 in v_cvt_i32_f32 before), position
+// added and `& 63` on both halves at once (both addends are masked first, so the sum of two 6-bit values stays inside its half and the
+// low six bits are those of the wrapping i16 sum).  zf = wx as i16 as f32, from the caller.
+__device__ __forceinline__ uint32_t flat_tail(const FrameVgprs &T, const uint4 a, const uint4 b, float wx, float wy, float zf, float &factor) {
+    const float rx = wx * T.cos_a - wy * T.sin_a;
+    const float ry = wy * T.cos_a + wx * T.sin_a;
+    const int32_t ix = f32_as_i32(rx), iy = f32_as_i32(ry);
+    uint32_t pk;
+    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(pk) : "v"(ix), "v"(iy));
+    const uint32_t t = ((pk & 0x003f003fu) + T.pos_pk) & 0x003f003fu;     // tx | ty << 16
+    factor = __builtin_fmaf(-zf, 1.0f / 4096.0f, bits_f32(b.y));
+    return a.z + (((t >> 10) & 0xfc0u) | (t & 0x3fu));
+}
+__device__ __forceinline__ uint32_t flat_offset_tile(const FrameVgprs &T, const uint4 a, const uint4 b, const RowConsts &R, unsigned long long lanes, float &factor) {
     float wx, wy;
-    if ((__builtin_amdgcn_ballot_w64((b.z & R.row_fast) == 0u) & lanes) == 0ull) {
+    if ((__builtin_amdgcn_ballot_w64((b.z & 0x100u) == 0u || R.vy == 0.0f) & lanes) == 0ull) {
         wx = div_prepared_nofix(bits_f32(b.x), R.vy, R.r_vy);
         wy = div_prepared_nofix(bits_f32(a.y), R.vy, R.r_vy);
     } else {                                      // a numerator outside the verified domain or the vy == 0 row somewhere in the wave: plain divides
         wx = bits_f32(b.x) / R.vy;
         wy = bits_f32(a.y) / R.vy;
     }
-    const float rx = wx * f.cos_a - wy * f.sin_a;
-    const float ry = wy * f.cos_a + wx * f.sin_a;
-    const int32_t tx = (f32_as_i16(rx) + f.pos_x_i16) & 63;
-    const int32_t ty = (f32_as_i16(ry) + f.pos_y_i16) & 63;
-    factor = __builtin_fmaf(-(float)f32_as_i16(wx), 1.0f / 4096.0f, bits_f32(b.y));
-    return a.z + (uint32_t)(ty * 64 + tx);
+    return flat_tail(T, a, b, wx, wy, (float)f32_as_i16(wx), factor);          // (wx may be NaN here: 0 / 0 on the horizon row)
 }
 
-// The same two mappers for a column whose 64 rows all belong to ONE plain span (w0_plain): a, b are that span's staged words, the same
-// in every lane, and nothing has to be voted on or selected — the arithmetic per row is exactly the general form's.
-__device__ __forceinline__ uint32_t wall_offset_plain(const uint4 a, const uint4 b, int y) {
-    const float ay = div_prepared_nofix((float)(y - lo_i16(b.y)), bits_f32(a.y), bits_f32(b.w));
-    const int32_t ty = f32_as_i16(bits_f32(b.z) + ay * bits_f32(b.x));
-    return a.z + ((uint32_t)(ty + hi_i16(b.y)) & a.x);
+// The same two mappers for a span that is plain (w0_plain) — a, b are its staged words, the same in every lane (an LDS broadcast), and
+// nothing has to be voted on.  Written out instruction by instruction: hipcc fuses the shifts, masks and adds below into SDWA /
+// three-operand forms (fewer instructions, but each of them takes an issue slot of its own: see the note on the two prices above).
+// Plain wall: the bitmap height is a power of two AND h + ay * uy1 stays inside i16 on the span's rows (resolve_wall_span checks both
+// ends; the expression is monotonic in y), so `as i16` is the bare conversion: 11 simple instructions + 1 conversion.
+__device__ __forceinline__ uint32_t wall_offset_plain(const uint4 a, const uint4 b, const RowConsts &R) {
+    uint32_t o, t0, t1;
+    asm("v_sub_f32 %1, %3, %8\n\t"            // n = y - top_y                                   (bitmap_render.rs:256)
+        "v_mul_f32 %2, %1, %10\n\t"           // q = n * (1 / d)
+        "v_fma_f32 %1, -%5, %2, %1\n\t"       // e = n - d * q
+        "v_fmac_f32 %2, %1, %10\n\t"          // ay = q + e * (1 / d): the correctly rounded n / d (div_prepared_nofix)
+        "v_mul_f32 %2, %2, %7\n\t"            // ay * uy1
+        "v_add_f32 %2, %2, %9\n\t"            // h + ay * uy1                                    (:257)
+        "v_cvt_i32_f32 %2, %2\n\t"            // as i16 (in range)
+        "v_lshrrev_b32 %1, 16, %4\n\t"        // off_y
+        "v_add_u32 %2, %2, %1\n\t"            // ty + off_y (the wrap of the i16 add is above the mask)
+        "v_and_b32 %1, 0xffff, %4\n\t"        // h - 1
+        "v_and_b32 %2, %2, %1\n\t"            // % h                                             (:259-263)
+        "v_add_u32 %0, %2, %6"                  // + start of the texture column
+        : "=v"(o), "=&v"(t0), "=&v"(t1)
+        : "v"(R.yf), "v"(a.x), "v"(a.y), "v"(a.z), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+    return o;
 }
-__device__ __forceinline__ uint32_t flat_offset_plain(const DevFrame &f, const uint4 a, const uint4 b, const RowConsts &R, float &factor) {
-    const float wx = div_prepared_nofix(bits_f32(b.x), R.vy, R.r_vy);
-    const float wy = div_prepared_nofix(bits_f32(a.y), R.vy, R.r_vy);
-    const float rx = wx * f.cos_a - wy * f.sin_a;
-    const float ry = wy * f.cos_a + wx * f.sin_a;
-    const int32_t tx = (f32_as_i16(rx) + f.pos_x_i16) & 63;
-    const int32_t ty = (f32_as_i16(ry) + f.pos_y_i16) & 63;
-    factor = __builtin_fmaf(-(float)f32_as_i16(wx), 1.0f / 4096.0f, bits_f32(b.y));
-    return a.z + (uint32_t)(ty * 64 + tx);
+// Plain floor / ceiling: numerators inside the prepared divide's domain, vy != 0 and light_level / 255 < 7 (resolve_flat_span), so wx is
+// finite, `wx as i16 as f32` is trunc(wx) clamped in f32, and its upper clamp cannot matter: wx >= 32767 makes the factor negative
+// (below light - 7.99) and the pixel black either way.  20 simple instructions + 5 of the other kind.
+__device__ __forceinline__ uint32_t flat_offset_plain(const FrameVgprs &T, const uint4 a, const uint4 b, const RowConsts &R, float &factor) {
+    uint32_t o, t0, t1, t2, t3;
+    float fac = bits_f32(b.y);
+    asm("v_mul_f32 %1, %6, %10\n\t"           // wx = gwz / vy                                   (visplanes.rs:113)
+        "v_fma_f32 %2, -%9, %1, %6\n\t"
+        "v_fmac_f32 %1, %2, %10\n\t"
+        "v_mul_f32 %2, %7, %10\n\t"           // wy = wz * vx / vy                               (:114)
+        "v_fma_f32 %3, -%9, %2, %7\n\t"
+        "v_fmac_f32 %2, %3, %10\n\t"
+        "v_mul_f32 %3, %1, %11\n\t"           // rx = wx * cos - wy * sin                        (:116)
+        "v_mul_f32 %4, %2, %12\n\t"
+        "v_sub_f32 %3, %3, %4\n\t"
+        "v_mul_f32 %4, %2, %11\n\t"           // ry = wy * cos + wx * sin                        (:117)
+        "v_mul_f32 %2, %1, %12\n\t"
+        "v_add_f32 %4, %4, %2\n\t"
+        "v_cvt_i32_f32 %3, %3\n\t"
+        "v_cvt_i32_f32 %4, %4\n\t"
+        "v_cvt_pk_i16_i32 %3, %3, %4\n\t"     // rx as i16 | ry as i16 << 16
+        "v_trunc_f32 %1, %1\n\t"              // z = wx as i16 as f32                            (:123-124)
+        "v_max_f32 %1, 0xc7000000, %1\n\t"
+        "v_fmac_f32 %5, 0xb9800000, %1\n\t"   // factor = light / 255 - z / 4096                 (bitmap_render.rs:198-201)
+        "v_and_b32 %3, 0x3f003f, %3\n\t"
+        "v_add_u32 %3, %3, %13\n\t"           // + position, both halves                         (visplanes.rs:119-120)
+        "v_lshrrev_b32 %4, 10, %3\n\t"
+        "v_and_b32 %4, 0xfc0, %4\n\t"         // ty * 64
+        "v_and_b32 %3, 63, %3\n\t"            // tx
+        "v_or_b32 %3, %3, %4\n\t"
+        "v_add_u32 %0, %3, %8"                  // + offset of the flat
+        : "=v"(o), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "+v"(fac)
+        : "v"(b.x), "v"(a.y), "v"(a.z), "v"(R.vy), "v"(R.r_vy), "v"(T.cos_a), "v"(T.sin_a), "v"(T.pos_pk));
+    factor = fac;
+    return o;
 }
 // Spans are addressed by their BYTE offset in the staging area (32 x record number): the owner of a row is the largest offset
-// among the opaque spans that cover it, 0 = the "nothing" record.
+// among the opaque spans that cover it, 0 = the "nothing" record.  The five low bits of such an offset are free and carry what a
+// wave-uniform loop wants to branch on without looking at the record: the span's kind (bits 0-1) and its plain flag (bit 2).
+constexpr uint32_t OFF_KIND = 3u, OFF_PLAIN = 4u, OFF_ADDR = ~31u;
 //
-// Both span loops below are wave-uniform walks over a 64-bit mask whose bit i says "the span held by lane i is to be looked at".
+// The span loops below are wave-uniform walks over a 64-bit mask whose bit i says "the span held by lane i is to be looked at".
 // Each lane holds its span's first row, row count - 1 and staging offset in three registers, so a step is three v_readlane and
 // no scalar unpacking: find-first-bit, clear it, compare, branch are the only scalar instructions.
 __device__ __forceinline__ int take_lowest(unsigned long long &m) {
@@ -188,30 +257,69 @@ __device__ __forceinline__ uint32_t owner_loop(unsigned long long m, uint32_t v_
 }
 
 __device__ __forceinline__ const uint4 *span_at(const uint4 *staged, uint32_t off) {
-    return reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(staged) + off);
+    return reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(staged) + (off & OFF_ADDR));
+}
+// Both halves of the staged record at LDS address `addr`, the same address in every lane (an LDS broadcast): two 16-byte reads off one
+// address register, waited for here (the record's words are what the next instructions need).
+__device__ __forceinline__ void lds_record(uint32_t addr, uint4 &a, uint4 &b) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(addr));   // (no "memory": the compiler would wait for the column's gather in flight first)
+}
+__device__ __forceinline__ uint32_t lds_address(const void *p) { return (uint32_t)(uintptr_t)p; }   // the low half of a flat LDS address is the LDS offset
+
+// One span's (texel offset, light factor) for all 64 rows from its broadcast record; `flags` = the low bits of its staging offset.
+template <bool FLATS>           // (a possibly-transparent span is never a floor / ceiling: its loop leaves that mapper out)
+__device__ __forceinline__ uint32_t span_texel(const FrameVgprs &T, const uint4 a, const uint4 b, uint32_t flags, const RowConsts &R, bool tile_vy0, float &factor) {
+    const uint32_t kind = flags & OFF_KIND;
+    if (kind == SPAN_WALL) {
+        factor = bits_f32(a.w);
+        return (flags & OFF_PLAIN) ? wall_offset_plain(a, b, R) : wall_offset_tile(a, b, R, ~0ull);
+    }
+    if (FLATS && kind == SPAN_FLAT) return ((flags & OFF_PLAIN) && !tile_vy0) ? flat_offset_plain(T, a, b, R, factor) : flat_offset_tile(T, a, b, R, ~0ull, factor);
+    factor = bits_f32(a.w) * sky_fac_of(R);       // sky: plain lookup, no lighting (x 1.0 is exact); 0.0 where the reference would index outside the bitmap
+    return a.z + sky_row_of(R);
 }
 
-// Possibly-transparent spans in draw order (m_wall: which of them are bitmap columns; the others are sky-with-holes spans): where such a
-// span shows — its texel is opaque and no later opaque span owns the row — its (texel, light factor) replace the row's; the pixel is
+// Stage 1 of a column that has no sole plain owner: its opaque spans that touch the tile's rows, in draw order, each evaluated with ITS
+// mapper on all 64 rows from one broadcast record and selected into the rows it covers — a later span overwrites an earlier one like
+// the reference's Pixels::set.  No owner search followed by a per-row record fetch and a vote on kinds: a chunk with a ceiling and a
+// wall costs one flat and one wall evaluation of the short kind, and both read their parameters as broadcasts.  Rows nothing covers
+// keep texel 0 with factor 0 -> 0,0,0.
+__device__ __forceinline__ uint32_t span_loop(const FrameVgprs &T, uint32_t lspans_addr, unsigned long long m, uint32_t v_lo, uint32_t v_rg, uint32_t v_off,
+                                              const RowConsts &R, bool tile_vy0, float &factor_out, uint32_t &winner_out) {
+    uint32_t o = 0, winner = 0;
+    float factor = 0.0f;
+    while (m) {
+        const int j = take_lowest(m);
+        const uint32_t off = bcast(v_off, j);
+        uint4 a, b;
+        lds_record(lspans_addr + (off & OFF_ADDR), a, b);
+        float sf;
+        const uint32_t so = span_texel<true>(T, a, b, off, R, tile_vy0, sf);
+        const bool in = ((uint32_t)R.y - bcast(v_lo, j)) <= bcast(v_rg, j);
+        o = in ? so : o;
+        factor = in ? sf : factor;
+        winner = in ? off : winner;
+    }
+    factor_out = factor;
+    winner_out = winner;
+    return o;
+}
+
+// Possibly-transparent spans in draw order (bitmap columns — masked walls, sprites — and sky-with-holes spans): where such a span
+// shows — its texel is opaque and no later opaque span owns the row — its (texel, light factor) replace the row's; the pixel is
 // shaded once, afterwards.  (Fetching two spans' texels per trip without exec masking was measured: slower at 1280x800 — most columns
 // meet one such span — and no faster at 320x200.)
-__device__ __forceinline__ void overlay_loop(const RasterParams &P, const uint4 *staged, unsigned long long m, unsigned long long m_wall,
+__device__ __forceinline__ void overlay_loop(const RasterParams &P, const FrameVgprs &T, uint32_t lspans_addr, unsigned long long m,
                                              uint32_t v_lo, uint32_t v_rg, uint32_t v_off, const RowConsts &R, uint32_t winner, uint32_t &tex_io, float &factor_io) {
     while (m) {
         const int j = take_lowest(m);
         const uint32_t off = bcast(v_off, j);
         if (((uint32_t)R.y - bcast(v_lo, j)) <= bcast(v_rg, j) && off > winner) {
-            const uint4 a = span_at(staged, off)[0], b = span_at(staged, off)[1];   // same address in every lane: LDS broadcast
-            const bool wall = (m_wall >> j) & 1ull;                                   // wave-uniform
-            uint32_t o;
+            uint4 a, b;
+            lds_record(lspans_addr + (off & OFF_ADDR), a, b);
+            const bool wall = (off & OFF_KIND) == SPAN_WALL;                        // wave-uniform
             float factor;
-            if (wall) {
-                o = wall_offset_tile(a, b, R.y, ~0ull);
-                factor = bits_f32(a.w);
-            } else {                                          // sky bitmap with holes: plain lookup, no lighting (x 1.0 is exact)
-                o = a.z + R.sky_row;
-                factor = bits_f32(a.w) * R.sky_fac;           // 0.0 where the reference would index outside the bitmap: nothing drawn
-            }
+            const uint32_t o = span_texel<false>(T, a, b, off, R, false, factor);
             uint32_t tex, opq;
             gather_u8x2(P.scene.texel_idx, P.scene.texel_opq, o, tex, opq);
             const bool shows = opq != 0u && (wall || factor != 0.0f);
@@ -221,25 +329,25 @@ __device__ __forceinline__ void overlay_loop(const RasterParams &P, const uint4 
     }
 }
 
-// Every row evaluates its owner.  The scalar instruction stream is what this kernel is short of (profiles/r02_raster_tiles.md), so
-// there is no divergent control flow here: a kind that some row of the wave needs is computed by ALL 64 lanes (on words of another
-// kind the arithmetic is garbage but harmless) and each lane then selects — two uniform branches and a few selects instead of
-// nested exec-mask regions.  The gather comes after the select, so every address is that of the lane's real owner.
-__device__ __forceinline__ uint32_t owner_texel(const DevFrame &fr, const uint4 *staged, uint32_t winner, const RowConsts &R, float &factor_out) {
+// Every row evaluates the owner it was given (columns with more than eight spans, and the eight-rows-per-pass form of a tile with few
+// live rows): per-lane records.  There is no divergent control flow here: a kind that some row of the wave needs is computed by ALL 64
+// lanes (on words of another kind the arithmetic is garbage but harmless) and each lane then selects — two uniform branches and a few
+// selects instead of nested exec-mask regions.  The gather comes after the select, so every address is that of the lane's real owner.
+__device__ __forceinline__ uint32_t owner_texel(const FrameVgprs &T, const uint4 *staged, uint32_t winner, const RowConsts &R, float &factor_out) {
     const uint4 a = span_at(staged, winner)[0], b = span_at(staged, winner)[1];
-    const bool is_wall = a.x < 0x40000000u, is_sky = (int32_t)a.x < 0;
+    const bool is_wall = staged_is_wall(b), is_sky = !is_wall && (int32_t)a.x < 0;
     const unsigned long long m_wall = __builtin_amdgcn_ballot_w64(is_wall), m_sky = __builtin_amdgcn_ballot_w64(is_sky);
-    uint32_t o = a.z + R.sky_row;                 // sky bitmap without holes, or nothing: plain lookup, no lighting (x 1.0 is exact)
-    float factor = bits_f32(a.w) * R.sky_fac;
+    uint32_t o = a.z + sky_row_of(R);             // sky bitmap without holes, or nothing: plain lookup, no lighting (x 1.0 is exact)
+    float factor = bits_f32(a.w) * sky_fac_of(R);
     if (~(m_wall | m_sky) != 0ull) {              // some row is owned by a floor / ceiling
         float ff;
-        const uint32_t fo = flat_offset_tile(fr, a, b, R, ~(m_wall | m_sky), ff);
+        const uint32_t fo = flat_offset_tile(T, a, b, R, ~(m_wall | m_sky), ff);
         const bool is_flat = !is_wall && !is_sky;
         o = is_flat ? fo : o;
         factor = is_flat ? ff : factor;
     }
     if (m_wall != 0ull) {
-        const uint32_t wo = wall_offset_tile(a, b, R.y, m_wall);
+        const uint32_t wo = wall_offset_tile(a, b, R, m_wall);
         o = is_wall ? wo : o;
         factor = is_wall ? bits_f32(a.w) : factor;
     }
@@ -251,12 +359,12 @@ __device__ __forceinline__ uint32_t owner_texel(const DevFrame &fr, const uint4 
 __device__ __forceinline__ void unpack_span(uint32_t w0, uint32_t off, uint32_t &v_lo, uint32_t &v_rg, uint32_t &v_off) {
     v_lo = w0 & 0x3fffu;
     v_rg = ((w0 >> 16) & 0x3fffu) - v_lo;
-    v_off = off;
+    v_off = off | w0_kind(w0) | (w0_plain(w0) ? OFF_PLAIN : 0u);
 }
 
 // A column is rendered in two stages so that the texel gather of one column is in flight while the next column's owners are worked
-// out (tile_body interleaves them):  stage 1 = the row owners and their (texel offset, light factor);  stage 2 = palette + shade of
-// the gathered texel, then the possibly-transparent spans on top.
+// out (tile_body interleaves them):  stage 1 = the rows' (texel offset, light factor);  stage 2 = palette + shade of the gathered
+// texel, then the possibly-transparent spans on top.
 //
 // Stage 1 for a column with any number of spans (lw0 = word 0 of every span of the column, off0 = byte offset of its first span in
 // the staging area): lane i looks at span i of each 64-span chunk, ballots pick the spans touching these rows.
@@ -273,7 +381,7 @@ __device__ __forceinline__ uint32_t big_column_owner(const uint32_t *lw0, uint32
     return winner;
 }
 // Stage 2 for such a column.
-__device__ __forceinline__ void big_column_overlays(const RasterParams &P, const uint32_t *lw0, const uint4 *staged, uint32_t off0, uint32_t n, int lane, int y0,
+__device__ __forceinline__ void big_column_overlays(const RasterParams &P, const FrameVgprs &T, const uint32_t *lw0, uint32_t lspans_addr, uint32_t off0, uint32_t n, int lane, int y0,
                                                     const RowConsts &R, uint32_t winner, uint32_t &tex_io, float &factor_io) {
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + (uint32_t)lane;
@@ -283,7 +391,7 @@ __device__ __forceinline__ void big_column_overlays(const RasterParams &P, const
         if (!m) continue;
         uint32_t v_lo, v_rg, v_off;
         unpack_span(w0v, off0 + 32u * i, v_lo, v_rg, v_off);
-        overlay_loop(P, staged, m, __ballot(hit && w0_kind(w0v) == SPAN_WALL), v_lo, v_rg, v_off, R, winner, tex_io, factor_io);
+        overlay_loop(P, T, lspans_addr, m, v_lo, v_rg, v_off, R, winner, tex_io, factor_io);
     }
 }
 
@@ -296,9 +404,6 @@ struct TileLds {
     uint32_t lw0[SPAN_CAP];
     float4 pal[256];                        // r, g, b as f32
     uint32_t lcoff[TILE_W + 1];
-#ifdef DG_EXP_T_LDSPAD
-    uint32_t pad[DG_EXP_T_LDSPAD / 4];
-#endif
 };
 
 // The tile rows [ty_begin, ty_end) of one 64-column strip of frame f (columns x0 ..): the strip's spans, the palette and the column
@@ -309,23 +414,18 @@ struct TileLds {
 // right edge and every row starts on a dword — the read-out stores dwords.  Any other width takes byte stores (dg_raster_tiles_anyw).
 template <bool W4>
 __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, int f, int x0, int ty_begin, int ty_end) {
-#ifdef DG_EXP_T_TIMING
-    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
-#define DG_PHASE(k) { const unsigned long long tnow = __builtin_readcyclecounter(); tm[k] += tnow - tprev; tprev = tnow; }
-#else
-#define DG_PHASE(k)
-#endif
     const DevFrame fr = P.frames[f];
     const int W = P.k.W, H = P.k.H;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
     const uint4 *gspans = reinterpret_cast<const uint4 *>(P.rspans + fr.span_base);
+    const uint32_t lspans_addr = lds_address(L.lspans), pal_addr = lds_address(L.pal);
 
     // The spans of adjacent columns are one contiguous range of the column-major span array: [col_off[x0], col_off[x0 + 64]).  The two
     // ends are wave-uniform (scalar loads); when the range fits in LDS — the normal case — every thread fetches its span straight
     // away, together with its palette entry (already f32x4 in HBM) and the 65 column offsets, and ONE barrier publishes all of it.
-    // The records are in their per-pixel form already (raster_core.h resolve_*_span): staging is a copy.
+    // The records are in their per-pixel form already (raster_core.h resolve_*_span): staging is a copy (stage_words: two words of a wall).
     const uint32_t t_first = coff[x0 < W ? x0 : W], t_last = coff[x0 + TILE_W < W ? x0 + TILE_W : W];
     const bool fits = t_last - t_first <= (uint32_t)SPAN_CAP;
     {
@@ -343,7 +443,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         if (threadIdx.x <= TILE_W) L.lcoff[threadIdx.x] = coff_v;
         if (mine) {
             L.lw0[threadIdx.x] = sa.x;
-            sa.x = staged_w0(sa.x, sb.z);
+            stage_words(sa, sb);
             L.lspans[2 * threadIdx.x + 2] = sa;
             L.lspans[2 * threadIdx.x + 3] = sb;
         }
@@ -355,17 +455,20 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
     auto row_consts = [&](int yy, const uint4 t) {
         RowConsts r;
         r.y = yy;
+        r.yf = (float)yy;
         r.r_vy = bits_f32(t.x);
         r.vy = bits_f32(t.y);
-        r.row_fast = t.z & 0x100u;
-        r.sky_row = t.z & 0xffu;
-        r.sky_fac = bits_f32(t.w);
+        r.sky = (t.z & 0xffu) | t.w;
         return r;
     };
+    // The frame constants the flat mapper uses per pixel, in VGPRs (the asm keeps the compiler from folding them back into scalar operands)
+    FrameVgprs T;
+    {
+        const uint32_t pk = ((uint32_t)fr.pos_x_i16 & 63u) | (((uint32_t)fr.pos_y_i16 & 63u) << 16);
+        asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=&v"(T.cos_a), "=&v"(T.sin_a), "=&v"(T.pos_pk) : "s"(fr.cos_a), "s"(fr.sin_a), "s"(pk));
+    }
     uint8_t *fb = P.fb + (size_t)f * (size_t)3 * (size_t)W * (size_t)H;
-    DG_PHASE(0)
     __syncthreads();
-    DG_PHASE(1)
 
   for (int ty = ty_begin; ty < ty_end; ty++) {
     const int y0 = ty * TILE_H;
@@ -375,7 +478,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
     // lane = (column, row) = (lane >> 3, lane & 7).  Its row constants:
     const bool few_rows = H - y0 <= PACK_ROWS;
     const RowConsts R = row_consts(y, rt);
-    const bool tile_vy0 = __builtin_amdgcn_ballot_w64(R.row_fast == 0u) != 0ull;   // the horizon row (vy == 0) is in this tile
+    const bool tile_vy0 = __builtin_amdgcn_ballot_w64(R.vy == 0.0f) != 0ull;   // the horizon row (vy == 0) is in this tile
 
     int c_lo = 0;
     while (c_lo < TILE_W) {
@@ -390,7 +493,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
             for (uint32_t i = threadIdx.x; i < n_stage; i += THREADS) {
                 uint4 a = gspans[2 * ((size_t)t0 + i)], b = gspans[2 * ((size_t)t0 + i) + 1];
                 L.lw0[i] = a.x;
-                a.x = staged_w0(a.x, b.z);
+                stage_words(a, b);
                 L.lspans[2 * i + 2] = a;
                 L.lspans[2 * i + 3] = b;
             }
@@ -418,21 +521,18 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         const unsigned long long big = __ballot(f_n > 8u);         // all 8 lanes of a column with more than 8 spans
         // Columns with ONE opaque owner: the last OPAQUE span that touches the tile's rows is plain and covers all of the tile's live
         // rows — whatever lies under it in draw order cannot show.  Such a column (two out of three in the benchmark scene) needs no
-        // owner search, no per-row parameter fetch and no kind vote: ucol_* carry one bit per column, at the owning span's lane.
+        // range test and no select: ucol_* carry one bit per column, at the owning span's lane.
         // Possibly-transparent spans drawn after it (a sprite in front of a wall) are laid on top in stage 2 as usual; those drawn
         // before it are dropped here.
         const uint32_t my_ops = (uint32_t)(hit_op >> (lane & ~7)) & 0xffu;
         const bool f_last = (my_ops >> (fslot + 1)) == 0u;
         const bool f_sole = f_op && f_last && w0_plain(f_w0) && w0_ctop(f_w0) <= y0 && w0_cbot(f_w0) >= (y0 + (TILE_H - 1) < H ? y0 + (TILE_H - 1) : H - 1);
-        const unsigned long long ucol_wall = __ballot(f_sole && w0_kind(f_w0) == SPAN_WALL);   // (a bitmap height that is not a power of two: the general path)
-        const unsigned long long ucol_flat = tile_vy0 ? 0ull : __ballot(f_sole && w0_kind(f_w0) == SPAN_FLAT);   // (the vy == 0 row, like numerators outside the prepared divide's domain: the general path)
-        // (more classes — floors with the plain divide, sky — were measured: the code they add to every copy of stage 1 costs more than
-        // the few per cent of chunks they take off the general path, profiles/r03_raster_tiles.md)
+        const unsigned long long ucol_wall = __ballot(f_sole && w0_kind(f_w0) == SPAN_WALL);   // (a bitmap height that is not a power of two, a texture row beyond i16: span_loop)
+        const unsigned long long ucol_flat = tile_vy0 ? 0ull : __ballot(f_sole && w0_kind(f_w0) == SPAN_FLAT);   // (the vy == 0 row, like numerators outside the prepared divide's domain: span_loop)
         const unsigned long long ucol = ucol_wall | ucol_flat;
         const uint32_t my_ucol = (uint32_t)(ucol >> (lane & ~7)) & 0xffu;                      // the sole owner of my column, if it has one
         const bool under = my_ucol != 0u && (1u << fslot) < my_ucol;                           // drawn before it: cannot show
         const unsigned long long hit_ov = __ballot(f_ov && !under);
-        const unsigned long long hit_ovwall = __ballot(f_ov && !under && w0_kind(f_w0) == SPAN_WALL);
         const unsigned long long walk2 = big | hit_ov;                        // columns whose stage 2 has more to do than shading
         const int nk = (c_hi - c_lo - wave + WAVES - 1) / WAVES;     // columns of this chunk that are this wave's
         if (few_rows && nk == WAVES && walk2 == 0ull) {
@@ -442,7 +542,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
             const int yp = y0 + (lane & (PACK_ROWS - 1));
             const RowConsts Rp = row_consts(yp, P.row_tab[yp < H ? yp : H - 1]);
             const uint32_t mine_word = (f_hit && !w0_immediate(f_w0)) ? (v_lo | (v_rg << 16)) : 0x0000ffffu;
-            const uint32_t off_first = v_off - 32u * (uint32_t)fslot;          // staging offset of the column's first span
+            const uint32_t off_first = (v_off & OFF_ADDR) - 32u * (uint32_t)fslot;          // staging offset of the column's first span
             uint32_t winner = 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -450,7 +550,7 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
                 winner = ((uint32_t)Rp.y - (w & 0xffffu)) <= (w >> 16) ? off_first + 32u * (uint32_t)j : winner;
             }
             float factor;
-            const uint32_t o = owner_texel(fr, L.lspans, winner, Rp, factor);
+            const uint32_t o = owner_texel(T, L.lspans, winner, Rp, factor);
             const uint32_t px = shade_f(L.pal[P.scene.texel_idx[o]], factor);
             L.tile[(c_lo + wave + WAVES * fk) * TILE_TS + fslot] = px;
             c_lo = c_hi;
@@ -459,63 +559,44 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         }
         // Two columns in flight per wave: stage 1 of a column and its gather are issued before stage 2 of the column before it.
         struct Col { uint32_t tex, winner; float factor; };
+        uint32_t *const tcol = &L.tile[(c_lo + wave) * TILE_TS + lane];       // this lane's row in the wave's first column; column k is k * 8 columns on
         auto stage1 = [&](int k, Col &C) {
-            DG_PHASE(2)
             const unsigned long long colmask = 0xffull << (8 * k);
             const unsigned long long mu = ucol & colmask;
-            if (mu) {                                                // one owner for all rows of this column
+            uint32_t o;
+            if (mu) {                                                // one plain owner for all rows of this column
                 const uint32_t off = bcast(v_off, __builtin_ctzll(mu));
-                const uint4 a = span_at(L.lspans, off)[0], b = span_at(L.lspans, off)[1];   // same address in every lane: LDS broadcast
-                uint32_t o;
-#ifdef DG_ABL_NOSOLEMAP
-                o = a.z + (uint32_t)lane; C.factor = bits_f32(a.w);
-#else
-                if (ucol_wall & mu) { o = wall_offset_plain(a, b, R.y); C.factor = bits_f32(a.w); }
-                else o = flat_offset_plain(fr, a, b, R, C.factor);
-#endif
-                C.winner = off;                                     // (stage 2 lays later possibly-transparent spans on top)
-                C.tex = P.scene.texel_idx[o];
-                DG_PHASE(3)
-                return;
-            }
-#ifdef DG_ABL_NOGENERAL
-            C.tex = 0; C.winner = 0; C.factor = 0.0f; return;
-#endif
-            if (big & colmask) {
-                const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
-                C.winner = big_column_owner(L.lw0 + n0, 32u * (n0 + 1u), n, lane, y0, R);
+                uint4 a, b;
+                lds_record(lspans_addr + (off & OFF_ADDR), a, b);
+                if (ucol_wall & mu) { o = wall_offset_plain(a, b, R); C.factor = bits_f32(a.w); }
+                else o = flat_offset_plain(T, a, b, R, C.factor);
+                C.winner = off;                                      // (stage 2 lays later possibly-transparent spans on top)
             } else {
-                C.winner = owner_loop(hit_op & colmask, v_lo, v_rg, v_off, R, 0u);
+                if (big & colmask) {
+                    const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
+                    C.winner = big_column_owner(L.lw0 + n0, 32u * (n0 + 1u), n, lane, y0, R);
+                } else {
+                    C.winner = owner_loop(hit_op & colmask, v_lo, v_rg, v_off, R, 0u);
+                }
+                o = owner_texel(T, L.lspans, C.winner, R, C.factor);
             }
-            const uint32_t o = owner_texel(fr, L.lspans, C.winner, R, C.factor);
-            C.tex = P.scene.texel_idx[o];                    // in flight until stage 2
-            DG_PHASE(3)
+            C.tex = P.scene.texel_idx[o];                            // in flight until stage 2
         };
         auto stage2 = [&](int k, const Col &C) {
             const unsigned long long colmask = 0xffull << (8 * k);
             uint32_t tex = C.tex;
             float factor = C.factor;
-            DG_PHASE(4)
-#ifdef DG_ABL_NOOVL
-            if (false) {
-#else
             if (walk2 & colmask) {                                   // possibly-transparent spans on top, in draw order
-#endif
                 if (big & colmask) {
                     const uint32_t n0 = bcast(f_n0, 8 * k), n = bcast(f_n, 8 * k);
-                    big_column_overlays(P, L.lw0 + n0, L.lspans, 32u * (n0 + 1u), n, lane, y0, R, C.winner, tex, factor);
+                    big_column_overlays(P, T, L.lw0 + n0, lspans_addr, 32u * (n0 + 1u), n, lane, y0, R, C.winner, tex, factor);
                 } else {
-                    // (issuing the first such span's texel fetch in stage 1, unmasked, was measured: slower — 0.60 against 0.57 ms)
-                    overlay_loop(P, L.lspans, hit_ov & colmask, hit_ovwall, v_lo, v_rg, v_off, R, C.winner, tex, factor);
+                    overlay_loop(P, T, lspans_addr, hit_ov & colmask, v_lo, v_rg, v_off, R, C.winner, tex, factor);
                 }
             }
-#ifdef DG_ABL_NOSHADE
-            const uint32_t px = tex + f32_bits(factor);
-#else
-            const uint32_t px = shade_f(L.pal[tex], factor);         // palette x light, `as u8` (bitmap_render.rs:202-207), once per pixel
-#endif
-            L.tile[(c_lo + wave + WAVES * k) * TILE_TS + lane] = px;
-            DG_PHASE(5)
+            float4 c;                                                // palette entry: one 16-byte read (a 12-byte one costs twice the LDS cycles)
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(c) : "v"(pal_addr + (tex << 4)));
+            tcol[k * WAVES * TILE_TS] = shade_f(c, factor);          // palette x light, `as u8` (bitmap_render.rs:202-207), once per pixel
         };
         Col A, B;
         if (nk == WAVES) {                                           // a whole tile's worth (the normal case): one loop shape, no conditionals
@@ -540,19 +621,13 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
         c_lo = c_hi;
         if (c_lo < TILE_W) __syncthreads();   // before the staging area is reused
     }
-    DG_PHASE(2)
     __syncthreads();
-    DG_PHASE(6)
 
     // Read-out: groups of 4 pixels of a row (4 LDS words -> 12 B of RGB24), 16 groups per tile row; the 64 lanes of a wave take
     // 4 rows x 16 groups in an order that is conflict-free in LDS; 8 adjacent lanes write 96 contiguous bytes.
     const int gc = (lane & 7) | ((lane >> 5) << 3), rsub = (lane >> 3) & 3;
 #pragma unroll
-#ifdef DG_ABL_NOREADOUT
-    for (int pass = 0; pass < 0; pass++) {
-#else
     for (int pass = 0; pass < TILE_H / (4 * WAVES); pass++) {
-#endif
         const int row = pass * 4 * WAVES + wave * 4 + rsub;
         const int yy = y0 + row, xx = x0 + 4 * gc;
         if (yy < H && xx < W) {
@@ -576,12 +651,6 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
     }
     if (ty + 1 < ty_end) __syncthreads();     // the LDS tile (and, when the spans did not fit, the staging area) is written again
   }
-#ifdef DG_EXP_T_TIMING
-    DG_PHASE(7)
-    if (lane == 0 && f == 100 && (x0 / TILE_W) % 5 == 2)
-        printf("[strip %d rows %d-%d wave %d] load+stage %llu barrier %llu between %llu stage1 %llu gather+shade %llu overlays+write %llu end-barrier %llu readout %llu\n", x0 / TILE_W,
-               ty_begin, ty_end, wave, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7]);
-#endif
 }
 
 // (launch bounds: 8 waves per SIMD = at most 64 VGPRs; one more register costs a fourth of the resident workgroups, 0.58 -> 0.67 ms)
@@ -672,9 +741,6 @@ hipError_t launch_setup(const RasterParams &P, uint32_t max_spans_per_frame, hip
 // Rule: the fewest equal segments per strip that still give ~30 000 workgroups, never fewer than 3 rows' worth for tall frames.
 int raster_tile_rows_per_wg(int W, int H, int n_frames) {
     const int n_tile_rows = (H + TILE_H - 1) / TILE_H;
-#ifdef DG_EXP_TILE_ROWS
-    return std::min(DG_EXP_TILE_ROWS, n_tile_rows);
-#endif
     if (n_tile_rows < 8) return std::min(2, n_tile_rows);
     const long long strips = (long long)((W + TILE_W - 1) / TILE_W) * (long long)std::max(1, n_frames);
     long long segments = (30000 + strips - 1) / strips;

@@ -31,7 +31,8 @@ DG_HD float bits_f32(uint32_t u) {
 DG_HD int32_t lo_i16(uint32_t w) { return (int32_t)(int16_t)(w & 0xffffu); }
 // DevRSpan word 0: ctop (bits 0-13) | plain-flag (bit 14) | immediate-flag (bit 15) | cbot (bits 16-29) | kind (bits 30-31); rows are
 // < 16384.  plain: the span's pixels take the short form of their mapper — a wall whose bitmap height is a power of two (mask instead
-// of modulus), a floor / ceiling whose numerators are inside the prepared divide's verified domain (div_guard_ok).
+// of modulus) and whose texture row stays inside i16 on its rows (no saturation in the `as i16`: resolve_wall_span), a floor / ceiling whose
+// numerators are inside the prepared divide's verified domain (div_guard_ok).
 DG_HD uint32_t pack_w0(int32_t ctop, int32_t cbot, uint32_t kind, bool immediate, bool plain) {
     return (uint32_t)(ctop & 0x3fff) | (plain ? 0x4000u : 0u) | (immediate ? 0x8000u : 0u) | ((uint32_t)(cbot & 0x3fff) << 16) | (kind << 30);
 }
@@ -184,8 +185,16 @@ DG_HD DevRSpan resolve_wall_span(const DevSpan &sp, const DevWallRec &r) {
     // and for a finite ay the middle term is +-0.0 and drops out (h >= 1), so the kernel evaluates h + ay * uy1.
     const float d = (float)((int32_t)sp.bot_y - (int32_t)sp.top_y);
     const bool pot = (h & (h - 1)) == 0;
+    // plain: the pixel takes the short form of the mapper — the modulus is a mask AND `h + ay * uy1` cannot leave i16 on the rows the span
+    // writes, so that its `as i16` is a bare conversion.  The expression is monotonic in y (a correctly rounded quotient by a constant, a
+    // product with a constant and a sum with a constant are), so its values on the first and the last row bound all of them; a NaN
+    // (d == 0) fails both comparisons.  IEEE quotients here (`/`), so that host binner and device scatter set the same bit.
+    const float uy1 = d == 0.0f ? bits_f32(0x7fc00000u) : r.uy1;
+    const float v_top = (float)h + ((float)((int32_t)sp.ctop - (int32_t)sp.top_y) / d) * uy1;
+    const float v_bot = (float)h + ((float)((int32_t)sp.cbot - (int32_t)sp.top_y) / d) * uy1;
+    const bool in_i16 = __builtin_fabsf(v_top) < 32000.0f && __builtin_fabsf(v_bot) < 32000.0f;
     DevRSpan o;
-    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_WALL, r.has_holes != 0, pot);
+    o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_WALL, r.has_holes != 0, pot && in_i16);
     o.w[1] = f32_bits(d);
     o.w[2] = r.texel_off + (uint32_t)tx * (uint32_t)h;          // start of the texture column (column-major planes)
     o.w[3] = f32_bits(light_factor(r.lightf, z));
@@ -199,7 +208,10 @@ DG_HD DevRSpan resolve_wall_span(const DevSpan &sp, const DevWallRec &r) {
 DG_HD DevRSpan resolve_flat_span(const DevSpan &sp, const DevPlaneRec &p, const DevConsts &k, uint32_t flats_rel) {
     const float vx = (k.CFX - (float)sp.x) / k.ARC;                      // visplanes.rs:108
     const float wzvx = p.wz * vx;                                        // numerator of wy = wz * vx / vy (visplanes.rs:114)
-    const bool guard_ok = div_guard_ok(wzvx) && div_guard_ok(p.gwz);
+    // plain (the short form of the mapper): both numerators inside the prepared divide's verified domain, and a light level below 7 x 255
+    // (the tile kernel's short form leaves `wx as i16` unclamped above: beyond 32767 the factor is negative whatever the clamp says —
+    // light / 255 - 7.99 — as long as light / 255 stays below that)
+    const bool guard_ok = div_guard_ok(wzvx) && div_guard_ok(p.gwz) && p.lightf < 7.0f;
     DevRSpan o;
     o.w[0] = pack_w0(sp.ctop, sp.cbot, SPAN_FLAT, false, guard_ok);
     o.w[1] = f32_bits(wzvx);
