@@ -379,16 +379,19 @@ SPRITE_DEFS = [(2035, "BAR1", False, 23, 32), (2028, "COLU", False, 19, 47), (48
 
 
 def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M1", quirks: bool = False,
-                     vanilla: bool = False) -> bytes:
+                     vanilla: bool = False, grid=None, n_things=None, custom_map=None) -> bytes:
     """`vanilla` (used with seed 1995) bends the lattice map towards what real IWAD maps hold: every vertex moved to an arbitrary
     integer position (so walls run at arbitrary angles and BSP split points are rounded onto the integer grid like a node
     builder's), chamfers with unequal legs, irregular pillars, closed doors (door sector ceiling == floor, segs.rs:222-225),
     thing angles in 1 degree steps and wall textures whose patches start above/left of the texture or run past its bottom.
-    The default maps do not consume any of the extra random numbers and stay byte-identical."""
+    The default maps do not consume any of the extra random numbers and stay byte-identical.
+    `grid` = (columns, rows) of rooms and `n_things` override the two sizes (8 x 6 / 16 x 12 rooms, 40 / 300 things): (32, 24) is a map of
+    doom2's scale — 768 rooms, over a thousand sectors, over ten thousand segs.  `custom_map(m, rng, names)` fills the `_Map` itself
+    (sectors, lines, things) instead of the room lattice; graphics, BSP builder and lump packing stay the generator's."""
     rng = XorShift32(seed)
-    gx, gy = (16, 12) if heavy else (8, 6)
+    gx, gy = grid if grid is not None else ((16, 12) if heavy else (8, 6))
     sky_pct = 50 if heavy else 25
-    n_things = 300 if heavy else 40
+    n_things = n_things if n_things is not None else (300 if heavy else 40)
 
     lumps: list[tuple[str, bytes]] = []
     lumps.append(("PLAYPAL", _palette(rng)))
@@ -493,6 +496,58 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
 
     # ---- map ----
     m = _Map()
+
+    def _finish():
+        # ---- BSP ----
+        segs = []
+        for li, ld in enumerate(m.linedefs):
+            a, b = m.vertexes[ld["v1"]], m.vertexes[ld["v2"]]
+            segs.append(dict(a=a, b=b, linedef=li, direction=0, offset=0, sector=m.sidedefs[ld["front"]]["sector"]))
+            if ld["back"] >= 0:
+                segs.append(dict(a=b, b=a, linedef=li, direction=1, offset=0, sector=m.sidedefs[ld["back"]]["sector"]))
+        bsp = _BspBuilder(m, rng, round_splits=vanilla)
+        root = bsp.build(segs)
+        assert not (root & 0x8000) and root == len(bsp.nodes) - 1
+
+        things = b"".join(struct.pack("<hhhhh", *t) for t in m.things)
+        seg_bytes = bytearray()
+        for s in bsp.segs_out:
+            v1, v2 = m.vertex(*s["a"]), m.vertex(*s["b"])
+            seg_bytes += struct.pack("<hhhhhh", v1, v2, _bam16(s["b"][0] - s["a"][0], s["b"][1] - s["a"][1]), s["linedef"],
+                                     s["direction"], min(32767, s["offset"]))
+        vertexes = b"".join(struct.pack("<hh", x, y) for x, y in m.vertexes)
+        linedefs = b"".join(struct.pack("<hhhhhhh", ld["v1"], ld["v2"], ld["flags"], 0, 0, ld["front"], ld["back"]) for ld in m.linedefs)
+        sidedefs = b"".join(struct.pack("<hh", sd["xoff"], sd["yoff"]) + _name8(sd["upper"]) + _name8(sd["lower"]) + _name8(sd["middle"]) +
+                            struct.pack("<h", sd["sector"]) for sd in m.sidedefs)
+        ssectors = b"".join(struct.pack("<hh", c, f) for c, f in bsp.ssectors)
+
+        def child(c):
+            return struct.pack("<H", c)
+
+        nodes = b"".join(struct.pack("<hhhh", n["x"], n["y"], n["dx"], n["dy"]) + struct.pack("<hhhh", *n["rb"]) +
+                         struct.pack("<hhhh", *n["lb"]) + child(n["rc"]) + child(n["lc"]) for n in bsp.nodes)
+        sectors = b"".join(struct.pack("<hh", s["floor"], s["ceil"]) + _name8(s["ffl"]) + _name8(s["cfl"]) +
+                           struct.pack("<hhh", s["light"], s["special"], s["tag"]) for s in m.sectors)
+        assert len(m.vertexes) < 32768 and len(bsp.segs_out) < 32768 and len(m.sidedefs) < 32768
+        out_lumps = lumps + [(map_name.upper(), b""), ("THINGS", things), ("LINEDEFS", linedefs), ("SIDEDEFS", sidedefs), ("VERTEXES", vertexes),
+                  ("SEGS", bytes(seg_bytes)), ("SSECTORS", ssectors), ("NODES", nodes), ("SECTORS", sectors), ("REJECT", b""),
+                  ("BLOCKMAP", b"")]
+
+        if quirks:
+            out_lumps = _apply_quirks(out_lumps, p, patches, map_name.upper())
+
+        # ---- container ----
+        body = bytearray()
+        directory = bytearray()
+        for name, data in out_lumps:
+            directory += struct.pack("<II", 12 + len(body), len(data)) + _name8(name)
+            body += data
+        hdr = b"IWAD" + struct.pack("<II", len(out_lumps), 12 + len(body))
+        return hdr + bytes(body) + bytes(directory)
+
+    if custom_map is not None:
+        custom_map(m, rng, dict(wall_textures=list(wall_textures), floor_flats=list(FLOOR_FLATS), ceil_flats=list(CEIL_FLATS), sprite_defs=list(SPRITE_DEFS)))
+        return _finish()
     if vanilla:
         def jitter(x, y, _seed=seed):
             h = (x * 73856093 ^ y * 19349663 ^ _seed * 83492791) & 0xFFFFFFFF
@@ -659,52 +714,7 @@ def build_synth_iwad(seed: int = 1993, heavy: bool = False, map_name: str = "E1M
         oy = rng.choice([-64, -48, -32, 32, 48, 64])
         m.things.append((r["cx"] + ox, r["cy"] + oy, rng.below(360) if vanilla else 45 * rng.below(8), num, 7))
 
-    # ---- BSP ----
-    segs = []
-    for li, ld in enumerate(m.linedefs):
-        a, b = m.vertexes[ld["v1"]], m.vertexes[ld["v2"]]
-        segs.append(dict(a=a, b=b, linedef=li, direction=0, offset=0, sector=m.sidedefs[ld["front"]]["sector"]))
-        if ld["back"] >= 0:
-            segs.append(dict(a=b, b=a, linedef=li, direction=1, offset=0, sector=m.sidedefs[ld["back"]]["sector"]))
-    bsp = _BspBuilder(m, rng, round_splits=vanilla)
-    root = bsp.build(segs)
-    assert not (root & 0x8000) and root == len(bsp.nodes) - 1
-
-    things = b"".join(struct.pack("<hhhhh", *t) for t in m.things)
-    seg_bytes = bytearray()
-    for s in bsp.segs_out:
-        v1, v2 = m.vertex(*s["a"]), m.vertex(*s["b"])
-        seg_bytes += struct.pack("<hhhhhh", v1, v2, _bam16(s["b"][0] - s["a"][0], s["b"][1] - s["a"][1]), s["linedef"],
-                                 s["direction"], min(32767, s["offset"]))
-    vertexes = b"".join(struct.pack("<hh", x, y) for x, y in m.vertexes)
-    linedefs = b"".join(struct.pack("<hhhhhhh", ld["v1"], ld["v2"], ld["flags"], 0, 0, ld["front"], ld["back"]) for ld in m.linedefs)
-    sidedefs = b"".join(struct.pack("<hh", sd["xoff"], sd["yoff"]) + _name8(sd["upper"]) + _name8(sd["lower"]) + _name8(sd["middle"]) +
-                        struct.pack("<h", sd["sector"]) for sd in m.sidedefs)
-    ssectors = b"".join(struct.pack("<hh", c, f) for c, f in bsp.ssectors)
-
-    def child(c):
-        return struct.pack("<H", c)
-
-    nodes = b"".join(struct.pack("<hhhh", n["x"], n["y"], n["dx"], n["dy"]) + struct.pack("<hhhh", *n["rb"]) +
-                     struct.pack("<hhhh", *n["lb"]) + child(n["rc"]) + child(n["lc"]) for n in bsp.nodes)
-    sectors = b"".join(struct.pack("<hh", s["floor"], s["ceil"]) + _name8(s["ffl"]) + _name8(s["cfl"]) +
-                       struct.pack("<hhh", s["light"], s["special"], s["tag"]) for s in m.sectors)
-    assert len(m.vertexes) < 32768 and len(bsp.segs_out) < 32768 and len(m.sidedefs) < 32768
-    lumps += [(map_name.upper(), b""), ("THINGS", things), ("LINEDEFS", linedefs), ("SIDEDEFS", sidedefs), ("VERTEXES", vertexes),
-              ("SEGS", bytes(seg_bytes)), ("SSECTORS", ssectors), ("NODES", nodes), ("SECTORS", sectors), ("REJECT", b""),
-              ("BLOCKMAP", b"")]
-
-    if quirks:
-        lumps = _apply_quirks(lumps, p, patches, map_name.upper())
-
-    # ---- container ----
-    body = bytearray()
-    directory = bytearray()
-    for name, data in lumps:
-        directory += struct.pack("<II", 12 + len(body), len(data)) + _name8(name)
-        body += data
-    hdr = b"IWAD" + struct.pack("<II", len(lumps), 12 + len(body))
-    return hdr + bytes(body) + bytes(directory)
+    return _finish()
 
 
 def _apply_quirks(lumps, p, patches, map_marker):
@@ -750,24 +760,24 @@ def _apply_quirks(lumps, p, patches, map_marker):
     return out
 
 
-def synth_route(seed: int = 1993, heavy: bool = False, vanilla: bool = False):
+def synth_route(seed: int = 1993, heavy: bool = False, vanilla: bool = False, grid=None, n_things=None):
     """Waypoints (x, y) of a closed walk through every room that only crosses door sectors:
     depth-first traversal of the generator's spanning tree (same RNG stream as build_synth_iwad)."""
     # Re-run the generator's RNG consumption up to the spanning tree by building the WAD's
     # connectivity again; cheaper: rebuild and introspect.
-    return _route_from_build(seed, heavy, vanilla)
+    return _route_from_build(seed, heavy, vanilla, grid, n_things)
 
 
-def _route_from_build(seed, heavy, vanilla=False):
+def _route_from_build(seed, heavy, vanilla=False, grid=None, n_things=None):
     # The route is derived from the door list, recovered from the WAD itself: two-sided linedefs.
-    wad = build_synth_iwad(seed, heavy, vanilla=vanilla)
+    wad = build_synth_iwad(seed, heavy, vanilla=vanilla, grid=grid, n_things=n_things)
     lumps = wad_directory(wad)
     idx = [i for i, (n, _, _) in enumerate(lumps) if n == "E1M1"][0]
     def lump(k):
         n, off, size = lumps[idx + k]
         return wad[off:off + size]
     ld, sd, vx, secs = lump(2), lump(3), lump(4), lump(8)
-    gx, gy = (16, 12) if heavy else (8, 6)
+    gx, gy = grid if grid is not None else ((16, 12) if heavy else (8, 6))
     nroom = gx * gy
     adj = {c: set() for c in range(nroom)}
     door_rooms: dict[int, set] = {}
@@ -801,7 +811,7 @@ def _route_from_build(seed, heavy, vanilla=False):
                 route.append(centre(c))
 
     import sys
-    sys.setrecursionlimit(10000)
+    sys.setrecursionlimit(max(10000, 8 * nroom))
     dfs(0)
     return route[:-1]  # closed loop: last point == first
 

@@ -548,8 +548,10 @@ int emul_frame_lists(void *scene, int W, int H, const dg_view *view_in, int32_t 
 // Runs the bodies of dg_fs_order / dg_fs_segs / dg_fs_frame for one frame — the "lanes" of every phase one after another, a barrier
 // between phases — and compares what they produce with the host walker's parts mode (build_frame_parts), record by record:
 // every FePart byte for byte, every FeSprite (but its behind_off: the row stride differs), the behind bits, the sky slot table, both
-// column-bin tables.  Returns 0 and stats = [parts, sprites, sky slots, flags, visible segs, candidates], 1 when the host walker
-// itself refuses the frame (then the device walk must have flagged it), < 0 with emul_last_error on a mismatch.
+// column-bin tables.  Returns 0 and stats = [parts, sprites, sky slots, flags, capacities exceeded, candidates], 1 when the host walker
+// itself refuses the frame (then the device walk must have flagged it), 2 when the device walk gave the frame up because it exceeds a
+// capacity (stats[4]: 1 parts, 2 candidates, 4 sprites, 8 sky parts, 16 part bins, 32 sprite bins), 3 when it gave it up for no such
+// reason, < 0 with emul_last_error on a mismatch.
 extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, uint64_t *stats) {
     const Scene &sc = *(const Scene *)scene;
     if (!sc.fs_ok || W > FS_MAX_W) { g_err = "scene / frame size not eligible for the device seg walk"; return -100; }
@@ -586,6 +588,8 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
 
     for (uint32_t l = 0; l < P.n_leaves; l++) fs_leaf_order(P, 0, l);                                      // dg_fs_order
     for (uint32_t s = 0; s < P.n_segs; s++) if (P.seg_leaf[s] != 0xffffu) fs_seg_lane(P, 0, s);             // dg_fs_segs
+    uint32_t n_cand = 0;                                                                                   // process_sidedef calls that reach their column loop
+    for (const uint2 &q : lite) n_cand += (q.x | q.y) != 0u;
     static thread_local FsShared S;                                                                        // dg_fs_frame
     static thread_local FsSpriteTmp T[FS_LANES];
 #define LANES(body) for (int lane = 0; lane < FS_LANES; lane++) { body; }
@@ -621,12 +625,18 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     for (const uint2 &q : lite) if (q.x | q.y) { g_err = "dg_fs_frame left a candidate row dirty"; return -3; }
     for (uint32_t v : slice_cnt) if (v) { g_err = "dg_fs_frame left a slice counter dirty"; return -3; }
     const FeFrame &ff = ffr[0];
-    if (stats) { stats[0] = ff.n_parts; stats[1] = ff.n_sprites; stats[2] = ff.n_sky_slots; stats[3] = flags[0]; stats[4] = 0; stats[5] = S.n_cl; }
+    if (stats) { stats[0] = ff.n_parts; stats[1] = ff.n_sprites; stats[2] = ff.n_sky_slots; stats[3] = flags[0]; stats[4] = 0; stats[5] = n_cand; }
     if (host_rc) {                                    // the host walker refuses the frame: the device walk must have given it up too
         if (!(flags[0] & FE_OVF_SEGS)) { g_err = "host walker fails (" + g_err + ") but the device seg walk did not flag the frame"; return -1; }
         return 1;
     }
-    if (flags[0] & FE_OVF_SEGS) return 2;             // given up on the device (capacity, or a failure in a part the host culls): the host redoes it
+    if (flags[0] & FE_OVF_SEGS) {                     // given up on the device although the host walker completes the frame: only a NAMED capacity may do that
+        const uint32_t why = (arena.parts.size() > FS_PART_CAP ? 1u : 0u) | (n_cand > FS_CL_CAP ? 2u : 0u) | (arena.sprites.size() > FS_SPRITE_CAP ? 4u : 0u) |
+                             (arena.n_sky_slots > FS_SKY_CAP ? 8u : 0u) | (arena.bin_off[nb] > FS_BIN_CAP ? 16u : 0u) | (arena.sbin_off[nb] > FS_SBIN_CAP ? 32u : 0u);
+        if (stats) stats[4] = why;
+        if (!why) { g_err = "the device seg walk gave up a frame that exceeds none of its capacities and that the host walker completes"; return 3; }
+        return 2;
+    }
     auto bad = [&](const std::string &m) { g_err = m; return -2; };
     if (ff.n_parts != arena.parts.size()) return bad("part count " + std::to_string(ff.n_parts) + " != host " + std::to_string(arena.parts.size()));
     for (uint32_t i = 0; i < ff.n_parts; i++)

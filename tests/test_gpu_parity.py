@@ -487,10 +487,14 @@ def test_random_views_device_walk_equals_host_lists(dg, synth, campath_mod, orac
                                              float(rng.choice([-64, -8, 0, 24, 41, 200]))) for _ in range(2000)], dtype=np.float32)
     for (W, H) in [(320, 200), (132, 67)]:
         B = 500
-        ctxs = {fe: make_ctx(dg, scene, W, H, B, slots=1, front_end=fe) for fe in (dg.DG_FE_HOST, dg.DG_FE_DEVICE)}
+        ctxs = {fe: make_ctx(dg, scene, W, H, B, slots=1, front_end=fe) for fe in (dg.DG_FE_HOST, dg.DG_FE_DEVICE, dg.DG_FE_DEVICE_SEGS)}
         for b0 in range(0, len(recs), B):
             views = dg.make_views(recs[b0:b0 + B])
             a = ctxs[dg.DG_FE_HOST].render(views).copy()
+            c = ctxs[dg.DG_FE_DEVICE_SEGS].render(views).copy()          # viewpoints outside the map, inside closed doors, off any path
+            assert ctxs[dg.DG_FE_DEVICE_SEGS].timing(0)["front_end"] == dg.DG_FE_DEVICE_SEGS
+            diff = [k for k in range(B) if not np.array_equal(a[k], c[k])]
+            assert not diff, f"{W}x{H}: views {[b0 + k for k in diff[:8]]} differ between the host lists and the device seg walk"
             b = ctxs[dg.DG_FE_DEVICE].render(views)
             assert ctxs[dg.DG_FE_DEVICE].timing(0)["front_end"] == dg.DG_FE_DEVICE
             diff = [k for k in range(B) if not np.array_equal(a[k], b[k])]
@@ -539,18 +543,20 @@ def test_device_frame_checksums(dg, scene1993, oracle_scene1993, path1993):
 
 
 def test_full_path_2560x1600_by_checksums(dg, scene1994, oracle_scene1994, path1994):
-    """BASELINE config 5 shape at full size: all 1 000 frames of the heavy map at 2560x1600 through both front ends, compared
-    by device checksums (8 bytes per 12 MB frame); every 125th frame also against the oracle's frame."""
+    """BASELINE config 5 shape at full size: all 1 000 frames of the heavy map at 2560x1600 (= FS_MAX_W, the widest frame the device seg
+    walk takes) through all three front ends, compared by device checksums (8 bytes per 12 MB frame); every 125th frame also against the
+    oracle's frame."""
     W, H, B = 2560, 1600, 50
-    ctxs = {fe: make_ctx(dg, scene1994, W, H, B, slots=1, front_end=fe) for fe in (dg.DG_FE_HOST, dg.DG_FE_DEVICE)}
+    ctxs = {fe: make_ctx(dg, scene1994, W, H, B, slots=1, front_end=fe) for fe in (dg.DG_FE_HOST, dg.DG_FE_DEVICE, dg.DG_FE_DEVICE_SEGS)}
     for b0 in range(0, 1000, B):
         views = dg.make_views(path1994[b0:b0 + B])
         sums = {}
         for fe, ctx in ctxs.items():
             ctx.submit(0, views)
             ctx.wait(0)
+            assert ctx.timing(0)["front_end"] == fe
             sums[fe] = ctx.frame_checksums(0, 0, B)
-        assert list(sums[dg.DG_FE_HOST]) == list(sums[dg.DG_FE_DEVICE]), f"batch at {b0}"
+        assert list(sums[dg.DG_FE_HOST]) == list(sums[dg.DG_FE_DEVICE]) == list(sums[dg.DG_FE_DEVICE_SEGS]), f"batch at {b0}"
         if b0 % 125 == 0:
             assert int(sums[dg.DG_FE_DEVICE][0]) == dg.frame_checksum(oracle_scene1994.render(W, H, path1994[b0])), f"frame {b0}"
     for c in ctxs.values():
@@ -824,3 +830,32 @@ def test_one_slot_alternating_front_ends_keeps_its_walk_state_clean(dg, scene199
     assert used == [dg.DG_FE_DEVICE_SEGS if n >= 64 else dg.DG_FE_DEVICE for (_, n) in plan], used
     assert ctx.fallbacks() == {"front_end": 0, "redone_frames": 0}
     ctx.close()
+
+
+def test_a_map_of_doom2_s_scale_through_all_three_front_ends(dg, synth, campath_mod, oracle):
+    """A vanilla-shaped map with 768 rooms, 1 800 sectors, 18 000 segs and 500 things (doom2's largest maps hold about that many): 100
+    path frames at 1280x800 through every front end against the oracle — long sight lines through open doors, thousands of segs in the
+    frustum.  The seg walk's capacities (fs_frame.h) were sized on maps a sixth of this: the share of frames it hands back is printed
+    and bounded here (src/map/mod.rs:48-78 loads any map; src/renderer/mod.rs:69-104 walks all of it)."""
+    grid, n_things, seed = (32, 24), 500, 2002
+    wad = synth.build_synth_iwad(seed, heavy=True, vanilla=True, grid=grid, n_things=n_things)
+    osc = oracle.Scene(wad, "e1m1")
+    assert osc.sector_count() > 1000
+    sc = dg.Scene(wad, "e1m1")
+    route = synth.synth_route(seed, heavy=True, vanilla=True, grid=grid, n_things=n_things)
+    path = campath_mod.make_camera_path(route, osc.floor_height_at, 4000)[::40]        # every 40th frame of a 4 000-frame walk through all rooms
+    assert len(path) == 100
+    W, H = 1280, 800
+    refs = [np.frombuffer(osc.render(W, H, r), dtype=np.uint8).reshape(H, W, 3) for r in path]
+    for fe in (dg.DG_FE_HOST, dg.DG_FE_DEVICE, dg.DG_FE_DEVICE_SEGS):
+        ctx = make_ctx(dg, sc, W, H, len(path), slots=1, front_end=fe)
+        out = ctx.render(dg.make_views(path))
+        assert ctx.timing(0)["front_end"] == fe
+        for k, ref in enumerate(refs):
+            assert np.array_equal(out[k], ref), f"front end {fe}, frame {k}"
+        if fe == dg.DG_FE_DEVICE_SEGS:
+            redone = ctx.fallbacks()["redone_frames"]
+            print(f"doom2-scale map: the device seg walk handed back {redone} of {len(path)} frames")
+            assert redone <= 60, f"{redone} of {len(path)} frames exceed a capacity of the device seg walk"   # (46 on the CPU emulation: FS_CL_CAP, FS_SPRITE_CAP — DESIGN section 6)
+        ctx.close()
+    sc.close()

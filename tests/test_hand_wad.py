@@ -178,7 +178,7 @@ def build_hand_iwad() -> bytes:
                        ("SSECTORS", ssectors), ("NODES", nodes), ("SECTORS", sectors), ("REJECT", b"\0"), ("BLOCKMAP", b"\0\0\0\0\0\0\0\0")])
 
 
-def build_polygon_iwad(n_walls: int = 1200, radius: int = 3000) -> bytes:
+def build_polygon_iwad(n_walls: int = 1200, radius: int = 3000, ceil_flat: str = "CEILA", n_things: int = 24) -> bytes:
     """One round room of n_walls one-sided walls (two BSP leaves: the halves above and below the x axis) with a ring of sprites: from
     a point next to the wall, looking across, several hundred walls are in view at once — more than 256 wall records in one frame, which
     is where the device column walk stops staging a sprite's behind-bit row (eight words) next to its record and the device seg walk
@@ -189,7 +189,7 @@ def build_polygon_iwad(n_walls: int = 1200, radius: int = 3000) -> bytes:
         a = 2.0 * math.pi * i / n_walls                      # vertices 0 and n / 2 lie on the x axis: no wall straddles the partition
         V.append((int(round(radius * math.cos(a))), int(round(radius * math.sin(a)))))
     assert len(set(V)) == n_walls and n_walls % 2 == 0
-    sectors = struct.pack("<hh", 0, 128) + _name8("FLOORA") + _name8("CEILA") + struct.pack("<hhh", 176, 0, 0)
+    sectors = struct.pack("<hh", 0, 128) + _name8("FLOORA") + _name8(ceil_flat) + struct.pack("<hhh", 176, 0, 0)
     sidedefs, linedefs, upper, lower = b"", b"", [], []
     for i in range(n_walls):                                  # wall i runs clockwise: V[i + 1] -> V[i], the room on its right
         sidedefs += struct.pack("<hh", (i * 7) % 64, (i * 3) % 32) + _name8("-") + _name8("-") + _name8("WALLA" if i % 3 else "TWOP") + struct.pack("<h", 0)
@@ -205,9 +205,9 @@ def build_polygon_iwad(n_walls: int = 1200, radius: int = 3000) -> bytes:
     nodes = struct.pack("<hhhh", -r, 0, 2 * r, 0) + struct.pack("<hhhh", 0, -r, -r, r) + struct.pack("<hhhh", r, 0, -r, r) + struct.pack("<HH", 0x8000 | 1, 0x8000 | 0)
     vertexes = b"".join(struct.pack("<hh", *v) for v in V)
     things = struct.pack("<hhhhh", 0, 0, 0, 1, 7)
-    for k in range(24):                                       # a ring of imps and barrels half way out, and a second one further out
-        a = 2.0 * math.pi * k / 24
-        rr = radius // 2 if k % 2 else (3 * radius) // 4
+    for k in range(n_things):                                 # a ring of imps and barrels half way out, and a second one further out
+        a = 2.0 * math.pi * k / n_things                      # (more than 24: five rings, so that they do not hide one another)
+        rr = (radius // 2 if k % 2 else (3 * radius) // 4) if n_things <= 24 else radius * (3 + k % 5) // 8
         things += struct.pack("<hhhhh", int(rr * math.cos(a)), int(rr * math.sin(a)), (k * 45) % 360, 3001 if k % 3 else 2035, 7)
     return _pack_iwad(playpal, pnames, texture1, patches, flats, sprites,
                       [("E1M1", b""), ("THINGS", things), ("LINEDEFS", linedefs), ("SIDEDEFS", sidedefs), ("VERTEXES", vertexes), ("SEGS", segs),

@@ -343,6 +343,8 @@ def test_device_seg_walk_bodies_match_the_host_walker(synth, campath_mod, seed, 
     for j in range(200):
         rec = campath_mod.view_record(float(rng.uniform(-100, 4200)), float(rng.uniform(-100, 3200)), float(rng.uniform(-7, 7)), float(rng.choice([-64, -8, 0, 24, 200])))
         rc, st = es.fs_frame([320, 1280, 132][j % 3], [200, 800, 67][j % 3], rec, [0.0, 0.4, 0.7][j % 3])
-        assert rc in (0, 1, 2), (j, rc, st)
+        # a view the seg walk gives up must be one the host walker refuses too (a panic of the reference: rc 1) or one that exceeds a named
+        # capacity (rc 2, st[4] says which) — never "for no reason" (rc 3)
+        assert rc in (0, 1) or (rc == 2 and st[4] != 0), (j, rc, st, emul_bind.lib().emul_last_error())
         given_up += rc != 0
     assert same > 150 and given_up < 40
