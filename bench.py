@@ -424,6 +424,16 @@ def run(args, backend_factory=DoomGpuBackend):
         except Exception as e:                            # a side measurement must not take the headline line down with it
             latency = {"error": repr(e)}
 
+    # ---- the other configurations through the same timed path (rank 0, N = 1 only) --------------------------------------
+    side = None
+    if rank == 0 and world == 1 and not args.no_side_legs and backend_factory is DoomGpuBackend and args.config == 3 and not args.wad:
+        side = {}
+        for key, (cfg, ht) in {"config2": (2, 0), "config5": (5, 0), "config3_two_host_threads": (3, 2)}.items():
+            try:
+                side[key] = side_leg(args, backend_factory, device, np, cfg, 5, ht)
+            except Exception as e:                        # a side measurement must not take the headline line down with it
+                side[key] = {"error": repr(e)}
+
     # ---- roofline of the rasteriser --------------------------------------------------------------------------------
     mean_raster_s = float(np.mean(raster_ms)) / 1e3
     achieved = float(np.mean(alg_bytes)) / mean_raster_s / 1e9
@@ -444,6 +454,7 @@ def run(args, backend_factory=DoomGpuBackend):
                 "achievable_write_GBps": achievable_fill, "frac_of_achievable_write": (achieved / achievable_fill) if achievable_fill else None,
                 "note": "achieved/frac are measured over the timed steps (all kernels on one in-order stream; only the next batch's H2D copy overlaps these kernels); "
                         "isolated_* is the same launch measured with nothing else on the GPU"}
+    roofline["issue"] = issue_roofline(W, H, B, mean_raster_s)
     if iso_ms:
         iso = float(np.mean(iso_ms)) / 1e3
         roofline.update({"isolated_launch_ms": iso * 1e3,
@@ -479,7 +490,7 @@ def run(args, backend_factory=DoomGpuBackend):
             "roofline": roofline, "cpu_baseline": cpu, "resident_replay": resident, "e2e_host_frames": e2e_host, "latency": latency,
             "host": {"ms_per_batch": float(np.mean(host_ms)), "threads": getattr(ctx, "host_threads", None),
                      "list_bytes_per_frame": int(stats.get("list_bytes", 0) // max(1, stats.get("n_frames", 1)))},
-            "fallbacks": fallbacks, "per_rank": reports,
+            "fallbacks": fallbacks, "side_legs": side, "per_rank": reports,
         }
         print(json.dumps(line))
     ctx.close()
@@ -637,6 +648,93 @@ def host_frames_rate(args, be, ctx, n_slots, views, B, batches_per_step, barrier
             "d2h_GBps": nb * B * ctx.frame_bytes / h_s / 1e9}
 
 
+def side_leg(args, backend_factory, device, np, config: int, steps: int, host_threads: int = 0):
+    """One more BASELINE configuration through the WHOLE timed path of the headline (host record generation + H2D + every kernel, frames
+    left in HBM): a context of its own, one warm-up step, `steps` timed steps bracketed by waits.  Never `value`: these are the numbers the
+    other configurations (and the headline with two host threads) run at, in the driver's record instead of a builder's log."""
+    import copy
+    a = copy.copy(args)
+    name, a.width, a.height, a.batch, maps, camera = CONFIGS[config]
+    a.config, a.host_threads, a.wad = config, host_threads, None
+    W, H, B = a.width, a.height, a.batch
+    be = backend_factory(a, device)
+    ctx = be.load(maps[0], 1993, camera)
+    n_slots, views = be.n_slots, be.views
+    batches_per_step = PATH_FRAMES // B
+    ran = [False] * n_slots
+    raster_ms, setup_ms, host_ms, alg, fe_used = [], [], [], [], {}
+
+    def collect(s):
+        t = ctx.timing(s)
+        raster_ms.append(t["raster_ms"]); setup_ms.append(t["setup_ms"]); host_ms.append(t["host_ms"])
+        alg.append(t["n_frames"] * (3 * W * H + W * H + 4 * (W + 1)) + 32 * t["n_spans"])
+        fe_used[t.get("front_end", 2)] = fe_used.get(t.get("front_end", 2), 0) + 1
+
+    def one_pass(g0, timed):
+        for g in range(g0, g0 + batches_per_step):
+            s = g % n_slots
+            if ran[s]:
+                ctx.wait(s)
+                if timed:
+                    collect(s)
+            ctx.submit(s, views[s])
+            ran[s] = True
+        return g0 + batches_per_step
+
+    g = one_pass(0, False)
+    for s in range(n_slots):
+        ctx.wait(s)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g = one_pass(g, True)
+    for s in range(n_slots):
+        ctx.wait(s)
+    elapsed = time.perf_counter() - t0
+    for s in range(n_slots):
+        if ran[s]:
+            collect(s)
+    fb = ctx.fallbacks() if hasattr(ctx, "fallbacks") else None
+    ctx.close()
+    names = {1: "host span lists", 2: "device column walk", 3: "device seg walk + column walk"}
+    mean_r = float(np.mean(raster_ms)) / 1e3
+    return {"workload": f"BASELINE {name}, {W}x{H}, {batches_per_step} batch(es) of {B} per step" + (f", {host_threads} host threads" if host_threads else ""),
+            "baseline_config": config, "steps": steps, "warmup": 1, "value": steps * batches_per_step * B / elapsed, "unit": "frames/s", "ms_per_step": elapsed / steps * 1e3,
+            "raster_ms_per_batch": mean_r * 1e3, "front_end_kernels_ms_per_batch": float(np.mean(setup_ms)), "host_ms_per_batch": float(np.mean(host_ms)),
+            "host_threads": getattr(ctx, "host_threads", None) or host_threads or None,
+            "roofline_frac": float(np.mean(alg)) / mean_r / 1e9 / 8000.0,
+            "front_end": "; ".join(f"{names.get(k, k)}: {v} batch(es)" for k, v in sorted(fe_used.items())), "fallbacks": fb}
+
+
+def issue_roofline(W, H, B, mean_launch_s):
+    """`roofline.issue`: dg_raster_tiles is bound by instruction issue, not by bandwidth, so the line also says how many
+    wave-instructions of each class one (column, 64-row) chunk costs and what share of the issue capacity they fill at the launch time THIS
+    run measured.  The counts cannot be read from inside the process: they come from profiles/issue.json, written by
+    tools/issue_counters.py from rocprofv3 --pmc passes of the same build and launch shape (SQ_INSTS_*, SQ_ACTIVE_INST_VALU2 = vector
+    instructions that shared an issue slot, SQ_LDS_IDX_ACTIVE, SQ_BUSY_CU_CYCLES for the clock).  Capacities (profiles/r05_issue_model.md,
+    measured with tools/microbench/issue_rates.hip under the same counters): one vector issue slot per SIMD every 4 clocks, into which a
+    second instruction of the simple class can be paired; one scalar instruction per CU and clock; one LDS cycle per CU and clock."""
+    path = os.path.join(ROOT, "profiles", "issue.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        j = json.load(open(path)).get(f"{W}x{H}x{B}")
+        if not j:
+            return None
+        chunks = B * ((W + 63) // 64) * 64 * ((H + 63) // 64)            # (column, 64-row) chunks per launch
+        clocks = mean_launch_s * j["clock_ghz"] * 1e9
+        cus, simds = 256, 1024
+        valu_slots = j["valu"] - j["valu_paired"]
+        return {"per_chunk": {k: j[k] / chunks for k in ("valu", "valu_paired", "salu", "lds", "vmem", "smem")},
+                "per_chunk_total": sum(j[k] for k in ("valu", "salu", "lds", "vmem", "smem")) / chunks,
+                "vector_issue_slots_filled": valu_slots * 4.0 / (clocks * simds),
+                "scalar_issue_filled": j["salu"] / (clocks * cus),
+                "lds_cycles_filled": j["lds_cycles"] / (clocks * cus),
+                "clock_ghz": j["clock_ghz"], "chunks_per_launch": chunks,
+                "source": "profiles/issue.json (rocprofv3 --pmc of this build, tools/issue_counters.py); fractions use this run's mean launch time"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -658,6 +756,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-resident", action="store_true")
     ap.add_argument("--no-host-frames", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-view-per-call latency leg (`latency` in the JSON line)")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the short legs of configs 2 and 5 and of config 3 with two host threads (`side_legs` in the JSON line)")
     ap.add_argument("--latency", action="store_true", help="(default) measure the one-view-per-call latency leg at 1024x768 and the bench size")
     a = ap.parse_args(argv)
     _, cw, ch, cb, _, _ = CONFIGS[a.config]

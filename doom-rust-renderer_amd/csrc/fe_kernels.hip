@@ -61,45 +61,6 @@ __device__ __forceinline__ void stage_heads(const T *recs, int my, uint32_t g, u
     }
 }
 
-#ifdef DG_EXP_FE_WAVETIME
-// per-wave record (life in core clocks, start / end in 100 MHz ticks), written with plain stores; dg_wt_report (one wave, after the
-// launch) prints the launch's span, when its last wave started, and the histogram of lives
-constexpr unsigned WT_CAP = 1u << 18;
-__device__ uint4 g_wt_rec[2][WT_CAP];
-__device__ __forceinline__ void wavetime_report(int which, unsigned long long t0, unsigned long long r0, unsigned widx, int f, int bin, unsigned a, unsigned b) {
-    if ((threadIdx.x & 63) != 0 || widx >= WT_CAP) return;
-    const unsigned long long dt = clock64() - t0, r1 = wall_clock64();
-    g_wt_rec[which][widx] = uint4{(unsigned)dt, (unsigned)r0, (unsigned)r1, a | b << 16};
-}
-__global__ void dg_wt_report(unsigned n0, unsigned n1) {
-    __shared__ unsigned hist[64];
-    for (int which = 0; which < 2; which++) {
-        const unsigned n = min(which ? n1 : n0, WT_CAP);
-        if (threadIdx.x < 64) hist[threadIdx.x] = 0;
-        __syncthreads();
-        unsigned t0 = ~0u, t1 = 0, s1 = 0, mx = 0; unsigned long long sum = 0;
-        if (threadIdx.x == 0) {
-            for (unsigned i = 0; i < n; i++) {
-                const uint4 r = g_wt_rec[which][i];
-                t0 = min(t0, r.y); s1 = max(s1, r.y); t1 = max(t1, r.z); sum += r.x; mx = max(mx, r.x);
-                hist[min(63u, r.x >> 11)]++;
-            }
-            printf("[wt%d] span %u ticks (10 ns), last wave started at +%u, waves %u, mean life %llu clk, longest %u clk, hist(2048-clk buckets):", which, t1 - t0, s1 - t0, n, sum / max(1u, n), mx);
-            for (int i = 0; i < 64; i++) printf(" %u", hist[i]);
-            printf("\n");
-            // the ten longest lives: when they started, what they had to do
-            for (int k = 0; k < 10; k++) {
-                unsigned best = 0, bi = 0;
-                for (unsigned i = 0; i < n; i++) if (g_wt_rec[which][i].x > best) { best = g_wt_rec[which][i].x; bi = i; }
-                const uint4 r = g_wt_rec[which][bi];
-                printf("[wt%d]   wave %u life %u clk started +%u ended +%u  a %u,%u b %u, parts phase %u clk\n", which, bi, r.x, r.y - t0, r.z - t0, r.w & 0xffu, (r.w >> 8) & 0xffu, (r.w >> 16) & 63u, (r.w >> 22) << 8);
-                g_wt_rec[which][bi].x = 0;
-            }
-        }
-        __syncthreads();
-    }
-}
-#endif
 
 constexpr uint32_t FE_NEAR_BEHIND = 8;     // a behind-bit row of at most this many words (256 parts) is staged in LDS with its sprite's record
 constexpr uint32_t FE_PART_ROUND = 32, FE_SPRITE_ROUND = 16;                  // records per staging round
@@ -115,9 +76,6 @@ static_assert(sizeof(ColumnsLds) * (FE_COL_THREADS / 64) * 8 <= 160 * 1024, "eig
 
 __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
     __shared__ ColumnsLds lds_all[FE_COL_THREADS / 64];
-#ifdef DG_EXP_FE_WAVETIME
-    const unsigned long long wt_t0 = clock64(), wt_r0 = wall_clock64();
-#endif
     const int W = P.k.W;
     const uint32_t groups = (uint32_t)(W + FE_COL_THREADS - 1) / FE_COL_THREADS;
     uint32_t item = blockIdx.x;                                                         // (frame, 256-column group): fe_core.h
@@ -224,9 +182,6 @@ __global__ __launch_bounds__(FE_COL_THREADS) void dg_fe_columns(FeParams P) {
         if (active) P.cnt[(size_t)f * (size_t)W + (size_t)x] = c.nsp;
         if (active && c.ovf) atomicOr(&P.flags[f], c.ovf);
     }
-#ifdef DG_EXP_FE_WAVETIME
-    wavetime_report(0, wt_t0, wt_r0, (unsigned)f * (unsigned)((W + 63) / 64) + bin, f, (int)bin, (b1 - b0) | (s1 - s0) << 8, 0);
-#endif
 }
 
 // One wave per (frame, sky part): the zero-filled entries of sky visplanes draw one sky pixel at row 0
@@ -328,9 +283,6 @@ __global__ __launch_bounds__(64 * FE_SCATTER_GROUPS) void dg_fe_scatter(FeParams
                                               // launch (12 KB at the default 48 slots), so that LDS does not cap the resident workgroups
     FeU4 *lout = reinterpret_cast<FeU4 *>(lds_dyn);
     uint32_t *lkeys = lds_dyn + FE_SCATTER_STAGE * 8;
-#ifdef DG_EXP_FE_WAVETIME
-    const unsigned long long wt_t0 = clock64(), wt_r0 = wall_clock64();
-#endif
     const int f = blockIdx.y;
     const int W = P.k.W;
     const int lx = (int)(threadIdx.x & 63);
@@ -359,16 +311,9 @@ __global__ __launch_bounds__(64 * FE_SCATTER_GROUPS) void dg_fe_scatter(FeParams
         to[0] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
         to[1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};
     }
-#ifdef DG_EXP_FE_WAVETIME
-    if (!staged) { wavetime_report(1, wt_t0, wt_r0, ((unsigned)f * gridDim.x + blockIdx.x) * FE_SCATTER_GROUPS + g, f, (int)blockIdx.x, t_last - t_first, g); return; }
-#else
     if (!staged) return;
-#endif
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 2 * (t_last - t_first); i += 64 * FE_SCATTER_GROUPS) out[2 * (size_t)t_first + i] = lout[i];
-#ifdef DG_EXP_FE_WAVETIME
-    wavetime_report(1, wt_t0, wt_r0, ((unsigned)f * gridDim.x + blockIdx.x) * FE_SCATTER_GROUPS + g, f, (int)blockIdx.x, t_last - t_first, g);
-#endif
 }
 
 }  // namespace
@@ -386,9 +331,6 @@ hipError_t launch_fe(const FeParams &P, hipStream_t stream, hipEvent_t start, hi
     hipLaunchKernelGGL(dg_fe_scan, dim3((unsigned)P.n_frames), dim3(FE_SCAN_THREADS), 0, stream, P);
     hipExtLaunchKernelGGL(dg_fe_scatter, dim3((unsigned)((P.k.W + 63) / 64), (unsigned)P.n_frames), dim3(64 * FE_SCATTER_GROUPS),
                           (uint32_t)((size_t)FE_SCATTER_STAGE * 32 + (size_t)P.col_slots * 64 * 4), stream, nullptr, stop, 0, P);
-#ifdef DG_EXP_FE_WAVETIME
-    hipLaunchKernelGGL(dg_wt_report, dim3(1), dim3(64), 0, stream, (unsigned)((P.k.W + 63) / 64) * (unsigned)P.n_frames, (unsigned)((P.k.W + 63) / 64) * (unsigned)P.n_frames * FE_SCATTER_GROUPS);
-#endif
     return hipGetLastError();
 }
 

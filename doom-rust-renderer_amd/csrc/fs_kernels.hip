@@ -25,12 +25,6 @@ __global__ __launch_bounds__(64) void dg_fs_segs(FsParams P) {
 __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
     __shared__ FsShared S;
     const int f = (int)blockIdx.x, lane = (int)threadIdx.x;
-#ifdef DG_FS_TIMING
-    unsigned long long tm[12], tp = wall_clock64(); int tk = 0;
-#define FS_T() { const unsigned long long tn = wall_clock64(); tm[tk++] = tn - tp; tp = tn; }
-#else
-#define FS_T()
-#endif
     if (lane == 0) fs_ph_init(S);
     __syncthreads();
     fs_ph_cand_count(P, S, f, lane);
@@ -40,7 +34,6 @@ __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
     fs_ph_cand_stage(P, S, f, lane);
     fs_ph_first_clear(P, S, lane);
     __syncthreads();
-    FS_T()
     fs_ph_solids(S, lane);
     __syncthreads();
     fs_ph_keep(S, lane);
@@ -51,10 +44,8 @@ __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
     __syncthreads();
     fs_ph_kept_place(P, S, f, lane);
     __syncthreads();
-    FS_T()
     fs_ph_emit(P, S, f, lane);
     __syncthreads();
-    FS_T()
     for (uint32_t base = 0; base < P.n_mobjs; base += FS_LANES) {
         FsSpriteTmp T;
         const uint32_t n_before = S.n_sprites;
@@ -65,16 +56,12 @@ __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
         fs_ph_mobj_emit(P, S, f, lane, T, n_before);
         __syncthreads();
     }
-    FS_T()
     fs_ph_behind(P, S, f, lane);
-    FS_T()
     fs_ph_sprite_order(S, lane);
     __syncthreads();
     fs_ph_masked_when(S, lane);
     __syncthreads();
-    FS_T()
     fs_ph_seq(P, S, f, lane);
-    FS_T()
     fs_ph_bin_clear(P, S, lane);
     __syncthreads();
     fs_ph_bin_mark(P, S, lane);
@@ -85,15 +72,8 @@ __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
     __syncthreads();
     fs_ph_bin_fill(P, S, f, lane);
     __syncthreads();
-    FS_T()
     fs_ph_clean(P, f, lane);
     if (lane == 0) fs_ph_header(P, S, f);
-#ifdef DG_FS_TIMING
-    FS_T()
-    if (lane == 0 && (f == 100 || f == 500))
-        printf("[fs_frame %d] cands %u parts %u sprites %u | 100 MHz ticks: stage %llu cull %llu emit %llu mobj %llu behind %llu order+when %llu seq %llu bins %llu header %llu\n", f, S.n_cl,
-               S.n_parts, S.n_sprites, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7], tm[8]);
-#endif
 }
 
 }  // namespace

@@ -23,10 +23,8 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (contraction would break bit-exactness; the IEEE
 // divide expansion keeps its own internal FMAs, which is what makes it correctly rounded).
-// Experiment builds (make variant VARIANT=x EXTRA="-D..."; never defined in the product build; results in profiles/r02_*.md):
-//   DG_EXP_T_LDSPAD=bytes   pad the tile kernel's LDS (occupancy experiment)      DG_EXP_T_TIMING   per-wave s_memtime phase probe (device printf)
-//   DG_EXP_TILE_ROWS=n      tile rows per workgroup                               DG_ABL_NOGENERAL / _NOSOLEMAP / _NOOVL / _NOSHADE / _NOREADOUT
-//                           ablations: the kernel minus one of its parts (wrong pixels; profiles/r04_raster_tiles.md)
+// Experiment builds: make variant VARIANT=x EXTRA="-D.." builds the same sources under another name (tools/ab_variants.sh compares builds
+// on one box); the kernels themselves carry no experiment switches — measured variants live as patches under tools/experiments/.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 

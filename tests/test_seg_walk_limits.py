@@ -66,14 +66,16 @@ def _render_all_front_ends(dg, osc, sc, views, W, H, expect_redone):
     refs = [np.frombuffer(osc.render(W, H, r), dtype=np.uint8).reshape(H, W, 3) for r in views]
     arr = dg.make_views(np.stack([r[:8] for r in views]))
     for fe in (dg.DG_FE_HOST, dg.DG_FE_DEVICE, dg.DG_FE_DEVICE_SEGS):
-        ctx = dg.Context(W, H, max_batch=len(views), slots=1, front_end=fe)
+        ctx = dg.Context(W, H, max_batch=64, slots=1, front_end=fe)       # (the list slabs scale with max_batch: these frames hold thousands of records)
         ctx.upload_scene(sc)
         out = ctx.render(arr)
         for k, ref in enumerate(refs):
             assert np.array_equal(out[k], ref), f"front end {fe}, {W}x{H}, view {k}"
         if fe == dg.DG_FE_DEVICE_SEGS:
-            assert ctx.timing(0)["front_end"] == dg.DG_FE_DEVICE_SEGS
-            assert ctx.fallbacks()["redone_frames"] >= expect_redone, ctx.fallbacks()
+            fb, used = ctx.fallbacks(), ctx.timing(0)["front_end"]
+            # frame by frame through the host walker — or, when a flagged frame does not fit the single-frame scratch either (the flight of
+            # 900 steps: half a million spans), the whole batch through the host list path, which timing then reports
+            assert (used == dg.DG_FE_DEVICE_SEGS and fb["redone_frames"] >= expect_redone) or (expect_redone and used == dg.DG_FE_HOST and fb["front_end"] >= 1), (fb, used)
         ctx.close()
 
 
