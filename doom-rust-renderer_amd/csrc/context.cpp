@@ -554,11 +554,19 @@ int upload_fs_scene(dg_ctx *c, const Scene &sc) {
     const size_t off_lite = align_up(F * FS_LANES * 4, 256);               // [slice counters | candidate rows]: zeroed together
     c->fs_zero_bytes = off_lite + F * (size_t)P.n_segs * FS_CALLS * sizeof(uint2);
     const size_t off_leaf = align_up(c->fs_zero_bytes, 256);
-    HIP_TRY(hipMalloc((void **)&c->d_fs_scratch, off_leaf + F * P.n_leaves * 4));
+    // ... and, per frame, room for a candidate list longer than dg_fs_frame's shared memory holds (FS_CL_CAP) with its keep bits: sized by the
+    // scene (every call of every seg), so that no frame of this map is handed back to the host for its number of candidates
+    const uint32_t cl_row_cap = (P.n_segs * FS_CALLS + 31u) / 32u * 32u;
+    const size_t off_cl = align_up(off_leaf + F * P.n_leaves * 4, 256);
+    const size_t off_keep = align_up(off_cl + (cl_row_cap > FS_CL_CAP ? F * (size_t)cl_row_cap * 4 : 0), 256);
+    HIP_TRY(hipMalloc((void **)&c->d_fs_scratch, off_keep + (cl_row_cap > FS_CL_CAP ? F * (size_t)(cl_row_cap / 32) * 4 : 0)));
     c->fs_rows_dirty = true;
     P.slice_cnt = reinterpret_cast<uint32_t *>(c->d_fs_scratch);
     P.lite = reinterpret_cast<uint2 *>(c->d_fs_scratch + off_lite);
     P.leaf_base = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_leaf);
+    P.cl_rows = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_cl);
+    P.keep_rows = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_keep);
+    P.cl_row_cap = cl_row_cap > FS_CL_CAP ? cl_row_cap : 0u;
     c->fs_scene_ok = true;
     return DG_OK;
 }
@@ -601,7 +609,7 @@ bool choose_fs(dg_ctx *c, const dg_view *views, int n) {
 // DG_FE_DEVICE_SEGS: nothing of the front end runs on the host.  Per frame it ships the view (trig filled) and the DevFrame header,
 // per batch the scene's current light levels and map-object states; dg_fs_* then write the same record arrays build_batch_fe packs,
 // with fixed per-frame strides (fs_frame.h), into the slot's record slab.
-int build_batch_fs(dg_ctx *c, Slot &s, const dg_view *views, int n) {
+int build_batch_fs(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_view_state *states) {
     const auto t0 = std::chrono::steady_clock::now();
     if (n <= 0 || n > c->cfg.max_batch) return set_err(DG_ERR_CAPACITY, "batch size outside [1, max_batch]");
     const Scene &sc = *c->scene;
@@ -613,8 +621,11 @@ int build_batch_fs(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     const size_t off_frames = 0;
     const size_t off_views = align_up(off_frames + (size_t)n * sizeof(DevFrame), 256);
     const size_t off_lights = align_up(off_views + (size_t)n * sizeof(dg_view), 256);
-    const size_t off_mstate = align_up(off_lights + sc.sectors.size() * 2, 256);
-    const size_t upload = align_up(off_mstate + sc.mobjs.size() * 4, 256);
+    // per-view game state (dg_view_state): every frame gets its own copy of the two state arrays — the scene's values with the view's
+    // entries on top — instead of one copy for the batch; the kernels index them with a per-frame stride
+    const size_t state_frames = states ? (size_t)n : 1;
+    const size_t off_mstate = align_up(off_lights + state_frames * sc.sectors.size() * 2, 256);
+    const size_t upload = align_up(off_mstate + state_frames * sc.mobjs.size() * 4, 256);
     // device-written part
     const size_t off_ff = upload;
     const size_t off_parts = align_up(off_ff + (size_t)n * sizeof(FeFrame), 256);
@@ -637,15 +648,34 @@ int build_batch_fs(dg_ctx *c, Slot &s, const dg_view *views, int n) {
         std::memcpy(s.h_fe + off_views + (size_t)i * sizeof(dg_view), &v, sizeof v);
     });
     int16_t *lights = reinterpret_cast<int16_t *>(s.h_fe + off_lights);
-    for (size_t i = 0; i < sc.sectors.size(); i++) lights[i] = sc.sectors[i].light;
     int32_t *mstate = reinterpret_cast<int32_t *>(s.h_fe + off_mstate);
-    for (size_t i = 0; i < sc.mobjs.size(); i++) mstate[i] = sc.mobjs[i].sprite_frame < 0 ? -1 : sc.mobjs[i].sprite_frame * 2 + (sc.mobjs[i].full_bright ? 1 : 0);
+    std::atomic<int> bad_state{-1};
+    c->pool->parallel_for((int)state_frames, [&](int i, int) {
+        int16_t *l = lights + (size_t)i * sc.sectors.size();
+        int32_t *m = mstate + (size_t)i * sc.mobjs.size();
+        for (size_t k = 0; k < sc.sectors.size(); k++) l[k] = sc.sectors[k].light;
+        for (size_t k = 0; k < sc.mobjs.size(); k++) m[k] = sc.mobjs[k].sprite_frame < 0 ? -1 : sc.mobjs[k].sprite_frame * 2 + (sc.mobjs[k].full_bright ? 1 : 0);
+        if (!states) return;
+        const dg_view_state &st = states[i];                        // the same rules as the host walker's (frontend.cpp: Walker::apply_state): later entries win
+        for (uint32_t k = 0; k < st.n_lights; k++) {
+            if (st.lights[k].sector < 0 || (size_t)st.lights[k].sector >= sc.sectors.size()) { bad_state = i; continue; }
+            l[(size_t)st.lights[k].sector] = (int16_t)st.lights[k].light_level;
+        }
+        for (uint32_t k = 0; k < st.n_mobjs; k++) {
+            const dg_mobj_state &ms = st.mobjs[k];
+            if (ms.mobj < 0 || (size_t)ms.mobj >= sc.mobjs.size() || ms.sprite_frame >= (int32_t)sc.sprite_frames.size()) { bad_state = i; continue; }
+            m[(size_t)ms.mobj] = (ms.sprite_frame < 0 ? -1 : ms.sprite_frame) * 2 + (ms.full_bright ? 1 : 0);
+        }
+    });
+    if (bad_state >= 0) return set_err(DG_ERR_INVALID, "frame " + std::to_string(bad_state.load()) + ": view state: sector, map object or sprite frame index out of range");
 
     FsParams &Q = s.FSP;
     Q = c->fs_proto;
     Q.k = c->dk;
     Q.sector_light = reinterpret_cast<const int16_t *>(s.d_fe + off_lights);
     Q.mobj_state = reinterpret_cast<const int32_t *>(s.d_fe + off_mstate);
+    Q.light_stride = states ? (uint32_t)sc.sectors.size() : 0u;
+    Q.mstate_stride = states ? (uint32_t)sc.mobjs.size() : 0u;
     Q.views = reinterpret_cast<const dg_view *>(s.d_fe + off_views);
     Q.n_frames = n;
     Q.flags = s.d_flags;
@@ -688,7 +718,7 @@ int build_batch_fs(dg_ctx *c, Slot &s, const dg_view *views, int n) {
     s.max_spans = 0; s.n_spans = 0; s.covered = 0; s.n_frames = n; s.n_walls = 0; s.n_planes = 0;
     s.list_bytes = upload;
     s.fe_mode = true; s.fs_mode = true; s.fe_check = false;
-    s.keep_states(nullptr, n);
+    s.keep_states(states, n);
     s.snapshot_scene(sc);
     s.host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HIP_TRY(hipMemcpyAsync(s.d_fe, s.h_fe, upload, hipMemcpyHostToDevice, s.stream));
@@ -696,8 +726,8 @@ int build_batch_fs(dg_ctx *c, Slot &s, const dg_view *views, int n) {
 }
 
 int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *given, int n, const dg_view_state *states = nullptr) {
-    if (!given && !states && c->fs_enabled && c->fs_scene_ok && choose_fs(c, views, n)) {
-        const int rc = build_batch_fs(c, s, views, n);
+    if (!given && c->fs_enabled && c->fs_scene_ok && choose_fs(c, views, n)) {
+        const int rc = build_batch_fs(c, s, views, n, states);
         if (rc != kPartsUnsupported) return rc;
     }
     if (!given && c->fe_enabled && c->fe_scene_ok) {

@@ -33,13 +33,13 @@ constexpr int FS_LANES = 256;                  // threads of dg_fs_frame's workg
 constexpr int FS_CALLS = 5;                    // process_sidedef calls a seg can make (segs.rs:493-588)
 constexpr int FS_BLOCK = 16;                   // lanes per block of the two-level prefix sums
 constexpr uint32_t FS_PART_CAP = 256;          // parts of one frame after the hidden-part culling
-constexpr uint32_t FS_CL_CAP = 3072;           // candidate parts of one frame the culling stages in shared memory
+constexpr uint32_t FS_CL_CAP = 1536;           // candidate parts of one frame the culling stages in shared memory (more: the frame's rows in global memory, FsParams::cl_rows)
 constexpr int FS_MAX_W = 2560;                 // widest frame the culling's per-column table holds (wider: DG_FE_DEVICE)
 constexpr int FS_GROUP = 16;                   // lanes that share one candidate in the column passes of the culling
-constexpr uint32_t FS_SPRITE_CAP = 256;        // visible map objects of one frame
+constexpr uint32_t FS_SPRITE_CAP = 512;        // visible map objects of one frame
 constexpr uint32_t FS_SKY_CAP = 64;            // parts of one frame that may produce sky visplanes (event rows of dg_fe_gaps)
 constexpr uint32_t FS_BIN_CAP = 4096;          // (part, column bin) pairs of one frame
-constexpr uint32_t FS_SBIN_CAP = 2048;         // (sprite, column bin) pairs
+constexpr uint32_t FS_SBIN_CAP = 4096;         // (sprite, column bin) pairs
 constexpr uint32_t FS_BEHIND_WORDS = FS_PART_CAP / 32;
 
 struct FsNode { float x, y, dx, dy; uint32_t segs_right, segs_left; };       // partition line + seg counts of the two subtrees
@@ -55,8 +55,9 @@ struct FsParams {
     const FsNode *nodes; const uint32_t *anc_off; const uint32_t *anc;           // per leaf: its ancestors, root first: node | (lies in the LEFT subtree) << 31
     uint32_t n_segs, n_leaves, n_mobjs;
     // game state of this batch (scene-wide values as of submission)
-    const int16_t *sector_light;               // [n_sectors]
-    const int32_t *mobj_state;                 // [n_mobjs] sprite_frame * 2 + full_bright, negative: S_NULL
+    const int16_t *sector_light;               // [n_sectors] for the whole batch (light_stride 0), or [n_frames][light_stride]: per-view game state
+    const int32_t *mobj_state;                 // [n_mobjs] / [n_frames][mstate_stride]: sprite_frame * 2 + full_bright, negative: S_NULL
+    uint32_t light_stride, mstate_stride;      // elements per frame of the two arrays above; 0: one array for every frame (lights.rs:47-259, map_objects.rs:63-121)
     // per frame
     const dg_view *views;                      // [n_frames], trig filled
     int32_t n_frames;
@@ -66,6 +67,10 @@ struct FsParams {
     // for a call that reaches its column loop (dg_fs_segs): the frame's candidate parts, already in the reference's visit order
     uint2 *lite;
     uint32_t *slice_cnt;                       // [frame][FS_LANES], zeroed per batch: parts in each lane's slice of the frame's row (dg_fs_frame's prefix sums start from these)
+    // a frame with more candidate parts than dg_fs_frame stages in shared memory (FS_CL_CAP) keeps its candidate list and keep bits here:
+    // [frame][cl_row_cap] words + [frame][cl_row_cap / 32] words (cl_row_cap: a multiple of 32, = n_segs x FS_CALLS rounded up; 0: none)
+    uint32_t *cl_rows, *keep_rows;
+    uint32_t cl_row_cap;
     uint32_t *flags;                           // [frame] FE_OVF_* (the column walk's flag words)
     // outputs: the DG_FE_DEVICE record arrays with fixed per-frame strides
     FeFrame *fframes; FePart *parts; FeSprite *sprites; uint32_t *behind; uint32_t *sky_parts;
@@ -131,7 +136,7 @@ DG_HD void fs_seg_lane(const FsParams &P, int f, uint32_t si) {
     const dg_view &v = P.views[f];
     const FsSeg &sg = P.segs[si];
     FsSegOut so;
-    const int16_t light = sg.front_sector >= 0 ? P.sector_light[sg.front_sector] : (int16_t)0;
+    const int16_t light = sg.front_sector >= 0 ? P.sector_light[(size_t)f * P.light_stride + (size_t)sg.front_sector] : (int16_t)0;
     const int32_t st = fs_seg(P.k, sg, P.sectors, P.anims, V2{v.x, v.y}, v.cos_na, v.sin_na, v.floor_height + 41.0f, v.timestamp, light, so);
     if (st == FS_SKIP) return;
     if (st != FS_OK) { fs_flag(P, f, FE_OVF_SEGS); return; }
@@ -157,8 +162,9 @@ DG_HD void fs_seg_lane(const FsParams &P, int f, uint32_t si) {
 struct FsShared {                              // LDS on the GPU
     uint32_t lane_cnt[FS_LANES], block_sum[FS_LANES / FS_BLOCK];
     uint32_t first[FS_MAX_W];                  // per screen column: visit index of the first full-height solid candidate that spans it
-    uint32_t cl[FS_CL_CAP];                    // the frame's candidate parts in visit order: sx | ex << 12 | FEP_* << 24
+    uint32_t cl[FS_CL_CAP];                    // the frame's candidate parts in visit order: sx | ex << 12 | FEP_* << 24 (more than FS_CL_CAP: FsParams::cl_rows)
     uint32_t keepw[FS_CL_CAP / 32];            // bit k: candidate k survives the hidden-part culling
+    uint32_t cl_big;                           // the frame's list lives in global memory
     uint32_t lane_k0[FS_LANES];                // index in cl[] of the first candidate of the lane's slice of the lite row
     uint32_t n_cl;
     // kept parts
@@ -178,7 +184,12 @@ struct FsShared {                              // LDS on the GPU
 };
 
 // phase 0 (lane 0): reset
-DG_HD void fs_ph_init(FsShared &S) { S.n_cl = 0; S.n_parts = 0; S.n_sky = 0; S.n_sprites = 0; S.fail = 0; }
+DG_HD void fs_ph_init(FsShared &S) { S.n_cl = 0; S.n_parts = 0; S.n_sky = 0; S.n_sprites = 0; S.fail = 0; S.cl_big = 0; }
+// The frame's candidate list / keep bits: shared memory, or the frame's rows in global memory when there are more than FS_CL_CAP (a map of
+// doom2's scale seen down its long axis: ten thousand).  The same code walks both (a generic pointer); the phases are separated by
+// workgroup barriers, which order the global accesses of a workgroup as well.
+DG_HD uint32_t *fs_cl(const FsParams &P, FsShared &S, int f) { return S.cl_big ? P.cl_rows + (size_t)f * P.cl_row_cap : S.cl; }
+DG_HD uint32_t *fs_keepw(const FsParams &P, FsShared &S, int f) { return S.cl_big ? P.keep_rows + (size_t)f * (P.cl_row_cap / 32) : S.keepw; }
 
 // Two-level exclusive prefix over lane_cnt[]: a phase in which the first FS_LANES / FS_BLOCK lanes sum their block, then any lane adds
 // the blocks before its own and the lanes before it in its block (at most 2 FS_BLOCK reads instead of FS_LANES).
@@ -202,14 +213,21 @@ DG_HD void fs_ph_cand_stage(const FsParams &P, FsShared &S, int f, int lane) {
     const uint32_t n = P.n_segs * FS_CALLS;
     uint32_t at = fs_lane_offset(S, lane);
     S.lane_k0[lane] = at;
+    uint32_t total = 0;                                               // (every lane: where the list goes is decided before anything is written)
+    for (int b = 0; b < FS_LANES / FS_BLOCK; b++) total += S.block_sum[b];
+    const bool big = total > FS_CL_CAP, fits = !big || total <= P.cl_row_cap;
     if (lane == FS_LANES - 1) {
-        S.n_cl = at + S.lane_cnt[lane];
-        if (S.n_cl > FS_CL_CAP) { S.fail = 1; S.n_cl = 0; }
+        S.n_cl = fits ? total : 0u;
+        S.cl_big = big && fits;
+        if (!fits) S.fail = 1;
     }
-    if (lane < (int)(FS_CL_CAP / 32)) S.keepw[lane] = 0;
+    if (!fits) return;
+    uint32_t *cl = big ? P.cl_rows + (size_t)f * P.cl_row_cap : S.cl;
+    uint32_t *keepw = big ? P.keep_rows + (size_t)f * (P.cl_row_cap / 32) : S.keepw;
+    for (uint32_t w = (uint32_t)lane; w < (big ? (total + 31u) / 32u : FS_CL_CAP / 32u); w += FS_LANES) keepw[w] = 0;
     fs_for_slice(P.lite + (size_t)f * n, n, fs_slice_len(P.n_segs), lane, [&](uint32_t, const uint2 q) {
         if (!(q.y & 0x100u)) return;
-        if (at < FS_CL_CAP) S.cl[at] = (q.x & 0xfffu) | ((q.x >> 16) << 12) | (q.y << 24);
+        cl[at] = (q.x & 0xfffu) | ((q.x >> 16) << 12) | (q.y << 24);
         at++;
     });
 }
@@ -241,36 +259,40 @@ DG_HD void fs_min_u32(uint32_t *p, uint32_t v) {
 #endif
 }
 // phases 2d / 2e: FS_GROUP lanes share a candidate and stride over its columns; the groups take the candidates round robin.
-DG_HD void fs_ph_solids(FsShared &S, int lane) {
+DG_HD void fs_ph_solids(const FsParams &P, FsShared &S, int f, int lane) {
     if (S.fail) return;
     const uint32_t g = (uint32_t)lane / FS_GROUP, sub = (uint32_t)lane % FS_GROUP;
+    const uint32_t *cl = fs_cl(P, S, f);
     for (uint32_t k = g; k < S.n_cl; k += FS_LANES / FS_GROUP) {
-        const uint32_t q = S.cl[k];
+        const uint32_t q = cl[k];
         if (!fs_part_is_solid(q >> 24)) continue;
         const uint32_t sx = q & 0xfffu, ex = (q >> 12) & 0xfffu;
         for (uint32_t c = sx + sub; c <= ex; c += FS_GROUP) fs_min_u32(&S.first[c], k);
     }
 }
-DG_HD void fs_ph_keep(FsShared &S, int lane) {
+DG_HD void fs_ph_keep(const FsParams &P, FsShared &S, int f, int lane) {
     if (S.fail) return;
     const uint32_t g = (uint32_t)lane / FS_GROUP, sub = (uint32_t)lane % FS_GROUP;
+    const uint32_t *cl = fs_cl(P, S, f);
+    uint32_t *keepw = fs_keepw(P, S, f);
     for (uint32_t k = g; k < S.n_cl; k += FS_LANES / FS_GROUP) {
-        const uint32_t q = S.cl[k];
+        const uint32_t q = cl[k];
         const uint32_t sx = q & 0xfffu, ex = (q >> 12) & 0xfffu;
         bool open = false;
         for (uint32_t c = sx + sub; c <= ex; c += FS_GROUP) open |= S.first[c] >= k;
-        if (open) fs_or_u32(&S.keepw[k >> 5], 1u << (k & 31u));
+        if (open) fs_or_u32(&keepw[k >> 5], 1u << (k & 31u));
     }
 }
 // phases 2f / 2g: the survivors get their place in the frame's part list (and their sky event slot).  Lane l walks its slice of the lite
 // row again (candidate indices from lane_k0); lane_cnt packs (survivors | survivors that want a sky slot << 16).
-DG_HD void fs_ph_kept_count(FsShared &S, int lane) {
+DG_HD void fs_ph_kept_count(const FsParams &P, FsShared &S, int f, int lane) {
     // (flags of candidate k: cl[k] >> 24)
     uint32_t c = 0;
     if (!S.fail) {
+        const uint32_t *cl = fs_cl(P, S, f), *keepw = fs_keepw(P, S, f);
         const uint32_t k1 = lane + 1 < FS_LANES ? S.lane_k0[lane + 1] : S.n_cl;
         for (uint32_t k = S.lane_k0[lane]; k < k1; k++)
-            if ((S.keepw[k >> 5] >> (k & 31u)) & 1u) c += 1u + (fs_part_wants_sky_slot(S.cl[k] >> 24) ? 0x10000u : 0u);
+            if ((keepw[k >> 5] >> (k & 31u)) & 1u) c += 1u + (fs_part_wants_sky_slot(cl[k] >> 24) ? 0x10000u : 0u);
     }
     S.lane_cnt[lane] = c;
 }
@@ -284,10 +306,11 @@ DG_HD void fs_ph_kept_place(const FsParams &P, FsShared &S, int f, int lane) {
         if (S.n_parts > FS_PART_CAP || S.n_sky > FS_SKY_CAP) { S.fail = 1; S.n_parts = 0; S.n_sky = 0; }
     }
     if (S.fail || S.lane_cnt[lane] == 0u) return;                        // (no survivor in this lane's slice: nothing to look up)
+    const uint32_t *keepw = fs_keepw(P, S, f);
     uint32_t k = S.lane_k0[lane];
     fs_for_slice(P.lite + (size_t)f * n, n, fs_slice_len(P.n_segs), lane, [&](uint32_t i, const uint2 q) {
         if (!(q.y & 0x100u)) return;
-        const bool kept = (S.keepw[k >> 5] >> (k & 31u)) & 1u;
+        const bool kept = (keepw[k >> 5] >> (k & 31u)) & 1u;
         k++;
         if (!kept) return;
         const bool wants = fs_part_wants_sky_slot(q.y & 0xffu);
@@ -310,7 +333,7 @@ DG_HD void fs_ph_emit(const FsParams &P, FsShared &S, int f, int lane) {
         const FsSeg &sg = P.segs[src >> 3];
         FsSegOut so;
         FePart p;
-        const int32_t st = fs_seg(P.k, sg, P.sectors, P.anims, V2{v.x, v.y}, v.cos_na, v.sin_na, v.floor_height + 41.0f, v.timestamp, P.sector_light[sg.front_sector], so);
+        const int32_t st = fs_seg(P.k, sg, P.sectors, P.anims, V2{v.x, v.y}, v.cos_na, v.sin_na, v.floor_height + 41.0f, v.timestamp, P.sector_light[(size_t)f * P.light_stride + (size_t)sg.front_sector], so);
         if (st != FS_OK || fs_part(P.k, so, fs_call(so, src & 7u), P.bitmaps, P.flat_sky, v.floor_height, p) != FS_OK) { S.fail = 1; continue; }   // (cannot happen: dg_fs_segs passed it)
         p.sky_slot = S.kept_sky[o];
         P.parts[(size_t)f * FS_PART_CAP + o] = p;
@@ -325,12 +348,12 @@ DG_HD void fs_ph_mobj(const FsParams &P, FsShared &S, int f, uint32_t base, int 
     T.status = FS_SKIP;
     const uint32_t mi = base + (uint32_t)lane;
     if (S.fail || mi >= P.n_mobjs) return;
-    const int32_t st = P.mobj_state[mi];
+    const int32_t st = P.mobj_state[(size_t)f * P.mstate_stride + mi];
     if (st < 0) return;                                                // S_NULL (renderer/map_objects.rs:37)
     const dg_view &v = P.views[f];
     const FsMobj &m = P.mobjs[mi];
     T.status = fs_mobj(P.k, m, P.sframes[st >> 1], P.bitmaps, P.sectors, V2{v.x, v.y}, v.angle, v.cos_na, v.sin_na, v.floor_height + 41.0f, st & 1,
-                       m.sector >= 0 ? P.sector_light[m.sector] : (int16_t)0, T.so);
+                       m.sector >= 0 ? P.sector_light[(size_t)f * P.light_stride + (size_t)m.sector] : (int16_t)0, T.so);
     if (T.status == FS_OK) S.lane_cnt[lane] = 1;
     else if (T.status != FS_SKIP) S.fail = 1;                          // a failure (every lane that sees one writes the same 1)
 }
@@ -413,15 +436,18 @@ DG_HD void fs_ph_seq(const FsParams &P, FsShared &S, int f, int lane) {
 // phases 9a .. 9e: the column bins (frontend.cpp bin_by_columns: for every FE_BIN_W-column strip the parts, and the sprites, that touch
 // it, in order).  A bin's members are a bit mask over the part (sprite) indices — set by one lane per part, counted per bin, and a
 // member's place in its bin's list is the number of mask bits below its own.  The masks live in first[], which is dead by now.
-constexpr uint32_t FS_MASK_WORDS = 8;          // 256 parts / sprites
-static_assert(FS_PART_CAP <= 32 * FS_MASK_WORDS && FS_SPRITE_CAP <= 32 * FS_MASK_WORDS, "bin masks");
-static_assert((FS_MAX_W / FE_BIN_W) * (2 * FS_MASK_WORDS + 2) <= FS_MAX_W, "bin masks fit first[]");
-DG_HD uint32_t *fs_bin_mask(FsShared &S, uint32_t nb, uint32_t kind, uint32_t b) { return S.first + (kind * nb + b) * FS_MASK_WORDS; }   // kind 0 parts, 1 sprites
-DG_HD uint32_t *fs_bin_off(FsShared &S, uint32_t nb, uint32_t kind) { return S.first + 2 * nb * FS_MASK_WORDS + kind * nb; }
+constexpr uint32_t FS_PMASK_WORDS = FS_PART_CAP / 32, FS_SMASK_WORDS = FS_SPRITE_CAP / 32;   // mask words per bin: parts, sprites
+static_assert(FS_PART_CAP % 32 == 0 && FS_SPRITE_CAP % 32 == 0, "bin masks");
+static_assert((FS_MAX_W / FE_BIN_W) * (FS_PMASK_WORDS + FS_SMASK_WORDS + 2) <= FS_MAX_W, "bin masks fit first[]");
+DG_HD uint32_t fs_mask_words(uint32_t kind) { return kind ? FS_SMASK_WORDS : FS_PMASK_WORDS; }
+DG_HD uint32_t *fs_bin_mask(FsShared &S, uint32_t nb, uint32_t kind, uint32_t b) {     // kind 0 parts, 1 sprites
+    return kind ? S.first + nb * FS_PMASK_WORDS + b * FS_SMASK_WORDS : S.first + b * FS_PMASK_WORDS;
+}
+DG_HD uint32_t *fs_bin_off(FsShared &S, uint32_t nb, uint32_t kind) { return S.first + nb * (FS_PMASK_WORDS + FS_SMASK_WORDS) + kind * nb; }
 DG_HD uint32_t fs_popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
 DG_HD void fs_ph_bin_clear(const FsParams &P, FsShared &S, int lane) {
     const uint32_t nb = (uint32_t)(P.k.W + FE_BIN_W - 1) / FE_BIN_W;
-    for (uint32_t i = (uint32_t)lane; i < nb * (2 * FS_MASK_WORDS + 2); i += FS_LANES) S.first[i] = 0u;
+    for (uint32_t i = (uint32_t)lane; i < nb * (FS_PMASK_WORDS + FS_SMASK_WORDS + 2); i += FS_LANES) S.first[i] = 0u;
 }
 DG_HD void fs_ph_bin_mark(const FsParams &P, FsShared &S, int lane) {
     if (S.fail) return;
@@ -436,7 +462,7 @@ DG_HD void fs_ph_bin_count(const FsParams &P, FsShared &S, int lane) {
     for (uint32_t i = (uint32_t)lane; i < 2 * nb; i += FS_LANES) {
         const uint32_t *m = fs_bin_mask(S, nb, i / nb, i % nb);
         uint32_t c = 0;
-        for (uint32_t w = 0; w < FS_MASK_WORDS; w++) c += fs_popc(m[w]);
+        for (uint32_t w = 0; w < fs_mask_words(i / nb); w++) c += fs_popc(m[w]);
         fs_bin_off(S, nb, i / nb)[i % nb] = c;
     }
 }

@@ -34,11 +34,11 @@ __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
     fs_ph_cand_stage(P, S, f, lane);
     fs_ph_first_clear(P, S, lane);
     __syncthreads();
-    fs_ph_solids(S, lane);
+    fs_ph_solids(P, S, f, lane);
     __syncthreads();
-    fs_ph_keep(S, lane);
+    fs_ph_keep(P, S, f, lane);
     __syncthreads();
-    fs_ph_kept_count(S, lane);
+    fs_ph_kept_count(P, S, f, lane);
     __syncthreads();
     fs_ph_block_sums(S, lane);
     __syncthreads();

@@ -552,6 +552,8 @@ int emul_frame_lists(void *scene, int W, int H, const dg_view *view_in, int32_t 
 // itself refuses the frame (then the device walk must have flagged it), 2 when the device walk gave the frame up because it exceeds a
 // capacity (stats[4]: 1 parts, 2 candidates, 4 sprites, 8 sky parts, 16 part bins, 32 sprite bins), 3 when it gave it up for no such
 // reason, < 0 with emul_last_error on a mismatch.
+static bool g_no_cl_rows = false;          // emul_fs_no_cl_rows(1): as if the ctx could not allocate the global candidate rows (FS_CL_CAP is the limit then)
+extern "C" void emul_fs_no_cl_rows(int on) { g_no_cl_rows = on != 0; }
 extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, uint64_t *stats) {
     const Scene &sc = *(const Scene *)scene;
     if (!sc.fs_ok || W > FS_MAX_W) { g_err = "scene / frame size not eligible for the device seg walk"; return -100; }
@@ -582,6 +584,9 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     P.sector_light = lights.data(); P.mobj_state = mstate.data();
     P.views = &view; P.n_frames = 1;
     std::vector<uint32_t> slice_cnt(FS_LANES, 0);
+    const uint32_t cl_row_cap = (P.n_segs * FS_CALLS + 31u) / 32u * 32u;                                  // (context.cpp: upload_fs_scene)
+    std::vector<uint32_t> cl_rows(cl_row_cap, 0xdeadbeefu), keep_rows(cl_row_cap / 32, 0xdeadbeefu);
+    P.cl_rows = cl_rows.data(); P.keep_rows = keep_rows.data(); P.cl_row_cap = g_no_cl_rows ? 0u : cl_row_cap;
     P.leaf_base = leaf_base.data(); P.lite = lite.data(); P.slice_cnt = slice_cnt.data(); P.flags = flags.data();
     P.fframes = ffr.data(); P.parts = parts.data(); P.sprites = sprites.data(); P.behind = behind.data(); P.sky_parts = sky_parts.data();
     P.bin_off = bin_off.data(); P.bin_parts = bin_parts.data(); P.sbin_off = sbin_off.data(); P.sbin_sprites = sbin_sprites.data();
@@ -598,9 +603,9 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     LANES(fs_ph_block_sums(S, lane))
     LANES(fs_ph_cand_stage(P, S, 0, lane))
     LANES(fs_ph_first_clear(P, S, lane))
-    LANES(fs_ph_solids(S, lane))
-    LANES(fs_ph_keep(S, lane))
-    LANES(fs_ph_kept_count(S, lane))
+    LANES(fs_ph_solids(P, S, 0, lane))
+    LANES(fs_ph_keep(P, S, 0, lane))
+    LANES(fs_ph_kept_count(P, S, 0, lane))
     LANES(fs_ph_block_sums(S, lane))
     LANES(fs_ph_kept_place(P, S, 0, lane))
     LANES(fs_ph_emit(P, S, 0, lane))
@@ -631,7 +636,7 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
         return 1;
     }
     if (flags[0] & FE_OVF_SEGS) {                     // given up on the device although the host walker completes the frame: only a NAMED capacity may do that
-        const uint32_t why = (arena.parts.size() > FS_PART_CAP ? 1u : 0u) | (n_cand > FS_CL_CAP ? 2u : 0u) | (arena.sprites.size() > FS_SPRITE_CAP ? 4u : 0u) |
+        const uint32_t why = (arena.parts.size() > FS_PART_CAP ? 1u : 0u) | (n_cand > std::max(FS_CL_CAP, P.cl_row_cap) ? 2u : 0u) | (arena.sprites.size() > FS_SPRITE_CAP ? 4u : 0u) |
                              (arena.n_sky_slots > FS_SKY_CAP ? 8u : 0u) | (arena.bin_off[nb] > FS_BIN_CAP ? 16u : 0u) | (arena.sbin_off[nb] > FS_SBIN_CAP ? 32u : 0u);
         if (stats) stats[4] = why;
         if (!why) { g_err = "the device seg walk gave up a frame that exceeds none of its capacities and that the host walker completes"; return 3; }

@@ -29,6 +29,8 @@ def lib():
         L.emul_render_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(DgView), ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
                                         ctypes.c_uint32, ctypes.c_void_p]
         L.emul_fs_frame.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(DgView), ctypes.POINTER(ctypes.c_uint64)]
+        L.emul_fs_no_cl_rows.argtypes = [ctypes.c_int]
+        L.emul_fs_no_cl_rows.restype = None
         L.emul_sprite_frame.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint8]
         L.emul_set_sector_light.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int16]
         L.emul_set_mobj_state.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint8, ctypes.c_int]

@@ -715,7 +715,7 @@ def test_rerendering_a_slot_completes_its_pending_readback_first(dg, scene1993, 
     ctx.close()
 
 
-@pytest.mark.parametrize("front_end", [1, 2], ids=["host-lists", "device-column-walk"])
+@pytest.mark.parametrize("front_end", [1, 2, 3], ids=["host-lists", "device-column-walk", "device-seg-walk"])
 def test_per_view_game_state_in_one_batch(dg, oracle, wad1993, path1993, front_end):
     """F4 / dg_view_state: every frame of a batch carries its own light levels and map-object states, as a recorded play-through
     would (src/lights.rs:47-259, src/map_objects.rs:63-121); each frame equals the oracle after the same changes to its scene."""
@@ -744,6 +744,7 @@ def test_per_view_game_state_in_one_batch(dg, oracle, wad1993, path1993, front_e
     views = dg.make_views(path1993[idx])
     st, keep = dg.make_view_states(states)
     out = ctx.render_state(views, st)
+    assert ctx.timing(0)["front_end"] == front_end                         # (the seg walk takes per-view state too: per-frame state arrays, fs_frame.h)
     for k, i in enumerate(idx):
         assert np.array_equal(out[k], refs[k]), f"frame {i}"
     plain = ctx.render(views)                                              # the scene itself is untouched

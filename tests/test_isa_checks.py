@@ -21,7 +21,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "doom-rust-renderer_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"]   # = csrc/Makefile
+def _makefile_flags():
+    """The product's own compile flags (csrc/Makefile: FLAGS), minus what only matters for linking a shared library."""
+    txt = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "doom-rust-renderer_amd", "csrc", "Makefile")).read()
+    line = re.search(r"^FLAGS\s*=\s*(.*)$", txt, re.M).group(1)
+    return [f.replace("$(ARCH)", "gfx950") for f in line.split() if f not in ("-fPIC",) and not f.startswith("-W")]
+
+
+FLAGS = _makefile_flags()
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 

@@ -14,7 +14,7 @@ import pytest
 sys.path.insert(0, os.path.dirname(__file__))
 from test_hand_wad import build_polygon_iwad  # noqa: E402
 
-FS_PART_CAP, FS_CL_CAP, FS_SPRITE_CAP, FS_SKY_CAP, FS_BIN_CAP, FS_MAX_W = 256, 3072, 256, 64, 4096, 2560   # csrc/fs_frame.h
+FS_PART_CAP, FS_CL_CAP, FS_SPRITE_CAP, FS_SKY_CAP, FS_BIN_CAP, FS_MAX_W = 256, 1536, 512, 64, 4096, 2560   # csrc/fs_frame.h
 
 
 def _capacities_from_header():
@@ -30,7 +30,7 @@ def test_the_capacities_this_file_assumes_are_the_header_s():
 
 
 LIMIT_VIEWS = {                     # map -> (builder, views (x, y, angle), frame size, the capacity bit tests/emul reports: emul.cpp emul_fs_frame)
-    "sprites": (lambda: build_polygon_iwad(n_walls=64, radius=3000, n_things=420), [(-2900.0, 10.0, 0.02), (2880.0, -25.0, math.pi - 0.1)], (1280, 200), 4),
+    "sprites": (lambda: build_polygon_iwad(n_walls=64, radius=3000, n_things=900), [(-2900.0, 10.0, 0.02), (2880.0, -25.0, math.pi - 0.1)], (1280, 200), 4),
     "sky parts": (lambda: build_polygon_iwad(n_walls=240, radius=3000, ceil_flat="F_SKY1"), [(-2950.0, 10.0, 0.02), (100.0, -2940.0, math.pi / 2 + 0.3)], (1280, 200), 8),
     "candidates": (lambda: _limit_wad("long flight"), [(-32.0, 0.0, 0.0), (-20.0, 300.0, 0.05)], (640, 160), 2),
     "part bins": (lambda: _limit_wad("staircase"), [(-32.0, 0.0, 0.0), (-20.0, 300.0, 0.05)], (2560, 120), 16),
@@ -49,8 +49,16 @@ def test_each_limit_map_exceeds_the_capacity_it_is_named_after(campath_mod, whic
     es = emul_bind.EmulScene(wad)
     for (x, y, a) in pts:
         rec = _view(campath_mod, osc, x, y, a)
-        rc, st = es.fs_frame(W, H, rec)
+        if which == "candidates":             # FS_CL_CAP is the limit only where the ctx has no global candidate rows (a scene with few segs, or no memory for them)
+            emul_bind.lib().emul_fs_no_cl_rows(1)
+        try:
+            rc, st = es.fs_frame(W, H, rec)
+        finally:
+            emul_bind.lib().emul_fs_no_cl_rows(0)
         assert rc == 2 and (st[4] & bit), (which, rc, st)
+        if which == "candidates":             # with them (context.cpp: upload_fs_scene sizes them by the scene) the list is no reason any more: these frames then exceed FS_PART_CAP
+            rc, st = es.fs_frame(W, H, rec)
+            assert rc == 2 and not (st[4] & bit) and (st[4] & 1) and st[5] > FS_CL_CAP, (rc, st)
         assert es.render(W, H, rec)[0] == osc.render(W, H, rec)
     if which == "part bins":                                  # the same frames at half the width fit
         rc, st = es.fs_frame(1280, H, _view(campath_mod, osc, *pts[0]))
@@ -81,11 +89,11 @@ def _render_all_front_ends(dg, osc, sc, views, W, H, expect_redone):
 
 @pytest.mark.gpu
 def test_more_visible_map_objects_than_the_seg_walk_holds(dg, campath_mod):
-    """FS_SPRITE_CAP: an open hall (64 walls: few parts) with 420 imps and barrels on five rings; from the wall, looking across, most are in view."""
+    """FS_SPRITE_CAP: an open hall (64 walls: few parts) with 900 imps and barrels on five rings; from the wall, looking across, most are in view."""
     import doomref
-    wad = build_polygon_iwad(n_walls=64, radius=3000, n_things=420)
+    wad = build_polygon_iwad(n_walls=64, radius=3000, n_things=900)
     osc = doomref.Scene(wad, "e1m1")
-    assert osc.mobj_count() == 420
+    assert osc.mobj_count() == 900
     sc = dg.Scene(wad, "e1m1")
     views = [_view(campath_mod, osc, -2900.0, 10.0, 0.02), _view(campath_mod, osc, 2880.0, -25.0, math.pi - 0.1), _view(campath_mod, osc, 0.0, 0.0, 0.7)]
     _render_all_front_ends(dg, osc, sc, views, 1280, 200, expect_redone=2)      # (from the centre a quarter of them: that frame stays on the GPU)
@@ -183,3 +191,23 @@ def test_the_widest_frame_the_seg_walk_takes_and_the_first_it_does_not(dg, wad19
             assert np.array_equal(out[k], np.frombuffer(oracle_scene_heavy.render(W, H, path_heavy[i]), dtype=np.uint8).reshape(H, W, 3)), f"{W} columns, frame {i}"
         ctx.close()
     scene_heavy.close()
+
+
+def test_more_candidates_than_shared_memory_holds_stay_on_the_gpu_walk(synth, campath_mod):
+    """A map of doom2's scale seen down its long axes: up to ten thousand candidate parts per frame, a hundred of which survive the hidden-part
+    culling.  dg_fs_frame keeps such a list in the frame's global rows (FsParams::cl_rows) instead of shared memory; on the CPU (tests/emul)
+    its records equal the host walker's byte for byte, and only frames with more than FS_SPRITE_CAP map objects in view are still given up."""
+    import doomref
+    import emul_bind
+    wad = synth.build_synth_iwad(2002, heavy=True, vanilla=True, grid=(32, 24), n_things=500)
+    osc = doomref.Scene(wad, "e1m1")
+    es = emul_bind.EmulScene(wad)
+    route = synth.synth_route(2002, heavy=True, vanilla=True, grid=(32, 24), n_things=500)
+    path = campath_mod.make_camera_path(route, osc.floor_height_at, 4000)[::40]
+    big = given_up = 0
+    for rec in path:
+        rc, st = es.fs_frame(1280, 800, rec)
+        assert rc == 0 or (rc == 2 and st[4] == 4), (rc, st)          # identical records, or too many sprites — never the candidate list
+        big += rc == 0 and st[5] > FS_CL_CAP
+        given_up += rc != 0
+    assert big >= 20 and given_up <= 30, (big, given_up)
