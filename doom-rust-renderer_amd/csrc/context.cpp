@@ -228,7 +228,7 @@ struct dg_ctx {
     int host_samples = 0;               // batches the host walker was timed on (the first one pays for cold caches and arena growth: not counted)
     int since_probe = 0;                // seg-walk batches since the host walker was last timed (it is timed again every 32 batches)
     uint8_t *d_fs_scene = nullptr;
-    uint8_t *d_fs_scratch = nullptr;    // candidate rows F x n_segs x 5 x 8 B (zeroed per batch) | leaf_base F x n_leaves
+    uint8_t *d_fs_scratch = nullptr;    // candidate rows F x n_segs x 5 x 8 B (zeroed per batch) | candidate lists + keep bits of frames beyond FS_CL_CAP
     size_t fs_zero_bytes = 0;
     FsParams fs_proto{};                // scene pointers and counts, filled at upload
     uint64_t fallbacks_fe = 0;          // batches in which frames were redone because a device-side capacity was exceeded (dg_ctx_fallbacks)
@@ -557,13 +557,12 @@ int upload_fs_scene(dg_ctx *c, const Scene &sc) {
     // ... and, per frame, room for a candidate list longer than dg_fs_frame's shared memory holds (FS_CL_CAP) with its keep bits: sized by the
     // scene (every call of every seg), so that no frame of this map is handed back to the host for its number of candidates
     const uint32_t cl_row_cap = (P.n_segs * FS_CALLS + 31u) / 32u * 32u;
-    const size_t off_cl = align_up(off_leaf + F * P.n_leaves * 4, 256);
+    const size_t off_cl = off_leaf;
     const size_t off_keep = align_up(off_cl + (cl_row_cap > FS_CL_CAP ? F * (size_t)cl_row_cap * 4 : 0), 256);
     HIP_TRY(hipMalloc((void **)&c->d_fs_scratch, off_keep + (cl_row_cap > FS_CL_CAP ? F * (size_t)(cl_row_cap / 32) * 4 : 0)));
     c->fs_rows_dirty = true;
     P.slice_cnt = reinterpret_cast<uint32_t *>(c->d_fs_scratch);
     P.lite = reinterpret_cast<uint2 *>(c->d_fs_scratch + off_lite);
-    P.leaf_base = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_leaf);
     P.cl_rows = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_cl);
     P.keep_rows = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_keep);
     P.cl_row_cap = cl_row_cap > FS_CL_CAP ? cl_row_cap : 0u;

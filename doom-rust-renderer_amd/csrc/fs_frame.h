@@ -2,13 +2,13 @@
 //
 // The reference walks the BSP front to back (src/renderer/mod.rs:61-104) and every step of it is cheap, branchy and order-dependent
 // only through three things: the order itself, which earlier full-height walls hide a later part (the host walker's solid-column
-// intervals, frontend.cpp), and the sprite / masked-wall draw sequence (renderer/map_objects.rs:216-240).  The GPU does it in three
+// intervals, frontend.cpp), and the sprite / masked-wall draw sequence (renderer/map_objects.rs:216-240).  The GPU does it in two
 // kernels per batch (fs_kernels.hip), with the arithmetic of fs_core.h:
-//   dg_fs_order   one lane per (frame, BSP leaf): position of the leaf's first seg in the reference's visit order — the sum, over the
-//                 leaf's ancestors on whose BACK side it lies for this viewer, of the seg count of the ancestor's front subtree;
 //   dg_fs_segs    one lane per (frame, seg): process_seg + the tests of every process_sidedef call (transform, clip, x projection): the
 //                 columns and flags of each call that reaches its column loop, written at the seg's VISIT POSITION in the frame's
-//                 candidate row — the row then holds the frame's candidate parts in the reference's order;
+//                 candidate row — the row then holds the frame's candidate parts in the reference's order.  The position of a seg is
+//                 that of its BSP leaf's first seg (fs_leaf_base: the sum, over the leaf's ancestors on whose BACK side it lies for
+//                 this viewer, of the seg count of the ancestor's front subtree) plus its index in the leaf;
 //   dg_fs_frame   one workgroup per frame, the phases below: hidden-part culling of the candidates -> the frame's FePart list (built
 //                 here, for the survivors only: a tenth of the candidates);
 //                 the map objects (FeSprite), their behind-bit rows and draw sequence; the column bins; the FeFrame header —
@@ -62,7 +62,6 @@ struct FsParams {
     const dg_view *views;                      // [n_frames], trig filled
     int32_t n_frames;
     // scratch (shared by all slots: every kernel runs on the ctx's one stream)
-    uint32_t *leaf_base;                       // [frame][n_leaves]
     // [frame][visit position of the seg x FS_CALLS + call], zeroed per batch: x = sx | ex << 16, y = FEP_* (bits 0-7) | 1 << 8 | seg << 12
     // for a call that reaches its column loop (dg_fs_segs): the frame's candidate parts, already in the reference's visit order
     uint2 *lite;
@@ -83,8 +82,11 @@ struct FsParams {
 };
 constexpr uint32_t FS_ORDER_CLASSES = 4;       // longest bin of the group (parts + 2 x sprites): > 32, > 16, > 8, the rest
 
-// ---- dg_fs_order: one (frame, leaf) --------------------------------------------------------------------------------------------------
-DG_HD void fs_leaf_order(const FsParams &P, int f, uint32_t leaf) {
+// ---- the visit position of a leaf (mod.rs:61-104 walks front to back from the root: the viewer's side of every partition first): the
+// number of segs visited before the leaf's first one = the seg counts of the FRONT subtrees of the ancestors on whose back side the leaf
+// lies.  Ten to fourteen ancestors; asked only for the segs that turn out to be candidates (dg_fs_segs), a few hundred per frame — a
+// kernel of its own over every (frame, leaf) was a launch, 10 us per 1 000 frames and a scratch row per frame for the same sums.
+DG_HD uint32_t fs_leaf_base(const FsParams &P, int f, uint32_t leaf) {
     const dg_view &v = P.views[f];
     const V2 ppos{v.x, v.y};
     uint32_t base = 0;
@@ -95,7 +97,7 @@ DG_HD void fs_leaf_order(const FsParams &P, int f, uint32_t leaf) {
         const bool leaf_left = (a >> 31) != 0;
         if (leaf_left != is_left) base += is_left ? n.segs_left : n.segs_right;                 // the whole front subtree comes before this leaf
     }
-    P.leaf_base[(size_t)f * P.n_leaves + leaf] = base;
+    return base;
 }
 
 // ---- dg_fs_segs: one (frame, seg) ----------------------------------------------------------------------------------------------------
@@ -143,7 +145,7 @@ DG_HD void fs_seg_lane(const FsParams &P, int f, uint32_t si) {
     // Only what the hidden-part culling reads is computed here — the columns and the flags of every call; the finished FePart of the
     // few calls that survive it (a tenth of them) is built afterwards, by dg_fs_frame, from (seg, call).
     const uint32_t leaf = P.seg_leaf[si];
-    const uint32_t pos = P.leaf_base[(size_t)f * P.n_leaves + leaf] + (si - P.leaf_first[leaf]);
+    const uint32_t pos = fs_leaf_base(P, f, leaf) + (si - P.leaf_first[leaf]);
     uint2 *lite = P.lite + ((size_t)f * P.n_segs + pos) * FS_CALLS;
 #pragma unroll
     for (int i = 0; i < 4; i++) {

@@ -1,4 +1,4 @@
-// fs_kernels.hip — the device seg walk (DG_FE_DEVICE_SEGS): BSP visit order, per-seg processing, hidden-part culling, map objects, draw
+// fs_kernels.hip — the device seg walk (DG_FE_DEVICE_SEGS): BSP visit order (inside dg_fs_segs: fs_leaf_base), per-seg processing, hidden-part culling, map objects, draw
 // sequence and column bins on the GPU.  Bodies: fs_core.h (arithmetic shared with the host walker) and fs_frame.h (the per-frame
 // phases, also run by tests/emul on the CPU).  Integer / f32 work with short dependent chains; nothing here is a contraction (no MFMA).
 #include <hip/hip_runtime.h>
@@ -9,11 +9,6 @@
 namespace dg {
 
 namespace {
-
-__global__ __launch_bounds__(64) void dg_fs_order(FsParams P) {
-    const uint32_t leaf = blockIdx.x * 64u + threadIdx.x;
-    if (leaf < P.n_leaves) fs_leaf_order(P, (int)blockIdx.y, leaf);
-}
 
 __global__ __launch_bounds__(64) void dg_fs_segs(FsParams P) {
     const uint32_t si = blockIdx.x * 64u + threadIdx.x;
@@ -80,8 +75,7 @@ __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
 
 hipError_t launch_fs(const FsParams &P, hipStream_t stream, hipEvent_t start) {
     if (P.n_frames <= 0) return start ? hipEventRecord(start, stream) : hipSuccess;
-    hipExtLaunchKernelGGL(dg_fs_order, dim3((P.n_leaves + 63u) / 64u, (unsigned)P.n_frames), dim3(64), 0, stream, start, nullptr, 0, P);
-    hipLaunchKernelGGL(dg_fs_segs, dim3((P.n_segs + 63u) / 64u, (unsigned)P.n_frames), dim3(64), 0, stream, P);
+    hipExtLaunchKernelGGL(dg_fs_segs, dim3((P.n_segs + 63u) / 64u, (unsigned)P.n_frames), dim3(64), 0, stream, start, nullptr, 0, P);
     hipLaunchKernelGGL(dg_fs_frame, dim3((unsigned)P.n_frames), dim3(FS_LANES), 0, stream, P);
     return hipGetLastError();
 }

@@ -545,7 +545,7 @@ int emul_frame_lists(void *scene, int W, int H, const dg_view *view_in, int32_t 
 }
 
 // ---- the device seg walk (fs_frame.h) on the CPU ------------------------------------------------------------------------------------
-// Runs the bodies of dg_fs_order / dg_fs_segs / dg_fs_frame for one frame — the "lanes" of every phase one after another, a barrier
+// Runs the bodies of dg_fs_segs / dg_fs_frame for one frame — the "lanes" of every phase one after another, a barrier
 // between phases — and compares what they produce with the host walker's parts mode (build_frame_parts), record by record:
 // every FePart byte for byte, every FeSprite (but its behind_off: the row stride differs), the behind bits, the sky slot table, both
 // column-bin tables.  Returns 0 and stats = [parts, sprites, sky slots, flags, capacities exceeded, candidates], 1 when the host walker
@@ -567,7 +567,7 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     for (size_t i = 0; i < sc.sectors.size(); i++) lights[i] = sc.sectors[i].light;
     std::vector<int32_t> mstate(sc.mobjs.size());
     for (size_t i = 0; i < sc.mobjs.size(); i++) mstate[i] = sc.mobjs[i].sprite_frame < 0 ? -1 : sc.mobjs[i].sprite_frame * 2 + (sc.mobjs[i].full_bright ? 1 : 0);
-    std::vector<uint32_t> leaf_base(sc.subsectors.size() + 1), flags(1, 0);
+    std::vector<uint32_t> flags(1, 0);
     std::vector<uint2> lite(sc.segs.size() * FS_CALLS + 1, uint2{0u, 0u});
     std::vector<FeFrame> ffr(1);
     std::vector<FePart> parts(FS_PART_CAP);
@@ -587,11 +587,10 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     const uint32_t cl_row_cap = (P.n_segs * FS_CALLS + 31u) / 32u * 32u;                                  // (context.cpp: upload_fs_scene)
     std::vector<uint32_t> cl_rows(cl_row_cap, 0xdeadbeefu), keep_rows(cl_row_cap / 32, 0xdeadbeefu);
     P.cl_rows = cl_rows.data(); P.keep_rows = keep_rows.data(); P.cl_row_cap = g_no_cl_rows ? 0u : cl_row_cap;
-    P.leaf_base = leaf_base.data(); P.lite = lite.data(); P.slice_cnt = slice_cnt.data(); P.flags = flags.data();
+    P.lite = lite.data(); P.slice_cnt = slice_cnt.data(); P.flags = flags.data();
     P.fframes = ffr.data(); P.parts = parts.data(); P.sprites = sprites.data(); P.behind = behind.data(); P.sky_parts = sky_parts.data();
     P.bin_off = bin_off.data(); P.bin_parts = bin_parts.data(); P.sbin_off = sbin_off.data(); P.sbin_sprites = sbin_sprites.data();
 
-    for (uint32_t l = 0; l < P.n_leaves; l++) fs_leaf_order(P, 0, l);                                      // dg_fs_order
     for (uint32_t s = 0; s < P.n_segs; s++) if (P.seg_leaf[s] != 0xffffu) fs_seg_lane(P, 0, s);             // dg_fs_segs
     uint32_t n_cand = 0;                                                                                   // process_sidedef calls that reach their column loop
     for (const uint2 &q : lite) n_cand += (q.x | q.y) != 0u;

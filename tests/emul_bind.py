@@ -80,7 +80,7 @@ class EmulScene:
         return buf.tobytes()
 
     def fs_frame(self, W, H, rec, timestamp=0.0):
-        """The device seg walk's bodies (fs_frame.h: dg_fs_order / dg_fs_segs / dg_fs_frame) on the CPU for one view, compared inside the
+        """The device seg walk's bodies (fs_frame.h: dg_fs_segs / dg_fs_frame) on the CPU for one view, compared inside the
         harness with the host walker's parts mode record by record.  -> (rc, stats): rc 0 = identical records, 1 = the host walker
         refuses the frame and the device walk flagged it, 2 = the device walk gave the frame up because it exceeds a capacity (the host
         redoes it; stats[4] says which: 1 parts, 2 candidates, 4 sprites, 8 sky parts, 16 part bins, 32 sprite bins), 3 = it gave the frame
