@@ -549,6 +549,8 @@ int upload_fs_scene(dg_ctx *c, const Scene &sc) {
     P.mobjs = reinterpret_cast<const FsMobj *>(at(i_mobjs)); P.sframes = reinterpret_cast<const FsSpriteFrame *>(at(i_sframes));
     P.nodes = reinterpret_cast<const FsNode *>(at(i_nodes)); P.anc_off = reinterpret_cast<const uint32_t *>(at(i_aoff)); P.anc = reinterpret_cast<const uint32_t *>(at(i_anc));
     P.n_segs = (uint32_t)sc.segs.size(); P.n_leaves = (uint32_t)sc.subsectors.size(); P.n_mobjs = (uint32_t)sc.mobjs.size();
+    P.sprite_stride = std::min<uint32_t>(FS_SPRITE_CAP, std::max<uint32_t>(32u, (P.n_mobjs + 31u) / 32u * 32u));
+    P.sbin_stride = std::min<uint32_t>(FS_SBIN_CAP, P.sprite_stride * (uint32_t)((c->cfg.width + FE_BIN_W - 1) / FE_BIN_W));
     // scratch: the candidate rows (zeroed before every walk), the leaves' visit positions
     const size_t F = (size_t)c->cfg.max_batch;
     const size_t off_lite = align_up(F * FS_LANES * 4, 256);               // [slice counters | candidate rows]: zeroed together
@@ -629,13 +631,13 @@ int build_batch_fs(dg_ctx *c, Slot &s, const dg_view *views, int n, const dg_vie
     const size_t off_ff = upload;
     const size_t off_parts = align_up(off_ff + (size_t)n * sizeof(FeFrame), 256);
     const size_t off_sprites = align_up(off_parts + (size_t)n * FS_PART_CAP * sizeof(FePart), 256);
-    const size_t off_behind = align_up(off_sprites + (size_t)n * FS_SPRITE_CAP * sizeof(FeSprite), 256);
-    const size_t off_sky = align_up(off_behind + (size_t)n * FS_SPRITE_CAP * FS_BEHIND_WORDS * 4, 256);
+    const size_t off_behind = align_up(off_sprites + (size_t)n * c->fs_proto.sprite_stride * sizeof(FeSprite), 256);
+    const size_t off_sky = align_up(off_behind + (size_t)n * c->fs_proto.sprite_stride * FS_BEHIND_WORDS * 4, 256);
     const size_t off_boff = align_up(off_sky + (size_t)n * FS_SKY_CAP * 4, 256);
     const size_t off_sboff = align_up(off_boff + (size_t)n * nb1 * 4, 256);
     const size_t off_bins = align_up(off_sboff + (size_t)n * nb1 * 4, 256);
     const size_t off_sbins = align_up(off_bins + (size_t)n * FS_BIN_CAP * 2, 256);
-    const size_t total = off_sbins + (size_t)n * FS_SBIN_CAP * 2;
+    const size_t total = off_sbins + (size_t)n * c->fs_proto.sbin_stride * 2;
     if (total > c->fe_slab_cap) return kPartsUnsupported;
     s.views.assign(views, views + n);
     c->pool->parallel_for(n, [&](int i, int) {
@@ -1161,6 +1163,8 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
         const int rc = upload_fs_scene(c, sc);
         if (rc && c->fs_forced) return rc;                 // (DG_FE_AUTO simply keeps the host walker when the seg walk's memory cannot be had)
         if (rc) {
+            static bool said = false;                      // once per process: the ctx works, but not the way it was asked to
+            if (!said) { said = true; std::fprintf(stderr, "doomgpu: DG_FE_AUTO keeps the per-seg half on the host: no device memory for the seg walk's per-batch rows (%d views x %zu segs)\n", c->cfg.max_batch, sc.segs.size()); }
             if (c->d_fs_scene) { (void)hipFree(c->d_fs_scene); c->d_fs_scene = nullptr; }
             if (c->d_fs_scratch) { (void)hipFree(c->d_fs_scratch); c->d_fs_scratch = nullptr; }
             c->fs_scene_ok = false;

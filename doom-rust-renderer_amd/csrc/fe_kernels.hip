@@ -289,41 +289,24 @@ __global__ __launch_bounds__(64 * FE_SCATTER_GROUPS) void dg_fe_scatter(FeParams
     const int x0 = (int)(blockIdx.x * 64), x = x0 + lx;
     const uint32_t g = threadIdx.x >> 6;
     const uint32_t *coff = P.col_off + (size_t)f * (size_t)(W + 1);
-    const FeU4 *src = P.cspans + (size_t)f * P.col_slots * (size_t)W + (size_t)x;
-    // A wave of this kernel lives through dependent round trips (10 000 clocks each, 80 000 waves: profiles/r04_column_walk.md), so as many of
-    // them as possible are issued together: the thread's first two spans (slots g and g + 4 of its column — nine columns in ten hold no more
-    // than eight spans) are fetched BEFORE the column's span count is known (a slot past the count holds an older batch's record: never
-    // used), and resolved into the rasteriser's form (which reads the part's record: the next round trip) before the workgroup meets at the
-    // barrier that publishes the keys; the ranks — which need every key of the column — come last and are cheap.
-    const bool col = x < W;
-    FeU4 c0 = FeU4{0u, 0u, 0u, 0u}, c1 = c0;
-    const bool have1 = g + FE_SCATTER_GROUPS < P.col_slots;
-    if (col) {
-        c0 = src[(size_t)g * (size_t)W];
-        if (have1) c1 = src[(size_t)(g + FE_SCATTER_GROUPS) * (size_t)W];
-    }
     uint32_t off = 0, n = 0;
-    if (col) { off = coff[x]; n = coff[x + 1] - off; }       // n = 0 for every column of a frame that did not fit
+    if (x < W) { off = coff[x]; n = coff[x + 1] - off; }      // n = 0 for every column of a frame that did not fit
     const uint32_t t_first = coff[x0], t_last = coff[min(x0 + 64, W)];            // wave-uniform: the workgroup's range of the output
     const bool staged = t_last - t_first <= FE_SCATTER_STAGE;
+    const FeU4 *src = P.cspans + (size_t)f * P.col_slots * (size_t)W + (size_t)x;
+    for (uint32_t i = g; i < n; i += FE_SCATTER_GROUPS) lkeys[i * 64 + (uint32_t)lx] = src[(size_t)i * (size_t)W].x;
+    __syncthreads();
     const DevFrame fr = P.frames[f];
     const FeFrame ff = P.fframes[f];
-    for (uint32_t i = g; i < n; i += FE_SCATTER_GROUPS)
-        lkeys[i * 64 + (uint32_t)lx] = i == g ? c0.x : i == g + FE_SCATTER_GROUPS ? c1.x : src[(size_t)i * (size_t)W].x;
-    DevRSpan r0{}, r1{};
-    if (g < n) r0 = fe_resolve(P, fr, ff, x, c0);
-    if (g + FE_SCATTER_GROUPS < n) r1 = fe_resolve(P, fr, ff, x, c1);
-    __syncthreads();
     FeU4 *out = reinterpret_cast<FeU4 *>(P.rspans + fr.span_base);
     for (uint32_t i = g; i < n; i += FE_SCATTER_GROUPS) {
-        const bool first = i == g, second = i == g + FE_SCATTER_GROUPS;
-        const FeU4 cs = first ? c0 : second ? c1 : src[(size_t)i * (size_t)W];
+        const FeU4 cs = src[(size_t)i * (size_t)W];
         uint32_t rank = 0;
         for (uint32_t j = 0; j < n; j++) {
             const uint32_t kj = lkeys[j * 64 + (uint32_t)lx];
             rank += (kj < cs.x || (kj == cs.x && j < i)) ? 1u : 0u;        // the tie-break keeps the scatter a permutation
         }
-        const DevRSpan r = first ? r0 : second ? r1 : fe_resolve(P, fr, ff, x, cs);
+        const DevRSpan r = fe_resolve(P, fr, ff, x, cs);
         FeU4 *to = staged ? lout + 2 * (size_t)(off - t_first + rank) : out + 2 * (size_t)(off + rank);
         to[0] = FeU4{r.w[0], r.w[1], r.w[2], r.w[3]};
         to[1] = FeU4{r.w[4], r.w[5], r.w[6], r.w[7]};

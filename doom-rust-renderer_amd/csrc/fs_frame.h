@@ -54,6 +54,9 @@ struct FsParams {
     const FsMobj *mobjs; const FsSpriteFrame *sframes;
     const FsNode *nodes; const uint32_t *anc_off; const uint32_t *anc;           // per leaf: its ancestors, root first: node | (lies in the LEFT subtree) << 31
     uint32_t n_segs, n_leaves, n_mobjs;
+    // per-frame strides of the sprite arrays below: the scene's map-object count (no frame can show more), rounded up, at most FS_SPRITE_CAP /
+    // FS_SBIN_CAP — a map with 40 things keeps its records 64 apart, not 512
+    uint32_t sprite_stride, sbin_stride;
     // game state of this batch (scene-wide values as of submission)
     const int16_t *sector_light;               // [n_sectors] for the whole batch (light_stride 0), or [n_frames][light_stride]: per-view game state
     const int32_t *mobj_state;                 // [n_mobjs] / [n_frames][mstate_stride]: sprite_frame * 2 + full_bright, negative: S_NULL
@@ -181,6 +184,10 @@ struct FsShared {                              // LDS on the GPU
     int16_t s_key[FS_SPRITE_CAP];
     uint16_t s_order[FS_SPRITE_CAP], s_x0b[FS_SPRITE_CAP], s_x1b[FS_SPRITE_CAP];   // place in the far-to-near order; first / last column bin (x0b > x1b: no columns)
     uint32_t n_sprites;
+    // `fail`: the frame is given up.  Invariant: it only ever goes from 0 to 1; a phase in which several lanes may raise it does so with an
+    // atomic OR, a phase in which one lane decides stores it; lanes that read it in the SAME phase may see either value, which is harmless by
+    // construction (everything a phase writes after such a read is guarded by a capacity test of its own, and the frame is flagged for the
+    // host either way); from the next barrier on every lane sees it.
     uint32_t fail;
     uint8_t group_cls[FS_MAX_W / 256 + 6];     // weight class of each 256-column group (fs_ph_bin_prefix)
 };
@@ -336,7 +343,7 @@ DG_HD void fs_ph_emit(const FsParams &P, FsShared &S, int f, int lane) {
         FsSegOut so;
         FePart p;
         const int32_t st = fs_seg(P.k, sg, P.sectors, P.anims, V2{v.x, v.y}, v.cos_na, v.sin_na, v.floor_height + 41.0f, v.timestamp, P.sector_light[(size_t)f * P.light_stride + (size_t)sg.front_sector], so);
-        if (st != FS_OK || fs_part(P.k, so, fs_call(so, src & 7u), P.bitmaps, P.flat_sky, v.floor_height, p) != FS_OK) { S.fail = 1; continue; }   // (cannot happen: dg_fs_segs passed it)
+        if (st != FS_OK || fs_part(P.k, so, fs_call(so, src & 7u), P.bitmaps, P.flat_sky, v.floor_height, p) != FS_OK) { fs_or_u32(&S.fail, 1u); continue; }   // (cannot happen: dg_fs_segs passed it)
         p.sky_slot = S.kept_sky[o];
         P.parts[(size_t)f * FS_PART_CAP + o] = p;
         S.kline[o][0] = so.cl.line.a.x; S.kline[o][1] = so.cl.line.a.y; S.kline[o][2] = so.cl.line.b.x; S.kline[o][3] = so.cl.line.b.y;
@@ -357,19 +364,19 @@ DG_HD void fs_ph_mobj(const FsParams &P, FsShared &S, int f, uint32_t base, int 
     T.status = fs_mobj(P.k, m, P.sframes[st >> 1], P.bitmaps, P.sectors, V2{v.x, v.y}, v.angle, v.cos_na, v.sin_na, v.floor_height + 41.0f, st & 1,
                        m.sector >= 0 ? P.sector_light[(size_t)f * P.light_stride + (size_t)m.sector] : (int16_t)0, T.so);
     if (T.status == FS_OK) S.lane_cnt[lane] = 1;
-    else if (T.status != FS_SKIP) S.fail = 1;                          // a failure (every lane that sees one writes the same 1)
+    else if (T.status != FS_SKIP) fs_or_u32(&S.fail, 1u);              // a failure (any lane may see one)
 }
 // phase 4c: the FeSprite records, sprite indices in map-object order (n_before: sprites of the chunks before this one)
 DG_HD void fs_ph_mobj_emit(const FsParams &P, FsShared &S, int f, int lane, const FsSpriteTmp &T, uint32_t n_before) {
     const uint32_t si = n_before + fs_lane_offset(S, lane);
     if (lane == FS_LANES - 1) {
         S.n_sprites = si + S.lane_cnt[lane];
-        if (S.n_sprites > FS_SPRITE_CAP) { S.fail = 1; S.n_sprites = 0; }
+        if (S.n_sprites > P.sprite_stride) { S.fail = 1; S.n_sprites = 0; }
     }
-    if (S.fail || S.lane_cnt[lane] != 1 || si >= FS_SPRITE_CAP) return;
+    if (S.fail || S.lane_cnt[lane] != 1 || si >= P.sprite_stride) return;
     FeSprite sp = T.so.sp;
     sp.behind_off = si * FS_BEHIND_WORDS;
-    P.sprites[(size_t)f * FS_SPRITE_CAP + si] = sp;
+    P.sprites[(size_t)f * P.sprite_stride + si] = sp;
     S.s_centre[si][0] = T.so.centre.x; S.s_centre[si][1] = T.so.centre.y;
     const Seg2 &l = T.so.line;
     S.s_mid[si][0] = (l.a.x + l.b.x) / 2.0f; S.s_mid[si][1] = (l.a.y + l.b.y) / 2.0f;       // map_objects.rs:222-226
@@ -390,7 +397,7 @@ DG_HD void fs_ph_behind(const FsParams &P, FsShared &S, int f, int lane) {
             const float *k = S.kline[w * 32 + b];
             if (fs_behind(Seg2{V2{k[0], k[1]}, V2{k[2], k[3]}}, c)) bits |= 1u << b;
         }
-        P.behind[((size_t)f * FS_SPRITE_CAP + si) * FS_BEHIND_WORDS + w] = bits;
+        P.behind[((size_t)f * P.sprite_stride + si) * FS_BEHIND_WORDS + w] = bits;
     }
 }
 // phase 6: place of every sprite in the far-to-near order: stable ascending sort on the key, reversed (map_objects.rs:216-217)
@@ -421,7 +428,7 @@ DG_HD void fs_ph_seq(const FsParams &P, FsShared &S, int f, int lane) {
         const uint32_t m = S.s_order[si];
         uint32_t walls = 0;
         for (uint32_t r = 0; r < S.n_parts; r++) walls += S.kept_t[r] <= m;                 // (0xfffe / 0xffff never are)
-        P.sprites[(size_t)f * FS_SPRITE_CAP + si].seq = m + walls;
+        P.sprites[(size_t)f * P.sprite_stride + si].seq = m + walls;
     }
     for (uint32_t r = (uint32_t)lane; r < S.n_parts; r += FS_LANES) {
         const uint32_t t = S.kept_t[r];
@@ -491,7 +498,7 @@ DG_HD void fs_ph_bin_prefix(const FsParams &P, FsShared &S, int f) {      // lan
         }
     }
     bo[nb] = rp; so[nb] = rs;
-    if (rp > FS_BIN_CAP || rs > FS_SBIN_CAP) S.fail = 1;
+    if (rp > FS_BIN_CAP || rs > P.sbin_stride) S.fail = 1;
     if (P.order_cnt) {
         const uint32_t groups = (nb + 3) / 4;
         uint32_t a0 = n0 ? fs_add_u32(&P.order_cnt[0], n0) : 0u, a1 = n1 ? fs_add_u32(&P.order_cnt[1], n1) : 0u;
@@ -517,7 +524,7 @@ DG_HD void fs_ph_bin_fill(const FsParams &P, FsShared &S, int f, int lane) {
             P.bin_parts[(size_t)f * FS_BIN_CAP + place(0, r, b)] = (uint16_t)r;
     for (uint32_t q = (uint32_t)lane; q < S.n_sprites; q += FS_LANES)
         for (uint32_t b = S.s_x0b[q]; b <= S.s_x1b[q] && b < nb; b++)
-            P.sbin_sprites[(size_t)f * FS_SBIN_CAP + place(1, q, b)] = (uint16_t)q;
+            P.sbin_sprites[(size_t)f * P.sbin_stride + place(1, q, b)] = (uint16_t)q;
 }
 // phase 10a: the frame's candidate row and slice counters go back to zero for the next batch (the rows are zeroed once, at upload: a
 // memset of all rows per batch is a 28 MB fill kernel plus a launch in front of every walk)
@@ -533,13 +540,13 @@ DG_HD void fs_ph_header(const FsParams &P, FsShared &S, int f) {
     const bool bad = S.fail || (P.flags[f] & FE_OVF_SEGS);
     FeFrame ff;
     ff.part_base = (uint32_t)f * FS_PART_CAP; ff.n_parts = bad ? 0u : S.n_parts;
-    ff.sprite_base = (uint32_t)f * FS_SPRITE_CAP; ff.n_sprites = bad ? 0u : S.n_sprites;
-    ff.behind_base = (uint32_t)f * FS_SPRITE_CAP * FS_BEHIND_WORDS;
+    ff.sprite_base = (uint32_t)f * P.sprite_stride; ff.n_sprites = bad ? 0u : S.n_sprites;
+    ff.behind_base = (uint32_t)f * P.sprite_stride * FS_BEHIND_WORDS;
     ff.behind_words = FS_BEHIND_WORDS;
     ff.n_sky_slots = bad ? 0u : S.n_sky;
     ff.sky_base = (uint32_t)f * FS_SKY_CAP;
     ff.bin_base = (uint32_t)f * FS_BIN_CAP;
-    ff.sbin_base = (uint32_t)f * FS_SBIN_CAP;
+    ff.sbin_base = (uint32_t)f * P.sbin_stride;
     ff.pad[0] = ff.pad[1] = 0;
     P.fframes[f] = ff;
     if (bad) {

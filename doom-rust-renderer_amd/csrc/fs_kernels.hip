@@ -75,7 +75,9 @@ __global__ __launch_bounds__(FS_LANES) void dg_fs_frame(FsParams P) {
 
 hipError_t launch_fs(const FsParams &P, hipStream_t stream, hipEvent_t start) {
     if (P.n_frames <= 0) return start ? hipEventRecord(start, stream) : hipSuccess;
+    if (P.n_segs == 0) return hipErrorInvalidValue;                     // (upload_fs_scene keeps such a scene off the seg walk)
     hipExtLaunchKernelGGL(dg_fs_segs, dim3((P.n_segs + 63u) / 64u, (unsigned)P.n_frames), dim3(64), 0, stream, start, nullptr, 0, P);
+    if (const hipError_t e = hipGetLastError(); e != hipSuccess) return e;   // each launch checked: a later success would hide it
     hipLaunchKernelGGL(dg_fs_frame, dim3((unsigned)P.n_frames), dim3(FS_LANES), 0, stream, P);
     return hipGetLastError();
 }

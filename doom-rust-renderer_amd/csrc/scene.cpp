@@ -434,7 +434,7 @@ void Scene::rebuild_fs_tables() {
         fs_segs[i] = f;
     }
     // every seg belongs to at most one leaf (0xffff: to none — the walk never reaches it)
-    fs_ok = !may_panic && subsectors.size() < 0xffffu && !nodes.empty();
+    fs_ok = !may_panic && subsectors.size() < 0xffffu && !nodes.empty() && !segs.empty();
     fs_seg_leaf.assign(segs.size(), (uint16_t)0xffffu);
     fs_leaf_first.resize(subsectors.size());
     for (size_t l = 0; l < subsectors.size(); l++) {

@@ -107,13 +107,20 @@ typedef struct dg_config {
  *                      map_objects.rs:130-209.  A frame that exceeds a device-side capacity is redone through DG_FE_HOST transparently
  *                      (same pixels either way).
  *   DG_FE_DEVICE_SEGS  the per-seg half runs on the GPU too (one lane per seg / map object, one wavefront per frame for what depends on
- *                      the BSP order): the host ships 88 bytes per view and nothing else.  Frames it cannot judge (a reference panic,
- *                      a capacity), batches with per-view game state (dg_submit_views_state) and maps in which a texture / flat lookup
- *                      would panic fall back to DG_FE_DEVICE / DG_FE_HOST transparently.
+ *                      the BSP order): the host ships 88 bytes per view and nothing else (with per-view game state,
+ *                      dg_submit_views_state: plus one copy of the sector lights and map-object states per view).  Frames it cannot
+ *                      judge (a reference panic, a per-frame capacity: 256 parts after culling, 512 map objects in view, 2 560 columns)
+ *                      and maps in which a texture / flat lookup would panic fall back to DG_FE_DEVICE / DG_FE_HOST transparently.
+ *                      Costs device memory per ctx: max_batch x segs x 40 B of candidate rows, plus max_batch x segs x 21 B for maps with
+ *                      more than 307 segs (candidate lists longer than shared memory holds); when that allocation fails the ctx simply
+ *                      keeps the host's per-seg half (DG_FE_DEVICE).
  *   DG_FE_AUTO         DG_FE_DEVICE or DG_FE_DEVICE_SEGS per batch, whichever is the faster way for it: the GPU takes the per-seg half when
  *                      nothing is in flight (the host's time would be exposed) or when the host has been measured to be the slower
  *                      side (few host threads, small frames); batches of fewer than 64 views always use the host walker.  The pixels
- *                      are the same whichever is picked; dg_timing.front_end says which one it was. */
+ *                      are the same whichever is picked; dg_timing.front_end says which one it was.  The choice rests on wall-clock
+ *                      measurements (host time per view, kernel time of finished batches): which front end — and therefore which
+ *                      instruction stream, and which fallback counters — a given batch gets is NOT reproducible from run to run.
+ *                      Ask for DG_FE_DEVICE or DG_FE_DEVICE_SEGS where that matters. */
 enum { DG_FE_AUTO = 0, DG_FE_HOST = 1, DG_FE_DEVICE = 2, DG_FE_DEVICE_SEGS = 3 };
 
 int dg_create(const dg_config *cfg, dg_ctx **out);

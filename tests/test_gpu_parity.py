@@ -805,7 +805,9 @@ def test_auto_front_end_picks_per_batch(dg, scene1993, oracle_scene1993, path199
                 assert np.array_equal(got[k], np.frombuffer(oracle_scene1993.render(W, H, path1993[pb0 + k]), dtype=np.uint8).reshape(H, W, 3)), (it, k)
     ctx.wait(1)
     assert used[0] == dg.DG_FE_DEVICE_SEGS, used              # the first batch found nothing in flight
-    assert used.count(dg.DG_FE_DEVICE_SEGS) >= 5, used         # ... and the slow host loses the later ones too
+    # (which side wins the later batches depends on measured host and GPU times — with one host thread the seg walk, on every box so far —
+    # and is not asserted: the choice must not make a frame differ, which is what the loop above checked)
+    assert set(used) <= {dg.DG_FE_DEVICE_SEGS, dg.DG_FE_DEVICE}, used
     ctx.wait(0)
     small = ctx.render(dg.make_views(path1993[100:132]))         # 32 views: always the host walker
     assert ctx.timing(0)["front_end"] == dg.DG_FE_DEVICE
