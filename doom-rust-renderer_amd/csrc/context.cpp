@@ -209,6 +209,8 @@ struct dg_ctx {
     DevScene dscene{};
     std::vector<Slot> slots;
     hipStream_t kstream = nullptr;      // every kernel of every slot, in submission order (enqueue_kernels)
+    hipStream_t rstream = nullptr;      // raster_overlap: the raster launches, so that the next batch's front-end kernels (kstream) run next to them
+    bool raster_overlap = false;
     std::unique_ptr<Pool> pool;
     std::vector<std::unique_ptr<FrameArena>> arenas;   // one per worker (+ caller)
     std::vector<BinnedFrame> binned;                   // one per frame of a batch
@@ -272,6 +274,7 @@ void free_ctx(dg_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->kstream) (void)hipStreamSynchronize(c->kstream);        // every slot's kernels, before anything they use is freed
+    if (c->rstream) (void)hipStreamSynchronize(c->rstream);
     for (Slot &s : c->slots) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         if (s.h_lists) (void)hipHostFree(s.h_lists);
@@ -293,6 +296,7 @@ void free_ctx(dg_ctx *c) {
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     if (c->kstream) (void)hipStreamDestroy(c->kstream);
+    if (c->rstream) (void)hipStreamDestroy(c->rstream);
     if (c->d_palette) (void)hipFree(c->d_palette);
     if (c->d_texel_idx) (void)hipFree(c->d_texel_idx);
     if (c->d_texel_opq) (void)hipFree(c->d_texel_opq);
@@ -738,12 +742,14 @@ int build_batch(dg_ctx *c, Slot &s, const dg_view *views, const dg_frame_lists *
     return build_batch_host(c, s, views, given, n, states);
 }
 
+constexpr size_t kOverlapMaxPixels = 500000;          // frames up to this size overlap their raster launch with the next batch's front end (dg_create)
+
 int enqueue_kernels(dg_ctx *c, Slot &s) {
     // All kernels of all slots run on ONE in-order stream (highest priority, so that it gets a hardware queue of its own): column walk
     // i, rasteriser i, column walk i + 1, ...  The slot's own stream carries its H2D copy (queued already; it overlaps the previous
     // slots' kernels), tied in with an event.  Letting the walk of batch i + 1 overlap the raster launch of batch i was measured to buy
-    // nothing: its waves take slots a raster workgroup needs as a whole, the launch stretches by what the walk costs alone
-    // (profiles/r03_column_walk.md).  The walk's per-frame status words (overflow flags, span totals) live in pinned host memory and are
+    // nothing at 1280x800: its waves take slots a raster workgroup needs as a whole, the launch stretches by what the walk costs alone
+    // (profiles/r03_column_walk.md) — for small frames it does pay, and the raster launches then go to a second stream (raster_overlap).  The walk's per-frame status words (overflow flags, span totals) live in pinned host memory and are
     // written by the kernels directly: nothing is queued behind the raster launch, so no stream ever holds a barrier that another
     // slot's upload could get stuck behind (streams share hardware queues).
     hipStream_t ks = c->kstream;
@@ -773,7 +779,12 @@ int enqueue_kernels(dg_ctx *c, Slot &s) {
     } else {
         HIP_TRY(launch_setup(s.P, s.max_spans, ks, s.ev_start, s.ev_setup));
     }
-    HIP_TRY(launch_raster(s.P, ks, s.ev_rstart, s.ev_raster));
+    if (c->raster_overlap && fe_mode) {                   // the front end of the next batch may start while this launch runs (the column scratch is the front end's alone)
+        HIP_TRY(hipStreamWaitEvent(c->rstream, s.ev_setup, 0));
+        HIP_TRY(launch_raster(s.P, c->rstream, s.ev_rstart, s.ev_raster));
+    } else {
+        HIP_TRY(launch_raster(s.P, ks, s.ev_rstart, s.ev_raster));
+    }
     if (fe_mode) s.walk_state_clean = true;               // everything was enqueued: dg_fe_scan will have cleaned up by the slot's next batch
     guard.armed = false;
     s.harvested = false;
@@ -892,7 +903,12 @@ void harvest_gpu_time(dg_ctx *c, Slot &s) {
     if (hipEventQuery(s.ev_raster) != hipSuccess) return;
     s.harvested = true;
     float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, s.ev_start, s.ev_raster) != hipSuccess || !(ms > 0.0f)) return;
+    if (c->raster_overlap) {                               // the raster launch may have waited behind the previous batch's: the two halves' own durations
+        float fe_ms = 0.0f, r_ms = 0.0f;
+        if (hipEventElapsedTime(&fe_ms, s.ev_start, s.ev_setup) != hipSuccess || hipEventElapsedTime(&r_ms, s.ev_rstart, s.ev_raster) != hipSuccess) return;
+        ms = std::max(fe_ms, r_ms);                        // (they overlap with the neighbouring batches': the longer one sets the pace)
+        if (!(ms > 0.0f)) return;
+    } else if (hipEventElapsedTime(&ms, s.ev_start, s.ev_raster) != hipSuccess || !(ms > 0.0f)) return;
     double &ema = s.fs_mode ? c->ema_gpu_fs : c->ema_gpu_dev;
     const double v = (double)ms / s.n_frames;
     ema = ema < 0.0 ? v : 0.75 * ema + 0.25 * v;
@@ -1078,6 +1094,13 @@ int dg_create(const dg_config *cfg, dg_ctx **out) {
         int lo = 0, hi = 0;
         CTX_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         CTX_TRY(hipStreamCreateWithPriority(&c->kstream, hipStreamNonBlocking, hi));
+        // Small frames: the front-end kernels of a batch are chains of dependent steps that leave most of the chip idle, and at 320x200 they
+        // last as long as the raster launch itself — letting the next batch's front end run next to this batch's raster launch (two streams,
+        // tied by the front end's last dispatch event) is worth 17 % there (2.57 -> 3.02 M frames/s), 7 % at 640x400, 2 % at 800x600.  From 1024x768 up the raster launch
+        // fills the chip and the overlap costs 1-2 % (profiles/r03_column_walk.md, r05_seg_walk.md).  DOOMGPU_RASTER_OVERLAP=0 / 1 overrides.
+        c->raster_overlap = (size_t)cfg->width * (size_t)cfg->height <= kOverlapMaxPixels;
+        if (const char *e = std::getenv("DOOMGPU_RASTER_OVERLAP")) c->raster_overlap = std::atoi(e) != 0;
+        if (c->raster_overlap) CTX_TRY(hipStreamCreateWithPriority(&c->rstream, hipStreamNonBlocking, hi));
     }
     for (Slot &s : c->slots) {
         CTX_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
