@@ -581,6 +581,8 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     P.mobjs = sc.fs_mobjs.data(); P.sframes = sc.sprite_frames_fs();
     P.nodes = sc.fs_nodes.data(); P.anc_off = sc.fs_anc_off.data(); P.anc = sc.fs_anc.data();
     P.n_segs = (uint32_t)sc.segs.size(); P.n_leaves = (uint32_t)sc.subsectors.size(); P.n_mobjs = (uint32_t)sc.mobjs.size();
+    P.sprite_stride = std::min<uint32_t>(FS_SPRITE_CAP, std::max<uint32_t>(32u, (P.n_mobjs + 31u) / 32u * 32u));        // (context.cpp: upload_fs_scene)
+    P.sbin_stride = std::min<uint32_t>(FS_SBIN_CAP, P.sprite_stride * nb);
     P.sector_light = lights.data(); P.mobj_state = mstate.data();
     P.views = &view; P.n_frames = 1;
     std::vector<uint32_t> slice_cnt(FS_LANES, 0);
@@ -635,8 +637,8 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
         return 1;
     }
     if (flags[0] & FE_OVF_SEGS) {                     // given up on the device although the host walker completes the frame: only a NAMED capacity may do that
-        const uint32_t why = (arena.parts.size() > FS_PART_CAP ? 1u : 0u) | (n_cand > std::max(FS_CL_CAP, P.cl_row_cap) ? 2u : 0u) | (arena.sprites.size() > FS_SPRITE_CAP ? 4u : 0u) |
-                             (arena.n_sky_slots > FS_SKY_CAP ? 8u : 0u) | (arena.bin_off[nb] > FS_BIN_CAP ? 16u : 0u) | (arena.sbin_off[nb] > FS_SBIN_CAP ? 32u : 0u);
+        const uint32_t why = (arena.parts.size() > FS_PART_CAP ? 1u : 0u) | (n_cand > std::max(FS_CL_CAP, P.cl_row_cap) ? 2u : 0u) | (arena.sprites.size() > P.sprite_stride ? 4u : 0u) |
+                             (arena.n_sky_slots > FS_SKY_CAP ? 8u : 0u) | (arena.bin_off[nb] > FS_BIN_CAP ? 16u : 0u) | (arena.sbin_off[nb] > P.sbin_stride ? 32u : 0u);
         if (stats) stats[4] = why;
         if (!why) { g_err = "the device seg walk gave up a frame that exceeds none of its capacities and that the host walker completes"; return 3; }
         return 2;
