@@ -267,3 +267,38 @@ def test_route_from_wad_gives_a_closed_walk(synth, campath_mod):
         assert 8 <= len(r) <= 48 and len(set(r)) > 4
         path = campath_mod.make_camera_path(r, lambda x, y, d: 0.0, 50)
         assert path.shape == (50, 8) and np.isfinite(path).all()
+
+
+def test_issue_roofline_from_the_committed_counters(tmp_path):
+    """`roofline.issue`: wave-instructions per (column, 64-row) chunk by class from profiles/issue.json and the share of the issue capacities
+    they fill at a given launch time; tools/issue_counters.py writes that file from rocprofv3 --pmc csv output (checked on a synthetic one)."""
+    import csv
+    import json
+    import subprocess
+    import bench
+    r = bench.issue_roofline(1280, 800, 1000, 1.8e-3)                 # the committed profile of the default command
+    assert r and "error" not in r, r
+    pc = r["per_chunk"]
+    assert r["chunks_per_launch"] == 1000 * 20 * 64 * 13
+    assert 40 < pc["valu"] < 80 and 20 < pc["salu"] < 60 and 0 < pc["valu_paired"] < pc["valu"]
+    assert abs(r["per_chunk_total"] - sum(pc[k] for k in ("valu", "salu", "lds", "vmem", "smem"))) < 1e-9
+    assert 0.3 < r["vector_issue_slots_filled"] < 1.0 and 0.2 < r["scalar_issue_filled"] < 1.0 and 0.1 < r["lds_cycles_filled"] < 1.0
+    assert bench.issue_roofline(123, 45, 6, 1e-3) is None               # a size nobody profiled
+    # the extractor on a synthetic counter dump: two launches of 4 frames (the largest grid), one smaller launch ignored
+    d = tmp_path / "pmc_x" / "run"
+    d.mkdir(parents=True)
+    cols = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id", "Grid_Size", "Kernel_Id", "Kernel_Name", "Workgroup_Size", "LDS_Block_Size",
+            "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+    vals = {"SQ_INSTS_VALU": 1000.0, "SQ_ACTIVE_INST_VALU2": 250.0, "SQ_INSTS_SALU": 600.0, "SQ_INSTS_LDS": 100.0, "SQ_INSTS_VMEM_RD": 30.0, "SQ_INSTS_VMEM_WR": 4.0,
+            "SQ_INSTS_SMEM": 3.0, "SQ_LDS_IDX_ACTIVE": 350.0, "SQ_BUSY_CU_CYCLES": 256.0 * 2000.0}
+    with open(d / "1_counter_collection.csv", "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(cols)
+        for disp, grid in ((1, 4096), (2, 8192), (3, 8192)):
+            for name, v in vals.items():
+                w.writerow([disp, disp, "Agent 2", 1, 1, 1, grid, 7, "dg::dg_raster_tiles(dg::RasterParams)", 512, 0, 0, 64, 0, 80, name, v * (2 if grid == 4096 else 1), 1000, 2000])
+    out = tmp_path / "issue.json"
+    subprocess.check_call([sys.executable, os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "tools", "issue_counters.py"), str(tmp_path), "64x64x4", "--out", str(out)])
+    e = json.load(open(out))["64x64x4"]
+    assert (e["valu"], e["valu_paired"], e["salu"], e["vmem"], e["launches"], e["grid"]) == (1000.0, 250.0, 600.0, 34.0, 2, 8192)
+    assert abs(e["clock_ghz"] - 2.0) < 1e-9                               # 2 000 cycles per CU in 1 000 ns
