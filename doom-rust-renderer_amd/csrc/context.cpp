@@ -1153,7 +1153,7 @@ int dg_upload_scene(dg_ctx *c, const dg_scene *scene) {
     if (c->d_texel_opq) { (void)hipFree(c->d_texel_opq); c->d_texel_opq = nullptr; }
     c->d_flats = nullptr;               // inside d_texel_idx's allocation
     // the slots' prepared records point into the device scene that was just freed: nothing may be replayed from them
-    for (Slot &s : c->slots) { s.n_frames = 0; s.timed = false; s.fe_check = false; s.busy = false; }
+    for (Slot &s : c->slots) { s.n_frames = 0; s.timed = false; s.fe_check = false; s.busy = false; s.snap_scene = nullptr; }   // (a new scene may reuse the old one's address and revision)
     uint32_t pal[256];
     for (int i = 0; i < 256; i++) pal[i] = (uint32_t)sc.palette[3 * i] | ((uint32_t)sc.palette[3 * i + 1] << 8) | ((uint32_t)sc.palette[3 * i + 2] << 16);
     const size_t nt = std::max<size_t>(sc.texel_idx.size(), 16), nf = std::max<size_t>(sc.flat_pool.size(), 16);
