@@ -207,3 +207,32 @@ def test_more_candidates_than_shared_memory_holds_stay_on_the_gpu_walk(synth, ca
         big += rc == 0 and st[5] > FS_CL_CAP
         given_up += rc != 0
     assert big >= 20 and given_up <= 30, (big, given_up)
+
+
+@pytest.mark.parametrize("which", ["sky parts", "part bins", "doom2 scale"])
+def test_the_second_opinion_on_this_rounds_maps(synth, campath_mod, which):
+    """The geometry the limit maps and the doom2-scale map add — a round room under a sky, a wide flight of steps, a 768-room lattice with long
+    sight lines — through the numpy renderer (tests/np_front_end.py + np_mappers.py: shares no code with the oracle or the product) against
+    the oracle, whole frames with their map objects: the oracle's treatment of these shapes is not only its own opinion."""
+    import doomref
+    import np_front_end as nf
+    import np_mappers as nm
+    if which == "doom2 scale":
+        wad = synth.build_synth_iwad(2002, heavy=True, vanilla=True, grid=(32, 24), n_things=500)
+        osc = doomref.Scene(wad, "e1m1")
+        route = synth.synth_route(2002, heavy=True, vanilla=True, grid=(32, 24), n_things=500)
+        recs = list(campath_mod.make_camera_path(route, osc.floor_height_at, 4000)[[0, 1333, 2777]])
+    else:
+        build, pts, _, _ = LIMIT_VIEWS[which]
+        wad = build()
+        osc = doomref.Scene(wad, "e1m1")
+        recs = [_view(campath_mod, osc, x, y, a) for (x, y, a) in pts]
+    W, H = 160, 100
+    np_map, np_wad, things, sprites = nf.Map(wad, "e1m1"), nm.Wad(wad), nf.load_things(wad, "e1m1"), nf.SpriteTable(wad)
+    assert len(things) == osc.mobj_count()
+    for r in recs:
+        view = {"x": r[0], "y": r[1], "angle": r[2], "cos": r[3], "sin": r[4], "cos_neg": r[5], "sin_neg": r[6], "floor_height": r[7]}
+        got = nf.render_frame(np_map, things, sprites, np_wad, nm, W, H, view)
+        want = np.frombuffer(osc.render(W, H, r), dtype=np.uint8).reshape(H, W, 3)
+        bad = np.argwhere(np.any(got != want, axis=2))
+        assert len(bad) == 0, f"{which}: {len(bad)} pixels differ, first at (x={bad[0][1]}, y={bad[0][0]})"
