@@ -244,6 +244,11 @@ class DoomGpuBackend:
         if a.wad:
             self.wad = open(a.wad, "rb").read()          # a user-supplied IWAD (BASELINE configs verbatim); data = "file"
             route = self.cp.route_from_wad(self.wad, a.map)
+        elif getattr(a, "synth_map", None):               # SEED:COLUMNSxROWS:THINGS, heavy + vanilla (2002:32x24:500 = the doom2-scale map of the GPU tier)
+            seed, grid, things = a.synth_map.split(":")
+            kw = dict(heavy=True, vanilla=True, grid=tuple(int(v) for v in grid.split("x")), n_things=int(things))
+            self.wad = self.sw.build_synth_iwad(int(seed), **kw)
+            route = self.sw.synth_route(int(seed), **kw)
         else:
             self.wad = self.sw.build_synth_iwad(map_seed, heavy=heavy)
             route = self.sw.synth_route(map_seed, heavy=heavy)
@@ -426,7 +431,7 @@ def run(args, backend_factory=DoomGpuBackend):
 
     # ---- the other configurations through the same timed path (rank 0, N = 1 only) --------------------------------------
     side = None
-    if rank == 0 and world == 1 and not args.no_side_legs and backend_factory is DoomGpuBackend and args.config == 3 and not args.wad:
+    if rank == 0 and world == 1 and not args.no_side_legs and backend_factory is DoomGpuBackend and args.config == 3 and not args.wad and not args.synth_map:
         side = {}
         for key, (cfg, ht, k) in {"config2": (2, 0, 20), "config5": (5, 0, 5), "config3_two_host_threads": (3, 2, 5)}.items():   # (a config-2 step is 0.35 ms: 20 of them)
             try:
@@ -478,8 +483,9 @@ def run(args, backend_factory=DoomGpuBackend):
             "gpu_ms_per_batch": {"median": float(np.median(np.add(raster_ms, setup_ms))), "min": float(np.min(np.add(raster_ms, setup_ms))),
                                  "max": float(np.max(np.add(raster_ms, setup_ms))), "what": "front-end kernels + raster launch of each timed batch (HIP events on the kernel stream)"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "file" if args.wad else "synthetic",
-            "config": {"workload": f"BASELINE {CONFIGS[args.config][0]}; " +
-                                   (f"{os.path.basename(args.wad)} {args.map}" if args.wad else
+            "config": {"workload": (f"NOT a BASELINE configuration: generated map {args.synth_map} (seed:rooms:things, heavy + vanilla) at the size of " if args.synth_map and not args.wad else "BASELINE ") +
+                                   f"{CONFIGS[args.config][0]}; " +
+                                   (f"{os.path.basename(args.wad)} {args.map}" if args.wad else f"synthetic IWAD {args.synth_map}" if args.synth_map else
                                     "synthetic IWAD(s) " + " + ".join(f"seed {m}{' (heavy)' if hv else ''}" for (m, hv) in CONFIGS[args.config][4]) + " (no id WAD in the environment)") +
                                    f", {W}x{H} native; one step = 1000 frames in {batches_per_step} batches of {B} through "
                                    "host record generation + H2D + all kernels, frames left in HBM (SURVEY 8d)",
@@ -655,7 +661,7 @@ def side_leg(args, backend_factory, device, np, config: int, steps: int, host_th
     import copy
     a = copy.copy(args)
     name, a.width, a.height, a.batch, maps, camera = CONFIGS[config]
-    a.config, a.host_threads, a.wad = config, host_threads, None
+    a.config, a.host_threads, a.wad, a.synth_map = config, host_threads, None, None
     W, H, B = a.width, a.height, a.batch
     be = backend_factory(a, device)
     ctx = be.load(maps[0], 1993, camera)
@@ -752,6 +758,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=4, help="cpu_baseline renders every n-th path frame")
     ap.add_argument("--wad", default=None, help="IWAD file to render instead of the synthetic one (e.g. doom1.wad); the camera path is derived from the map")
     ap.add_argument("--map", default="e1m1")
+    ap.add_argument("--synth-map", default=None, help="SEED:COLUMNSxROWS:THINGS: a generated vanilla-shaped map of that many rooms and things instead of the config's "
+                                                     "(2002:32x24:500 = 18 131 segs, doom2's scale); not a BASELINE configuration, `config.workload` says so")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resident", action="store_true")
     ap.add_argument("--no-host-frames", action="store_true")

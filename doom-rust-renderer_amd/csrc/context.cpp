@@ -537,9 +537,8 @@ int upload_fs_scene(dg_ctx *c, const Scene &sc) {
     const size_t i_sky = add(sc.flat_sky.data(), sc.flat_sky.size());
     const size_t i_mobjs = add(sc.fs_mobjs.data(), sc.fs_mobjs.size() * sizeof(FsMobj));
     const size_t i_sframes = add(sc.sprite_frames.data(), sc.sprite_frames.size() * sizeof(SpriteFrameRec));
-    const size_t i_nodes = add(sc.fs_nodes.data(), sc.fs_nodes.size() * sizeof(FsNode));
     const size_t i_aoff = add(sc.fs_anc_off.data(), sc.fs_anc_off.size() * 4);
-    const size_t i_anc = add(sc.fs_anc.data(), sc.fs_anc.size() * 4);
+    const size_t i_anc = add(sc.fs_anc.data(), sc.fs_anc.size() * sizeof(FsAnc));
     HIP_TRY(hipMalloc((void **)&c->d_fs_scene, total));
     for (const Piece &p : pieces)
         if (p.bytes) HIP_TRY(hipMemcpy(c->d_fs_scene + p.at, p.src, p.bytes, hipMemcpyHostToDevice));
@@ -551,15 +550,15 @@ int upload_fs_scene(dg_ctx *c, const Scene &sc) {
     P.sectors = reinterpret_cast<const FsSector *>(at(i_sectors)); P.anims = reinterpret_cast<const FsAnim *>(at(i_anims));
     P.bitmaps = reinterpret_cast<const FsBitmap *>(at(i_bitmaps)); P.flat_sky = at(i_sky);
     P.mobjs = reinterpret_cast<const FsMobj *>(at(i_mobjs)); P.sframes = reinterpret_cast<const FsSpriteFrame *>(at(i_sframes));
-    P.nodes = reinterpret_cast<const FsNode *>(at(i_nodes)); P.anc_off = reinterpret_cast<const uint32_t *>(at(i_aoff)); P.anc = reinterpret_cast<const uint32_t *>(at(i_anc));
+    P.anc_off = reinterpret_cast<const uint32_t *>(at(i_aoff)); P.anc = reinterpret_cast<const FsAnc *>(at(i_anc));
     P.n_segs = (uint32_t)sc.segs.size(); P.n_leaves = (uint32_t)sc.subsectors.size(); P.n_mobjs = (uint32_t)sc.mobjs.size();
     P.sprite_stride = std::min<uint32_t>(FS_SPRITE_CAP, std::max<uint32_t>(32u, (P.n_mobjs + 31u) / 32u * 32u));
     P.sbin_stride = std::min<uint32_t>(FS_SBIN_CAP, P.sprite_stride * (uint32_t)((c->cfg.width + FE_BIN_W - 1) / FE_BIN_W));
-    // scratch: the candidate rows (zeroed before every walk), the leaves' visit positions
+    // scratch: the occupancy rows (zero before every walk: dg_fs_frame leaves them so), then the candidate rows they index (never cleared)
     const size_t F = (size_t)c->cfg.max_batch;
-    const size_t off_lite = align_up(F * FS_LANES * 4, 256);               // [slice counters | candidate rows]: zeroed together
-    c->fs_zero_bytes = off_lite + F * (size_t)P.n_segs * FS_CALLS * sizeof(uint2);
-    const size_t off_leaf = align_up(c->fs_zero_bytes, 256);
+    c->fs_zero_bytes = F * (size_t)fs_occ_words(P.n_segs) * 4;
+    const size_t off_lite = align_up(c->fs_zero_bytes, 256);
+    const size_t off_leaf = align_up(off_lite + F * (size_t)P.n_segs * FS_CALLS * sizeof(uint2), 256);
     // ... and, per frame, room for a candidate list longer than dg_fs_frame's shared memory holds (FS_CL_CAP) with its keep bits: sized by the
     // scene (every call of every seg), so that no frame of this map is handed back to the host for its number of candidates
     const uint32_t cl_row_cap = (P.n_segs * FS_CALLS + 31u) / 32u * 32u;
@@ -567,7 +566,7 @@ int upload_fs_scene(dg_ctx *c, const Scene &sc) {
     const size_t off_keep = align_up(off_cl + (cl_row_cap > FS_CL_CAP ? F * (size_t)cl_row_cap * 4 : 0), 256);
     HIP_TRY(hipMalloc((void **)&c->d_fs_scratch, off_keep + (cl_row_cap > FS_CL_CAP ? F * (size_t)(cl_row_cap / 32) * 4 : 0)));
     c->fs_rows_dirty = true;
-    P.slice_cnt = reinterpret_cast<uint32_t *>(c->d_fs_scratch);
+    P.occ = reinterpret_cast<uint32_t *>(c->d_fs_scratch);
     P.lite = reinterpret_cast<uint2 *>(c->d_fs_scratch + off_lite);
     P.cl_rows = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_cl);
     P.keep_rows = reinterpret_cast<uint32_t *>(c->d_fs_scratch + off_keep);

@@ -259,7 +259,9 @@ __global__ __launch_bounds__(FE_SCAN_THREADS) void dg_fe_scan(FeParams P) {
     // The walk's per-batch state goes back to zero here, after its last reader: the frame's flag word (above), its event words (read by
     // dg_fe_gaps) and the launch-order counters (read by dg_fe_columns) — the next batch of this slot then needs no fill kernel in front of
     // it (5 us plus a kernel boundary per batch; context.cpp clears everything once, and again after a failed enqueue).
-    const size_t ev_words = (size_t)P.max_sky_slots * (size_t)P.w64;
+    // (only the rows of the frame's own sky slots can hold bits: dg_fe_columns writes a part's row at its sky_slot < n_sky_slots; the rows of
+    // the slots up to the batch's bound stay as they were cleared — a third of the kernel's time when the bound is the seg walk's 64)
+    const size_t ev_words = (size_t)min(P.fframes[f].n_sky_slots, P.max_sky_slots) * (size_t)P.w64;
     for (int kind = 0; kind < 3; kind++) {
         uint64_t *ev = fe_event_words(P, f, 0, kind);
         for (size_t i = (size_t)tid; i < ev_words; i += FE_SCAN_THREADS) ev[i] = 0ull;

@@ -184,6 +184,13 @@ template <typename K>
 DG_HD int32_t fs_seg(const K &k, const FsSeg &sg, const FsSector *sectors, const FsAnim *anims, V2 ppos, float cos_na, float sin_na, float player_height,
                      float timestamp, int16_t light, FsSegOut &o) {
     if (sg.front_sector < 0) return FS_SKIP;
+    // (the clip comes first here: it needs the seg's two vertices only and turns away most segs of a map; the sector heights the
+    // reference reads before it — segs.rs:364-402 — have no side effects and are read below, by the segs that are left)
+    V2 a = v2_rot(v2_sub(V2{sg.v1x, sg.v1y}, ppos), cos_na, sin_na);
+    V2 b = v2_rot(v2_sub(V2{sg.v2x, sg.v2y}, ppos), cos_na, sin_na);
+    if (!clip_to_viewport(Seg2{a, b}, o.cl)) return FS_SKIP;
+    if (o.cl.line.a.x < -0.01f) return FS_FAIL_CLIP_X;
+
     const FsSector &fs = sectors[sg.front_sector];
     const FsSector *bs = sg.back_sector >= 0 ? &sectors[sg.back_sector] : nullptr;
     float floor_height = (float)fs.floor_h, ceiling_height = (float)fs.ceil_h;
@@ -194,11 +201,6 @@ DG_HD int32_t fs_seg(const K &k, const FsSeg &sg, const FsSector *sectors, const
         if (bs->ceil_h < fs.ceil_h) { has_pt = true; pt_h = (float)bs->ceil_h; }
     }
     const bool two_sided = (sg.ld_flags & 4) != 0, top_unpegged = (sg.ld_flags & 8) != 0, bottom_unpegged = (sg.ld_flags & 16) != 0;
-
-    V2 a = v2_rot(v2_sub(V2{sg.v1x, sg.v1y}, ppos), cos_na, sin_na);
-    V2 b = v2_rot(v2_sub(V2{sg.v2x, sg.v2y}, ppos), cos_na, sin_na);
-    if (!clip_to_viewport(Seg2{a, b}, o.cl)) return FS_SKIP;
-    if (o.cl.line.a.x < -0.01f) return FS_FAIL_CLIP_X;
 
     ScreenLine fl = project(k, o.cl.line, floor_height - player_height);
     if (fl.sx > fl.ex) return FS_SKIP;                            // back face

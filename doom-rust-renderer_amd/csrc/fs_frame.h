@@ -42,8 +42,10 @@ constexpr uint32_t FS_BIN_CAP = 4096;          // (part, column bin) pairs of on
 constexpr uint32_t FS_SBIN_CAP = 4096;         // (sprite, column bin) pairs
 constexpr uint32_t FS_BEHIND_WORDS = FS_PART_CAP / 32;
 
-struct FsNode { float x, y, dx, dy; uint32_t segs_right, segs_left; };       // partition line + seg counts of the two subtrees
-static_assert(sizeof(FsNode) == 24, "FsNode layout");
+// One ancestor of one leaf: the partition line, and the seg count of the subtree on the OTHER side of it (visited before the leaf when the
+// viewer stands on that side) | (the leaf lies in the LEFT subtree) << 31
+struct FsAnc { float x, y, dx, dy; uint32_t front; };
+static_assert(sizeof(FsAnc) == 20, "FsAnc layout");
 
 
 struct FsParams {
@@ -52,7 +54,7 @@ struct FsParams {
     const FsSeg *segs; const uint16_t *seg_leaf; const uint32_t *leaf_first;
     const FsSector *sectors; const FsAnim *anims; const FsBitmap *bitmaps; const uint8_t *flat_sky;
     const FsMobj *mobjs; const FsSpriteFrame *sframes;
-    const FsNode *nodes; const uint32_t *anc_off; const uint32_t *anc;           // per leaf: its ancestors, root first: node | (lies in the LEFT subtree) << 31
+    const uint32_t *anc_off; const FsAnc *anc;                                   // per leaf: its ancestors, root first (entries [anc_off[leaf], anc_off[leaf + 1]))
     uint32_t n_segs, n_leaves, n_mobjs;
     // per-frame strides of the sprite arrays below: the scene's map-object count (no frame can show more), rounded up, at most FS_SPRITE_CAP /
     // FS_SBIN_CAP — a map with 40 things keeps its records 64 apart, not 512
@@ -65,10 +67,11 @@ struct FsParams {
     const dg_view *views;                      // [n_frames], trig filled
     int32_t n_frames;
     // scratch (shared by all slots: every kernel runs on the ctx's one stream)
-    // [frame][visit position of the seg x FS_CALLS + call], zeroed per batch: x = sx | ex << 16, y = FEP_* (bits 0-7) | 1 << 8 | seg << 12
-    // for a call that reaches its column loop (dg_fs_segs): the frame's candidate parts, already in the reference's visit order
+    // [frame][visit position of the seg x FS_CALLS + call]: x = sx | ex << 16, y = FEP_* (bits 0-7) | 1 << 8 | seg << 12
+    // for a call that reaches its column loop (dg_fs_segs): the frame's candidate parts, already in the reference's visit order.  Which
+    // entries of the row hold a candidate of THIS batch says the frame's occupancy row (one bit per entry): the row itself is never cleared
     uint2 *lite;
-    uint32_t *slice_cnt;                       // [frame][FS_LANES], zeroed per batch: parts in each lane's slice of the frame's row (dg_fs_frame's prefix sums start from these)
+    uint32_t *occ;                             // [frame][fs_occ_words(n_segs)], zero between batches (dg_fs_frame clears what dg_fs_segs set): bit e = entry e of the frame's row
     // a frame with more candidate parts than dg_fs_frame stages in shared memory (FS_CL_CAP) keeps its candidate list and keep bits here:
     // [frame][cl_row_cap] words + [frame][cl_row_cap / 32] words (cl_row_cap: a multiple of 32, = n_segs x FS_CALLS rounded up; 0: none)
     uint32_t *cl_rows, *keep_rows;
@@ -93,12 +96,25 @@ DG_HD uint32_t fs_leaf_base(const FsParams &P, int f, uint32_t leaf) {
     const dg_view &v = P.views[f];
     const V2 ppos{v.x, v.y};
     uint32_t base = 0;
-    for (uint32_t i = P.anc_off[leaf]; i < P.anc_off[leaf + 1]; i++) {
-        const uint32_t a = P.anc[i];
-        const FsNode &n = P.nodes[a & 0x7fffffffu];
-        const bool is_left = left_of(ppos, Seg2{V2{n.x, n.y}, V2{n.x + n.dx, n.y + n.dy}});     // mod.rs:70-77: the viewer's side is visited first
-        const bool leaf_left = (a >> 31) != 0;
-        if (leaf_left != is_left) base += is_left ? n.segs_left : n.segs_right;                 // the whole front subtree comes before this leaf
+    // four ancestors per round, fetched together: a loop of one ancestor per turn pays a memory latency per ancestor, and a large map has
+    // thirty of them above a leaf.  (The list carries each ancestor's line and count itself — a list of node indices costs a second,
+    // dependent fetch per ancestor.)
+    const uint32_t i1 = P.anc_off[leaf + 1];
+    for (uint32_t i = P.anc_off[leaf]; i < i1; i += 4) {
+        FsAnc a[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t j = 0; j < 4; j++) a[j] = P.anc[i + j < i1 ? i + j : i1 - 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t j = 0; j < 4; j++) {
+            if (i + j >= i1) continue;
+            const bool is_left = left_of(ppos, Seg2{V2{a[j].x, a[j].y}, V2{a[j].x + a[j].dx, a[j].y + a[j].dy}});   // mod.rs:70-77: the viewer's side is visited first
+            const bool leaf_left = (a[j].front >> 31) != 0;
+            if (leaf_left != is_left) base += a[j].front & 0x7fffffffu;                            // the whole front subtree comes before this leaf
+        }
     }
     return base;
 }
@@ -111,43 +127,70 @@ DG_HD void fs_flag(const FsParams &P, int f, uint32_t bits) {
     P.flags[f] |= bits;
 #endif
 }
-DG_HD void fs_count(uint32_t *counter) {
+DG_HD void fs_or_u32(uint32_t *p, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    atomicAdd(counter, 1u);
+    atomicOr(p, v);
 #else
-    *counter += 1u;
+    *p |= v;
 #endif
 }
-// Entries of a frame's candidate row that one lane of dg_fs_frame owns (lane l: [l * len, (l + 1) * len))
-DG_HD uint32_t fs_slice_len(uint32_t n_segs) { return (n_segs * FS_CALLS + FS_LANES - 1) / FS_LANES; }
-// body(i, entry) for every entry i of the lane's slice, the loads issued eight at a time (a loop of dependent single loads would pay
-// the memory latency once per entry)
-template <typename Body> DG_HD void fs_for_slice(const uint2 *row, uint32_t n, uint32_t len, int lane, Body body) {
-    const uint32_t i0 = (uint32_t)lane * len, i1 = i0 + len < n ? i0 + len : n;
-    for (uint32_t i = i0; i < i1; i += 8) {
-        uint2 q[8];
+// The occupancy row of a frame: lane l of dg_fs_frame owns words [l * wpl, (l + 1) * wpl) of it — entries [l * wpl * 32, ..) of the candidate row
+DG_HD uint32_t fs_occ_wpl(uint32_t n_segs) { return ((n_segs * FS_CALLS + 31u) / 32u + FS_LANES - 1) / FS_LANES; }
+DG_HD uint32_t fs_occ_words(uint32_t n_segs) { return fs_occ_wpl(n_segs) * FS_LANES; }
+DG_HD uint32_t fs_ctz(uint32_t v) { return (uint32_t)__builtin_ctz(v); }           // (v != 0)
+DG_HD uint32_t fs_popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+// body(i, entry) for every occupied entry i of the lane's slice, in row order; the entries of up to eight set bits of a word are fetched
+// together (a seg's calls sit next to each other in the row)
+template <typename Body> DG_HD void fs_for_occupied(const uint32_t *occ, const uint2 *row, uint32_t wpl, int lane, Body body) {
+    for (uint32_t w = (uint32_t)lane * wpl; w < ((uint32_t)lane + 1u) * wpl; w++) {
+        uint32_t bits = occ[w];
+        while (bits) {
+            uint32_t e[8];
+            uint2 q[8];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (uint32_t j = 0; j < 8; j++) q[j] = row[i + j < n ? i + j : n - 1];
+            for (uint32_t j = 0; j < 8; j++) {
+                e[j] = bits ? w * 32u + fs_ctz(bits) : 0xffffffffu;
+                bits &= bits - 1u;                                            // (0 stays 0)
+            }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (uint32_t j = 0; j < 8; j++)
-            if (i + j < i1) body(i + j, q[j]);
+            for (uint32_t j = 0; j < 8; j++) q[j] = row[e[j] != 0xffffffffu ? e[j] : e[0]];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (uint32_t j = 0; j < 8; j++)
+                if (e[j] != 0xffffffffu) body(e[j], q[j]);
+        }
     }
 }
+// The whole 48-byte record in one fetch: field by field the compiler fetches what each step needs when it needs it, a chain of memory
+// latencies in front of the clip test that turns most segs away.
+DG_HD FsSeg fs_load_seg(const FsSeg *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    union U { uint4 w[3]; FsSeg s; __device__ U() {} } u;
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    u.w[0] = q[0]; u.w[1] = q[1]; u.w[2] = q[2];
+    return u.s;
+#else
+    return *p;
+#endif
+}
+static_assert(sizeof(FsSeg) == 48, "fs_load_seg");
 DG_HD void fs_seg_lane(const FsParams &P, int f, uint32_t si) {
     const dg_view &v = P.views[f];
-    const FsSeg &sg = P.segs[si];
+    const uint32_t leaf = P.seg_leaf[si];
+    const FsSeg sg = fs_load_seg(P.segs + si);
     FsSegOut so;
-    const int16_t light = sg.front_sector >= 0 ? P.sector_light[(size_t)f * P.light_stride + (size_t)sg.front_sector] : (int16_t)0;
-    const int32_t st = fs_seg(P.k, sg, P.sectors, P.anims, V2{v.x, v.y}, v.cos_na, v.sin_na, v.floor_height + 41.0f, v.timestamp, light, so);
-    if (st == FS_SKIP) return;
+    // (the sector's light level is not read here: nothing below looks at it, fs_ph_emit fetches it for the parts that are kept)
+    const int32_t st = fs_seg(P.k, sg, P.sectors, P.anims, V2{v.x, v.y}, v.cos_na, v.sin_na, v.floor_height + 41.0f, v.timestamp, (int16_t)0, so);
+    if (st == FS_SKIP || leaf == 0xffffu) return;                             // (a seg of no reachable leaf is never visited; asked here, after the
+                                                                              // clip, so that the seg's record is not fetched behind its leaf's)
     if (st != FS_OK) { fs_flag(P, f, FE_OVF_SEGS); return; }
     // Only what the hidden-part culling reads is computed here — the columns and the flags of every call; the finished FePart of the
     // few calls that survive it (a tenth of them) is built afterwards, by dg_fs_frame, from (seg, call).
-    const uint32_t leaf = P.seg_leaf[si];
     const uint32_t pos = fs_leaf_base(P, f, leaf) + (si - P.leaf_first[leaf]);
     uint2 *lite = P.lite + ((size_t)f * P.n_segs + pos) * FS_CALLS;
 #pragma unroll
@@ -159,7 +202,8 @@ DG_HD void fs_seg_lane(const FsParams &P, int f, uint32_t si) {
         if (ps == FS_SKIP) continue;                                          // nothing (a zero-width part)
         if (ps != FS_OK) { fs_flag(P, f, FE_OVF_SEGS); continue; }
         lite[i] = uint2{(uint32_t)sx | ((uint32_t)ex << 16), flags | 0x100u | (si << 12)};
-        fs_count(&P.slice_cnt[(size_t)f * FS_LANES + (pos * FS_CALLS + (uint32_t)i) / fs_slice_len(P.n_segs)]);
+        const uint32_t e = pos * FS_CALLS + (uint32_t)i;
+        fs_or_u32(&P.occ[(size_t)f * fs_occ_words(P.n_segs) + (e >> 5)], 1u << (e & 31u));
     }
 }
 
@@ -217,7 +261,13 @@ DG_HD uint32_t fs_lane_offset(const FsShared &S, int lane) {
 
 // phases 1a / 1b: the candidates of the frame, in visit order, into cl[].  Lane l owns the slice [l * per, (l + 1) * per) of the frame's
 // lite row (entries that hold no part are skipped; the order of the others is the reference's visit order).
-DG_HD void fs_ph_cand_count(const FsParams &P, FsShared &S, int f, int lane) { S.lane_cnt[lane] = P.slice_cnt[(size_t)f * FS_LANES + lane]; }
+DG_HD void fs_ph_cand_count(const FsParams &P, FsShared &S, int f, int lane) {
+    const uint32_t wpl = fs_occ_wpl(P.n_segs);
+    const uint32_t *occ = P.occ + (size_t)f * wpl * FS_LANES + (size_t)lane * wpl;
+    uint32_t c = 0;
+    for (uint32_t w = 0; w < wpl; w++) c += fs_popc(occ[w]);
+    S.lane_cnt[lane] = c;
+}
 DG_HD void fs_ph_cand_stage(const FsParams &P, FsShared &S, int f, int lane) {
     const uint32_t n = P.n_segs * FS_CALLS;
     uint32_t at = fs_lane_offset(S, lane);
@@ -234,8 +284,8 @@ DG_HD void fs_ph_cand_stage(const FsParams &P, FsShared &S, int f, int lane) {
     uint32_t *cl = big ? P.cl_rows + (size_t)f * P.cl_row_cap : S.cl;
     uint32_t *keepw = big ? P.keep_rows + (size_t)f * (P.cl_row_cap / 32) : S.keepw;
     for (uint32_t w = (uint32_t)lane; w < (big ? (total + 31u) / 32u : FS_CL_CAP / 32u); w += FS_LANES) keepw[w] = 0;
-    fs_for_slice(P.lite + (size_t)f * n, n, fs_slice_len(P.n_segs), lane, [&](uint32_t, const uint2 q) {
-        if (!(q.y & 0x100u)) return;
+    if (S.lane_cnt[lane] == 0u) return;
+    fs_for_occupied(P.occ + (size_t)f * fs_occ_words(P.n_segs), P.lite + (size_t)f * n, fs_occ_wpl(P.n_segs), lane, [&](uint32_t, const uint2 q) {
         cl[at] = (q.x & 0xfffu) | ((q.x >> 16) << 12) | (q.y << 24);
         at++;
     });
@@ -243,13 +293,6 @@ DG_HD void fs_ph_cand_stage(const FsParams &P, FsShared &S, int f, int lane) {
 // phase 2c: the column table starts empty
 DG_HD void fs_ph_first_clear(const FsParams &P, FsShared &S, int lane) {
     for (int c = lane; c < P.k.W; c += FS_LANES) S.first[c] = 0xffffffffu;
-}
-DG_HD void fs_or_u32(uint32_t *p, uint32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    atomicOr(p, v);
-#else
-    *p |= v;
-#endif
 }
 DG_HD uint32_t fs_add_u32(uint32_t *p, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -317,8 +360,7 @@ DG_HD void fs_ph_kept_place(const FsParams &P, FsShared &S, int f, int lane) {
     if (S.fail || S.lane_cnt[lane] == 0u) return;                        // (no survivor in this lane's slice: nothing to look up)
     const uint32_t *keepw = fs_keepw(P, S, f);
     uint32_t k = S.lane_k0[lane];
-    fs_for_slice(P.lite + (size_t)f * n, n, fs_slice_len(P.n_segs), lane, [&](uint32_t i, const uint2 q) {
-        if (!(q.y & 0x100u)) return;
+    fs_for_occupied(P.occ + (size_t)f * fs_occ_words(P.n_segs), P.lite + (size_t)f * n, fs_occ_wpl(P.n_segs), lane, [&](uint32_t i, const uint2 q) {
         const bool kept = (keepw[k >> 5] >> (k & 31u)) & 1u;
         k++;
         if (!kept) return;
@@ -453,7 +495,6 @@ DG_HD uint32_t *fs_bin_mask(FsShared &S, uint32_t nb, uint32_t kind, uint32_t b)
     return kind ? S.first + nb * FS_PMASK_WORDS + b * FS_SMASK_WORDS : S.first + b * FS_PMASK_WORDS;
 }
 DG_HD uint32_t *fs_bin_off(FsShared &S, uint32_t nb, uint32_t kind) { return S.first + nb * (FS_PMASK_WORDS + FS_SMASK_WORDS) + kind * nb; }
-DG_HD uint32_t fs_popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
 DG_HD void fs_ph_bin_clear(const FsParams &P, FsShared &S, int lane) {
     const uint32_t nb = (uint32_t)(P.k.W + FE_BIN_W - 1) / FE_BIN_W;
     for (uint32_t i = (uint32_t)lane; i < nb * (FS_PMASK_WORDS + FS_SMASK_WORDS + 2); i += FS_LANES) S.first[i] = 0u;
@@ -526,13 +567,12 @@ DG_HD void fs_ph_bin_fill(const FsParams &P, FsShared &S, int f, int lane) {
         for (uint32_t b = S.s_x0b[q]; b <= S.s_x1b[q] && b < nb; b++)
             P.sbin_sprites[(size_t)f * P.sbin_stride + place(1, q, b)] = (uint16_t)q;
 }
-// phase 10a: the frame's candidate row and slice counters go back to zero for the next batch (the rows are zeroed once, at upload: a
-// memset of all rows per batch is a 28 MB fill kernel plus a launch in front of every walk)
+// phase 10a: the frame's occupancy row goes back to zero for the next batch (the rows are zeroed once, at upload: a memset of all rows
+// per batch is a fill kernel plus a launch in front of every walk).  The candidate row itself keeps its stale entries: no bit, no entry.
 DG_HD void fs_ph_clean(const FsParams &P, int f, int lane) {
-    const uint32_t n = P.n_segs * FS_CALLS;
-    uint2 *row = P.lite + (size_t)f * n;
-    for (uint32_t i = (uint32_t)lane; i < n; i += FS_LANES) row[i] = uint2{0u, 0u};
-    P.slice_cnt[(size_t)f * FS_LANES + lane] = 0u;
+    const uint32_t wpl = fs_occ_wpl(P.n_segs);
+    uint32_t *occ = P.occ + (size_t)f * wpl * FS_LANES + (size_t)lane * wpl;
+    for (uint32_t w = 0; w < wpl; w++) occ[w] = 0u;
 }
 // phase 10 (lane 0): the frame header the column walk reads; a frame that was given up carries nothing and is flagged for the host
 DG_HD void fs_ph_header(const FsParams &P, FsShared &S, int f) {

@@ -12,7 +12,7 @@ namespace {
 
 __global__ __launch_bounds__(64) void dg_fs_segs(FsParams P) {
     const uint32_t si = blockIdx.x * 64u + threadIdx.x;
-    if (si < P.n_segs && P.seg_leaf[si] != 0xffffu) fs_seg_lane(P, (int)blockIdx.y, si);
+    if (si < P.n_segs) fs_seg_lane(P, (int)blockIdx.y, si);
 }
 
 // One workgroup (four wavefronts) per frame.  What the phases cost is their dependent loads, which is why the serial ones (lane 0)

@@ -6,8 +6,8 @@
 
 namespace dg {
 
-// dg_fs_segs, dg_fs_frame on `stream`.  P.flags must be zeroed (in stream order) before the launch; P.lite and P.slice_cnt must be zero as well —
-// dg_fs_frame leaves them so (the context zeroes them at upload and after a launch that failed half way).
+// dg_fs_segs, dg_fs_frame on `stream`.  P.flags must be zeroed (in stream order) before the launch; P.occ must be zero as well —
+// dg_fs_frame leaves it so (the context zeroes it at upload and after a launch that failed half way).
 // start: attached to the first kernel's dispatch.
 hipError_t launch_fs(const FsParams &P, hipStream_t stream, hipEvent_t start = nullptr);
 

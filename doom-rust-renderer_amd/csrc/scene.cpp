@@ -446,7 +446,6 @@ void Scene::rebuild_fs_tables() {
         }
     }
     // the tree: depth-first from the root (the last node, map/mod.rs:57); a leaf reached twice or a path longer than 256 is not a tree
-    fs_nodes.assign(nodes.size(), FsNode{0, 0, 0, 0, 0, 0});
     fs_anc_off.assign(subsectors.size() + 1, 0);
     fs_anc.clear();
     if (fs_ok) {
@@ -481,15 +480,14 @@ void Scene::rebuild_fs_tables() {
         for (size_t l = 0; l < subsectors.size() && fs_ok; l++)        // a leaf no path leads to: its segs are never visited
             if (!seen_leaf[l])
                 for (int i = 0; i < subsectors[l].count; i++) fs_seg_leaf[(size_t)(subsectors[l].first + i)] = (uint16_t)0xffffu;
-        for (size_t n = 0; n < nodes.size() && fs_ok; n++) {
-            fs_nodes[n].x = nodes[n].x; fs_nodes[n].y = nodes[n].y; fs_nodes[n].dx = nodes[n].dx; fs_nodes[n].dy = nodes[n].dy;
-        }
+        std::vector<uint32_t> segs_left(nodes.size(), 0), segs_right(nodes.size(), 0);        // segs below each child of a node
+        for (size_t l = 0; l < subsectors.size() && fs_ok; l++)
+            for (uint32_t e : chains[l]) (e >> 31 ? segs_left : segs_right)[e & 0x7fffffffu] += (uint32_t)subsectors[l].count;
         for (size_t l = 0; l < subsectors.size() && fs_ok; l++) {
             fs_anc_off[l] = (uint32_t)fs_anc.size();
             for (uint32_t e : chains[l]) {
-                fs_anc.push_back(e);
-                FsNode &n = fs_nodes[e & 0x7fffffffu];
-                if (e >> 31) n.segs_left += (uint32_t)subsectors[l].count; else n.segs_right += (uint32_t)subsectors[l].count;
+                const size_t n = e & 0x7fffffffu;
+                fs_anc.push_back(FsAnc{nodes[n].x, nodes[n].y, nodes[n].dx, nodes[n].dy, (e >> 31 ? segs_right[n] : segs_left[n]) | (e & 0x80000000u)});
             }
         }
         fs_anc_off[subsectors.size()] = (uint32_t)fs_anc.size();

@@ -96,8 +96,8 @@ struct Scene {
     // BSP tables of the device seg walk (fs_frame.h): per node its partition and the seg counts of its subtrees; per leaf its ancestors,
     // root first (node | lies-in-the-LEFT-subtree << 31).  fs_ok: the map is a proper tree whose leaves partition the segs they
     // reference — otherwise (and for maps in which a texture / flat lookup would panic) only the host walker is used.
-    std::vector<FsNode> fs_nodes;
-    std::vector<uint32_t> fs_anc_off, fs_anc, fs_leaf_first;
+    std::vector<FsAnc> fs_anc;
+    std::vector<uint32_t> fs_anc_off, fs_leaf_first;
     bool fs_ok = false;
     const FsSpriteFrame *sprite_frames_fs() const { return reinterpret_cast<const FsSpriteFrame *>(sprite_frames.data()); }
     void rebuild_fs_tables();

@@ -568,7 +568,7 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     std::vector<int32_t> mstate(sc.mobjs.size());
     for (size_t i = 0; i < sc.mobjs.size(); i++) mstate[i] = sc.mobjs[i].sprite_frame < 0 ? -1 : sc.mobjs[i].sprite_frame * 2 + (sc.mobjs[i].full_bright ? 1 : 0);
     std::vector<uint32_t> flags(1, 0);
-    std::vector<uint2> lite(sc.segs.size() * FS_CALLS + 1, uint2{0u, 0u});
+    std::vector<uint2> lite(sc.segs.size() * FS_CALLS + 1, uint2{0xdeadbeefu, 0xdeadbeefu});      // (stale entries: only what the occupancy row marks may be read)
     std::vector<FeFrame> ffr(1);
     std::vector<FePart> parts(FS_PART_CAP);
     std::vector<FeSprite> sprites(FS_SPRITE_CAP);
@@ -579,23 +579,23 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     P.segs = sc.fs_segs.data(); P.seg_leaf = sc.fs_seg_leaf.data(); P.leaf_first = sc.fs_leaf_first.data();
     P.sectors = sc.fs_sectors.data(); P.anims = sc.fs_anims.data(); P.bitmaps = sc.fs_bitmaps.data(); P.flat_sky = sc.flat_sky.data();
     P.mobjs = sc.fs_mobjs.data(); P.sframes = sc.sprite_frames_fs();
-    P.nodes = sc.fs_nodes.data(); P.anc_off = sc.fs_anc_off.data(); P.anc = sc.fs_anc.data();
+    P.anc_off = sc.fs_anc_off.data(); P.anc = sc.fs_anc.data();
     P.n_segs = (uint32_t)sc.segs.size(); P.n_leaves = (uint32_t)sc.subsectors.size(); P.n_mobjs = (uint32_t)sc.mobjs.size();
     P.sprite_stride = std::min<uint32_t>(FS_SPRITE_CAP, std::max<uint32_t>(32u, (P.n_mobjs + 31u) / 32u * 32u));        // (context.cpp: upload_fs_scene)
     P.sbin_stride = std::min<uint32_t>(FS_SBIN_CAP, P.sprite_stride * nb);
     P.sector_light = lights.data(); P.mobj_state = mstate.data();
     P.views = &view; P.n_frames = 1;
-    std::vector<uint32_t> slice_cnt(FS_LANES, 0);
+    std::vector<uint32_t> occ(fs_occ_words(P.n_segs), 0);
     const uint32_t cl_row_cap = (P.n_segs * FS_CALLS + 31u) / 32u * 32u;                                  // (context.cpp: upload_fs_scene)
     std::vector<uint32_t> cl_rows(cl_row_cap, 0xdeadbeefu), keep_rows(cl_row_cap / 32, 0xdeadbeefu);
     P.cl_rows = cl_rows.data(); P.keep_rows = keep_rows.data(); P.cl_row_cap = g_no_cl_rows ? 0u : cl_row_cap;
-    P.lite = lite.data(); P.slice_cnt = slice_cnt.data(); P.flags = flags.data();
+    P.lite = lite.data(); P.occ = occ.data(); P.flags = flags.data();
     P.fframes = ffr.data(); P.parts = parts.data(); P.sprites = sprites.data(); P.behind = behind.data(); P.sky_parts = sky_parts.data();
     P.bin_off = bin_off.data(); P.bin_parts = bin_parts.data(); P.sbin_off = sbin_off.data(); P.sbin_sprites = sbin_sprites.data();
 
     for (uint32_t s = 0; s < P.n_segs; s++) if (P.seg_leaf[s] != 0xffffu) fs_seg_lane(P, 0, s);             // dg_fs_segs
     uint32_t n_cand = 0;                                                                                   // process_sidedef calls that reach their column loop
-    for (const uint2 &q : lite) n_cand += (q.x | q.y) != 0u;
+    for (uint32_t w : occ) n_cand += (uint32_t)__builtin_popcount(w);
     static thread_local FsShared S;                                                                        // dg_fs_frame
     static thread_local FsSpriteTmp T[FS_LANES];
 #define LANES(body) for (int lane = 0; lane < FS_LANES; lane++) { body; }
@@ -628,8 +628,7 @@ extern "C" int emul_fs_frame(void *scene, int W, int H, const dg_view *view_in, 
     LANES(fs_ph_clean(P, 0, lane))
     fs_ph_header(P, S, 0);
 #undef LANES
-    for (const uint2 &q : lite) if (q.x | q.y) { g_err = "dg_fs_frame left a candidate row dirty"; return -3; }
-    for (uint32_t v : slice_cnt) if (v) { g_err = "dg_fs_frame left a slice counter dirty"; return -3; }
+    for (uint32_t w : occ) if (w) { g_err = "dg_fs_frame left an occupancy row dirty"; return -3; }
     const FeFrame &ff = ffr[0];
     if (stats) { stats[0] = ff.n_parts; stats[1] = ff.n_sprites; stats[2] = ff.n_sky_slots; stats[3] = flags[0]; stats[4] = 0; stats[5] = n_cand; }
     if (host_rc) {                                    // the host walker refuses the frame: the device walk must have given it up too
