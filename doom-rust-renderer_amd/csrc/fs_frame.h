@@ -310,30 +310,42 @@ DG_HD void fs_min_u32(uint32_t *p, uint32_t v) {
     if (v < *p) *p = v;
 #endif
 }
-// phases 2d / 2e: FS_GROUP lanes share a candidate and stride over its columns; the groups take the candidates round robin.
+// phases 2d / 2e: FS_GROUP lanes share a candidate and stride over its columns; the groups take the candidates round robin, four of a group's
+// candidates fetched together (a frame's list may live in global memory: one candidate per turn is one memory latency per candidate).
+template <typename Body> DG_HD void fs_for_group_candidates(const uint32_t *cl, uint32_t n_cl, uint32_t g, Body body) {
+    constexpr uint32_t STEP = FS_LANES / FS_GROUP;
+    for (uint32_t k = g; k < n_cl; k += 4 * STEP) {
+        uint32_t q[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t j = 0; j < 4; j++) q[j] = cl[k + j * STEP < n_cl ? k + j * STEP : k];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t j = 0; j < 4; j++)
+            if (k + j * STEP < n_cl) body(k + j * STEP, q[j]);
+    }
+}
 DG_HD void fs_ph_solids(const FsParams &P, FsShared &S, int f, int lane) {
     if (S.fail) return;
     const uint32_t g = (uint32_t)lane / FS_GROUP, sub = (uint32_t)lane % FS_GROUP;
-    const uint32_t *cl = fs_cl(P, S, f);
-    for (uint32_t k = g; k < S.n_cl; k += FS_LANES / FS_GROUP) {
-        const uint32_t q = cl[k];
-        if (!fs_part_is_solid(q >> 24)) continue;
+    fs_for_group_candidates(fs_cl(P, S, f), S.n_cl, g, [&](uint32_t k, uint32_t q) {
+        if (!fs_part_is_solid(q >> 24)) return;
         const uint32_t sx = q & 0xfffu, ex = (q >> 12) & 0xfffu;
         for (uint32_t c = sx + sub; c <= ex; c += FS_GROUP) fs_min_u32(&S.first[c], k);
-    }
+    });
 }
 DG_HD void fs_ph_keep(const FsParams &P, FsShared &S, int f, int lane) {
     if (S.fail) return;
     const uint32_t g = (uint32_t)lane / FS_GROUP, sub = (uint32_t)lane % FS_GROUP;
-    const uint32_t *cl = fs_cl(P, S, f);
     uint32_t *keepw = fs_keepw(P, S, f);
-    for (uint32_t k = g; k < S.n_cl; k += FS_LANES / FS_GROUP) {
-        const uint32_t q = cl[k];
+    fs_for_group_candidates(fs_cl(P, S, f), S.n_cl, g, [&](uint32_t k, uint32_t q) {
         const uint32_t sx = q & 0xfffu, ex = (q >> 12) & 0xfffu;
         bool open = false;
         for (uint32_t c = sx + sub; c <= ex; c += FS_GROUP) open |= S.first[c] >= k;
         if (open) fs_or_u32(&keepw[k >> 5], 1u << (k & 31u));
-    }
+    });
 }
 // phases 2f / 2g: the survivors get their place in the frame's part list (and their sky event slot).  Lane l walks its slice of the lite
 // row again (candidate indices from lane_k0); lane_cnt packs (survivors | survivors that want a sky slot << 16).
