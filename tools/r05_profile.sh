@@ -19,6 +19,10 @@ for c in 2 3; do
   run trace_segs_c$c rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_segs_c$c -- python3 bench.py --config $c --front-end segs --steps 20 --warmup 2 --no-cpu-baseline --no-resident --no-host-frames --no-latency --no-side-legs
   cat $OUT/trace_segs_c$c/*/*_kernel_stats.csv | cut -d, -f1-4,6,7 | head -12
 done
+# config 2 with the raster launch on the kernel stream (no overlap): the front-end kernels' own durations
+DOOMGPU_RASTER_OVERLAP=0 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_segs_c2_serial -- python3 bench.py --config 2 --front-end segs --steps 20 --warmup 2 --no-cpu-baseline --no-resident --no-host-frames --no-latency --no-side-legs > $OUT/trace_segs_c2_serial.log 2>&1 && { echo "config 2, one stream"; cat $OUT/trace_segs_c2_serial/*/*_kernel_stats.csv | cut -d, -f1-4,6,7 | head -9; }
+# the doom2-scale map through the seg walk
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_segs_doom2 -- python3 bench.py --config 3 --synth-map 2002:32x24:500 --front-end segs --steps 10 --warmup 1 --no-cpu-baseline --no-resident --no-host-frames --no-latency --no-side-legs > $OUT/trace_segs_doom2.log 2>&1 && { echo "doom2-scale map"; cat $OUT/trace_segs_doom2/*/*_kernel_stats.csv | cut -d, -f1-4,6,7 | head -9; }
 python3 tools/issue_counters.py $OUT 1280x800x1000 --out $OUT/issue.json
 python3 tools/summarize_prof.py $OUT "default bench (round 5)" > $OUT/summary.md
 head -20 $OUT/summary.md
