@@ -433,9 +433,12 @@ def run(args, backend_factory=DoomGpuBackend):
     side = None
     if rank == 0 and world == 1 and not args.no_side_legs and backend_factory is DoomGpuBackend and args.config == 3 and not args.wad and not args.synth_map:
         side = {}
-        for key, (cfg, ht, k) in {"config2": (2, 0, 20), "config5": (5, 0, 5), "config3_two_host_threads": (3, 2, 5)}.items():   # (a config-2 step is 0.35 ms: 20 of them)
+        # (a config-2 step is 0.35 ms: 20 of them; config 2 a second time with the device seg walk forced: what the kernels do when DG_FE_AUTO does
+        # not spend one of the leg's 21 batches timing the host walker)
+        for key, (cfg, ht, k, fe) in {"config2": (2, 0, 20, None), "config2_seg_walk": (2, 0, 20, "segs"), "config5": (5, 0, 5, None),
+                                      "config3_two_host_threads": (3, 2, 5, None)}.items():
             try:
-                side[key] = side_leg(args, backend_factory, device, np, cfg, k, ht)
+                side[key] = side_leg(args, backend_factory, device, np, cfg, k, ht, fe)
             except Exception as e:                        # a side measurement must not take the headline line down with it
                 side[key] = {"error": repr(e)}
 
@@ -654,7 +657,7 @@ def host_frames_rate(args, be, ctx, n_slots, views, B, batches_per_step, barrier
             "d2h_GBps": nb * B * ctx.frame_bytes / h_s / 1e9}
 
 
-def side_leg(args, backend_factory, device, np, config: int, steps: int, host_threads: int = 0):
+def side_leg(args, backend_factory, device, np, config: int, steps: int, host_threads: int = 0, front_end=None):
     """One more BASELINE configuration through the WHOLE timed path of the headline (host record generation + H2D + every kernel, frames
     left in HBM): a context of its own, one warm-up step, `steps` timed steps bracketed by waits.  Never `value`: these are the numbers the
     other configurations (and the headline with two host threads) run at, in the driver's record instead of a builder's log."""
@@ -662,6 +665,8 @@ def side_leg(args, backend_factory, device, np, config: int, steps: int, host_th
     a = copy.copy(args)
     name, a.width, a.height, a.batch, maps, camera = CONFIGS[config]
     a.config, a.host_threads, a.wad, a.synth_map = config, host_threads, None, None
+    if front_end:
+        a.front_end = front_end
     W, H, B = a.width, a.height, a.batch
     be = backend_factory(a, device)
     ctx = be.load(maps[0], 1993, camera)
@@ -703,7 +708,7 @@ def side_leg(args, backend_factory, device, np, config: int, steps: int, host_th
     ctx.close()
     names = {1: "host span lists", 2: "device column walk", 3: "device seg walk + column walk"}
     mean_r = float(np.mean(raster_ms)) / 1e3
-    return {"workload": f"BASELINE {name}, {W}x{H}, {batches_per_step} batch(es) of {B} per step" + (f", {host_threads} host threads" if host_threads else ""),
+    return {"workload": f"BASELINE {name}, {W}x{H}, {batches_per_step} batch(es) of {B} per step" + (f", {host_threads} host threads" if host_threads else "") + (f", --front-end {front_end}" if front_end else ""),
             "baseline_config": config, "steps": steps, "warmup": 1, "value": steps * batches_per_step * B / elapsed, "unit": "frames/s", "ms_per_step": elapsed / steps * 1e3,
             "raster_ms_per_batch": mean_r * 1e3, "front_end_kernels_ms_per_batch": float(np.mean(setup_ms)), "host_ms_per_batch": float(np.mean(host_ms)),
             "host_threads": getattr(ctx, "host_threads", None) or host_threads or None,
