@@ -302,3 +302,25 @@ def test_issue_roofline_from_the_committed_counters(tmp_path):
     e = json.load(open(out))["64x64x4"]
     assert (e["valu"], e["valu_paired"], e["salu"], e["vmem"], e["launches"], e["grid"]) == (1000.0, 250.0, 600.0, 34.0, 2, 8192)
     assert abs(e["clock_ghz"] - 2.0) < 1e-9                               # 2 000 cycles per CU in 1 000 ns
+
+
+def test_synth_map_runs_are_labelled_as_not_a_baseline_configuration(monkeypatch):
+    """`--synth-map SEED:COLSxROWS:THINGS` (the doom2-scale map of the GPU tier through the whole timed path) is not one of BASELINE.json's
+    configurations: the line says so in `config.workload`, carries no side legs, and the flag reaches the backend unchanged."""
+    import bench
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    args = bench.parse_args(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-resident", "--no-host-frames", "--no-latency",
+                             "--config", "3", "--synth-map", "2002:32x24:500", "--front-end", "segs"])
+    holder = {}
+
+    def factory(a, device):
+        holder["be"] = _StubBackend(a, device)
+        return holder["be"]
+    line = bench.run(args, factory)
+    assert holder["be"].args.synth_map == "2002:32x24:500"
+    assert line["config"]["workload"].startswith("NOT a BASELINE configuration: generated map 2002:32x24:500")
+    assert "synthetic IWAD 2002:32x24:500" in line["config"]["workload"] and line["side_legs"] is None
+    assert line["n_gpus"] == 1 and line["steps"] == 2
+    plain = bench.run(bench.parse_args(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-resident", "--no-host-frames", "--no-latency"]), factory)
+    assert plain["config"]["workload"].startswith("BASELINE config 3")
