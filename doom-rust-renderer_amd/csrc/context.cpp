@@ -230,7 +230,7 @@ struct dg_ctx {
     int host_samples = 0;               // batches the host walker was timed on (the first one pays for cold caches and arena growth: not counted)
     int since_probe = 0;                // seg-walk batches since the host walker was last timed (it is timed again every 32 batches)
     uint8_t *d_fs_scene = nullptr;
-    uint8_t *d_fs_scratch = nullptr;    // candidate rows F x n_segs x 5 x 8 B (zeroed per batch) | candidate lists + keep bits of frames beyond FS_CL_CAP
+    uint8_t *d_fs_scratch = nullptr;    // occupancy rows (zero between batches) | candidate rows F x n_segs x 5 x 8 B | candidate lists + keep bits of frames beyond FS_CL_CAP
     size_t fs_zero_bytes = 0;
     FsParams fs_proto{};                // scene pointers and counts, filled at upload
     uint64_t fallbacks_fe = 0;          // batches in which frames were redone because a device-side capacity was exceeded (dg_ctx_fallbacks)

@@ -6,9 +6,10 @@
 // kernels per batch (fs_kernels.hip), with the arithmetic of fs_core.h:
 //   dg_fs_segs    one lane per (frame, seg): process_seg + the tests of every process_sidedef call (transform, clip, x projection): the
 //                 columns and flags of each call that reaches its column loop, written at the seg's VISIT POSITION in the frame's
-//                 candidate row — the row then holds the frame's candidate parts in the reference's order.  The position of a seg is
-//                 that of its BSP leaf's first seg (fs_leaf_base: the sum, over the leaf's ancestors on whose BACK side it lies for
-//                 this viewer, of the seg count of the ancestor's front subtree) plus its index in the leaf;
+//                 candidate row, with the entry's bit set in the frame's occupancy row — the live entries of the row are then the
+//                 frame's candidate parts in the reference's order.  The position of a seg is that of its BSP leaf's first seg
+//                 (fs_leaf_base: the sum, over the leaf's ancestors on whose BACK side it lies for this viewer, of the seg count of the
+//                 ancestor's front subtree) plus its index in the leaf;
 //   dg_fs_frame   one workgroup per frame, the phases below: hidden-part culling of the candidates -> the frame's FePart list (built
 //                 here, for the survivors only: a tenth of the candidates);
 //                 the map objects (FeSprite), their behind-bit rows and draw sequence; the column bins; the FeFrame header —
@@ -260,7 +261,7 @@ DG_HD uint32_t fs_lane_offset(const FsShared &S, int lane) {
 }
 
 // phases 1a / 1b: the candidates of the frame, in visit order, into cl[].  Lane l owns the slice [l * per, (l + 1) * per) of the frame's
-// lite row (entries that hold no part are skipped; the order of the others is the reference's visit order).
+// candidate row, found through its words of the occupancy row (the order of the live entries is the reference's visit order).
 DG_HD void fs_ph_cand_count(const FsParams &P, FsShared &S, int f, int lane) {
     const uint32_t wpl = fs_occ_wpl(P.n_segs);
     const uint32_t *occ = P.occ + (size_t)f * wpl * FS_LANES + (size_t)lane * wpl;
@@ -347,7 +348,7 @@ DG_HD void fs_ph_keep(const FsParams &P, FsShared &S, int f, int lane) {
         if (open) fs_or_u32(&keepw[k >> 5], 1u << (k & 31u));
     });
 }
-// phases 2f / 2g: the survivors get their place in the frame's part list (and their sky event slot).  Lane l walks its slice of the lite
+// phases 2f / 2g: the survivors get their place in the frame's part list (and their sky event slot).  Lane l walks its slice of the candidate
 // row again (candidate indices from lane_k0); lane_cnt packs (survivors | survivors that want a sky slot << 16).
 DG_HD void fs_ph_kept_count(const FsParams &P, FsShared &S, int f, int lane) {
     // (flags of candidate k: cl[k] >> 24)
