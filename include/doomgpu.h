@@ -111,7 +111,7 @@ typedef struct dg_config {
  *                      dg_submit_views_state: plus one copy of the sector lights and map-object states per view).  Frames it cannot
  *                      judge (a reference panic, a per-frame capacity: 256 parts after culling, 512 map objects in view, 2 560 columns)
  *                      and maps in which a texture / flat lookup would panic fall back to DG_FE_DEVICE / DG_FE_HOST transparently.
- *                      Costs device memory per ctx: max_batch x segs x 40 B of candidate rows, plus max_batch x segs x 21 B for maps with
+ *                      Costs device memory per ctx: max_batch x segs x 41 B of candidate rows + occupancy bits, plus max_batch x segs x 21 B for maps with
  *                      more than 307 segs (candidate lists longer than shared memory holds); when that allocation fails the ctx simply
  *                      keeps the host's per-seg half (DG_FE_DEVICE).
  *   DG_FE_AUTO         DG_FE_DEVICE or DG_FE_DEVICE_SEGS per batch, whichever is the faster way for it: the GPU takes the per-seg half when
