@@ -433,9 +433,9 @@ def run(args, backend_factory=DoomGpuBackend):
     side = None
     if rank == 0 and world == 1 and not args.no_side_legs and backend_factory is DoomGpuBackend and args.config == 3 and not args.wad and not args.synth_map:
         side = {}
-        # (a config-2 step is 0.35 ms: 20 of them; config 2 a second time with the device seg walk forced: what the kernels do when DG_FE_AUTO does
-        # not spend one of the leg's 21 batches timing the host walker)
-        for key, (cfg, ht, k, fe) in {"config2": (2, 0, 20, None), "config2_seg_walk": (2, 0, 20, "segs"), "config5": (5, 0, 5, None),
+        # (a config-2 step is 0.35 ms: 40 of them; config 2 a second time with the device seg walk forced: what the kernels do when DG_FE_AUTO does
+        # not spend one of the leg's batches timing the host walker — it does that once per context, 1.2 ms against 0.3)
+        for key, (cfg, ht, k, fe) in {"config2": (2, 0, 40, None), "config2_seg_walk": (2, 0, 40, "segs"), "config5": (5, 0, 5, None),
                                       "config3_two_host_threads": (3, 2, 5, None)}.items():
             try:
                 side[key] = side_leg(args, backend_factory, device, np, cfg, k, ht, fe)
