@@ -26,6 +26,7 @@
 // Experiment builds: make variant VARIANT=x EXTRA="-D.." builds the same sources under another name (tools/ab_variants.sh compares builds
 // on one box); the kernels themselves carry no experiment switches — measured variants live as patches under tools/experiments/.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -651,20 +652,43 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
   }
 }
 
+// Which (frame, strip, segment) a workgroup renders.  Dispatch order (blockIdx) deals a frame's workgroups over all eight XCDs — blocks b and
+// b + 8 are observed to share one (MI355X_MICROARCH.md: placement is not a contract, so this is for speed only: any bijection renders the
+// same frames).  With P.frame_per_xcd the workgroups of one frame go to ONE XCD instead, the frames dealt round robin: every XCD then renders
+// whole frames — an even share of the work whatever the strips cost, where dispatch order gives an XCD the SAME few strips of every frame
+// (at 1024 columns, 16 strips: two of them) — and neighbouring strips, which sample the same wall textures and flats, find each other's
+// lines in that XCD's L2.  Measured (profiles/r05_raster_tiles.md section 5g): 1024x768 - 9.5 %, 1280x800 - 1.5 to - 2.4 %, 800x600 - 2 %;
+// 640x400 + 3 %, 320x200 + 1.5 %, 2560x1600 + 1 %; runs of 2 / 4 / 8 consecutive frames per XCD + 2 % — launch_raster asks for it between
+// 500 000 and 2 000 000 pixels.  The frames beyond the last multiple of eight keep dispatch order.
+__device__ __forceinline__ void raster_block(const RasterParams &P, uint32_t &bx, uint32_t &by, uint32_t &f) {
+    bx = blockIdx.x; by = blockIdx.y; f = blockIdx.z;
+    if (!P.frame_per_xcd) return;
+    const uint32_t gx = gridDim.x, gy = gridDim.y, pf = gx * gy;
+    const uint32_t orig = bx + gx * (by + gy * f);
+    if (orig >= ((uint32_t)P.n_frames & ~7u) * pf) return;
+    const uint32_t xcd = orig & 7u, idx = orig >> 3;                   // the idx-th workgroup of its XCD: workgroup idx % pf of that XCD's frame idx / pf
+    const uint32_t lin = ((idx / pf) * 8u + xcd) * pf + idx % pf;
+    bx = lin % gx; by = (lin / gx) % gy; f = lin / pf;
+}
+
 // (launch bounds: 8 waves per SIMD = at most 64 VGPRs; one more register costs a fourth of the resident workgroups, 0.58 -> 0.67 ms)
 // One workgroup per (frame, 64-column strip, segment of P.tile_rows_per_wg tile rows).
 __global__ __launch_bounds__(THREADS, 8) void dg_raster_tiles(RasterParams P) {
     __shared__ __attribute__((aligned(16))) TileLds L;
     const int n_tile_rows = (P.k.H + TILE_H - 1) / TILE_H;
-    const int ty_begin = (int)blockIdx.y * P.tile_rows_per_wg;
-    strip_body<true>(P, L, (int)blockIdx.z, (int)blockIdx.x * TILE_W, ty_begin, min(n_tile_rows, ty_begin + P.tile_rows_per_wg));
+    uint32_t bx, by, f;
+    raster_block(P, bx, by, f);
+    const int ty_begin = (int)by * P.tile_rows_per_wg;
+    strip_body<true>(P, L, (int)f, (int)bx * TILE_W, ty_begin, min(n_tile_rows, ty_begin + P.tile_rows_per_wg));
 }
 // The same for a frame width that is not a multiple of 4 (constants.rs:3-17 makes any width legal).
 __global__ __launch_bounds__(THREADS, 8) void dg_raster_tiles_anyw(RasterParams P) {
     __shared__ __attribute__((aligned(16))) TileLds L;
     const int n_tile_rows = (P.k.H + TILE_H - 1) / TILE_H;
-    const int ty_begin = (int)blockIdx.y * P.tile_rows_per_wg;
-    strip_body<false>(P, L, (int)blockIdx.z, (int)blockIdx.x * TILE_W, ty_begin, min(n_tile_rows, ty_begin + P.tile_rows_per_wg));
+    uint32_t bx, by, f;
+    raster_block(P, bx, by, f);
+    const int ty_begin = (int)by * P.tile_rows_per_wg;
+    strip_body<false>(P, L, (int)f, (int)bx * TILE_W, ty_begin, min(n_tile_rows, ty_begin + P.tile_rows_per_wg));
 }
 
 // Per-row constants of the flat and sky mappers for one frame size: vy = CFY - y (visplanes.rs:109), its prepared reciprocal, the
@@ -751,6 +775,9 @@ hipError_t launch_raster(const RasterParams &P_in, hipStream_t stream, hipEvent_
     RasterParams P = P_in;
     const int n_tile_rows = (P.k.H + TILE_H - 1) / TILE_H;
     if (P.tile_rows_per_wg <= 0) P.tile_rows_per_wg = raster_tile_rows_per_wg(P.k.W, P.k.H, P.n_frames);
+    const size_t pixels = (size_t)P.k.W * (size_t)P.k.H;
+    P.frame_per_xcd = pixels >= 500000 && pixels <= 2000000 ? 1 : 0;                  // (raster_block; DOOMGPU_FRAME_PER_XCD=0 / 1 overrides)
+    if (const char *e = std::getenv("DOOMGPU_FRAME_PER_XCD")) P.frame_per_xcd = std::atoi(e) != 0 ? 1 : 0;
     dim3 grid((unsigned)((P.k.W + TILE_W - 1) / TILE_W), (unsigned)((n_tile_rows + P.tile_rows_per_wg - 1) / P.tile_rows_per_wg), (unsigned)P.n_frames);
     if (P.k.W % 4 == 0) hipExtLaunchKernelGGL(dg_raster_tiles, grid, dim3(THREADS), 0, stream, start, stop, 0, P);
     else hipExtLaunchKernelGGL(dg_raster_tiles_anyw, grid, dim3(THREADS), 0, stream, start, stop, 0, P);

@@ -91,6 +91,23 @@ def test_heavy_map_bit_exact(dg, scene1994, oracle_scene1994, path1994, golden_f
     ctx.close()
 
 
+@pytest.mark.parametrize("setting", ["0", "1"], ids=["dispatch-order", "a-frame-per-xcd"])
+@pytest.mark.parametrize("W,H,n", [(1280, 800, 21), (320, 200, 67), (1283, 97, 19), (640, 400, 8)])
+def test_workgroup_to_frame_mapping_of_the_rasteriser(dg, scene1993, oracle_scene1993, path1993, monkeypatch, W, H, n, setting):
+    """dg_raster_tiles renders (frame, strip, segment) of a workgroup id that is either its dispatch order or a bijection of it that keeps a
+    frame's workgroups on one XCD (kernels.hip: raster_block; by default between 500 000 and 2 000 000 pixels): both settings forced at sizes
+    inside and outside that window, with batch sizes that are and are not multiples of eight (the frames beyond the last multiple keep dispatch order) and a
+    width that takes the byte-store read-out, every frame against the oracle."""
+    monkeypatch.setenv("DOOMGPU_FRAME_PER_XCD", setting)
+    sub = path1993[:: max(1, 1000 // n)][:n]
+    ctx = make_ctx(dg, scene1993, W, H, len(sub), slots=1, front_end=dg.DG_FE_DEVICE)
+    out = ctx.render(dg.make_views(sub))
+    for k, rec in enumerate(sub):
+        ref = np.frombuffer(oracle_scene1993.render(W, H, rec), dtype=np.uint8).reshape(H, W, 3)
+        assert np.array_equal(out[k], ref), f"{W}x{H}, setting {setting}, frame {k}"
+    ctx.close()
+
+
 @pytest.mark.parametrize("front_end", [1, 2, 3], ids=["host-lists", "device-column-walk", "device-seg-walk"])
 def test_vanilla_shaped_map_bit_exact(dg, wad1995, oracle_scene1995, path1995, golden_frames, front_end):
     """Seed 1995 — arbitrary integer vertices and wall angles, rounded BSP splits, closed doors (segs.rs:222-225), thing angles in
