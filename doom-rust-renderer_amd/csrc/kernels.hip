@@ -667,8 +667,12 @@ __device__ __forceinline__ void raster_block(const RasterParams &P, uint32_t &bx
     const uint32_t orig = bx + gx * (by + gy * f);
     if (orig >= ((uint32_t)P.n_frames & ~7u) * pf) return;
     const uint32_t xcd = orig & 7u, idx = orig >> 3;                   // the idx-th workgroup of its XCD: workgroup idx % pf of that XCD's frame idx / pf
-    const uint32_t lin = ((idx / pf) * 8u + xcd) * pf + idx % pf;
-    bx = lin % gx; by = (lin / gx) % gy; f = lin / pf;
+    // (the two divisions as multiplications by launch_raster's reciprocals — exact for these ranges: a u32 division by a run-time value
+    // is two dozen instructions per wave, and there are eight waves per workgroup)
+    const uint32_t j = __umulhi(idx, P.xcd_rcp_pf), w = idx - j * pf;
+    f = j * 8u + xcd;
+    by = __umulhi(w, P.xcd_rcp_gx);
+    bx = w - by * gx;
 }
 
 // (launch bounds: 8 waves per SIMD = at most 64 VGPRs; one more register costs a fourth of the resident workgroups, 0.58 -> 0.67 ms)
@@ -775,10 +779,15 @@ hipError_t launch_raster(const RasterParams &P_in, hipStream_t stream, hipEvent_
     RasterParams P = P_in;
     const int n_tile_rows = (P.k.H + TILE_H - 1) / TILE_H;
     if (P.tile_rows_per_wg <= 0) P.tile_rows_per_wg = raster_tile_rows_per_wg(P.k.W, P.k.H, P.n_frames);
+    dim3 grid((unsigned)((P.k.W + TILE_W - 1) / TILE_W), (unsigned)((n_tile_rows + P.tile_rows_per_wg - 1) / P.tile_rows_per_wg), (unsigned)P.n_frames);
     const size_t pixels = (size_t)P.k.W * (size_t)P.k.H;
     P.frame_per_xcd = pixels >= 500000 && pixels <= 2000000 ? 1 : 0;                  // (raster_block; DOOMGPU_FRAME_PER_XCD=0 / 1 overrides)
     if (const char *e = std::getenv("DOOMGPU_FRAME_PER_XCD")) P.frame_per_xcd = std::atoi(e) != 0 ? 1 : 0;
-    dim3 grid((unsigned)((P.k.W + TILE_W - 1) / TILE_W), (unsigned)((n_tile_rows + P.tile_rows_per_wg - 1) / P.tile_rows_per_wg), (unsigned)P.n_frames);
+    {   // n / d = (n * (2^32 / d + 1)) >> 32 for n * d < 2^32: asked of n < workgroups of the launch, d = workgroups per frame / strips per frame
+        const uint64_t gx = grid.x, pf = (uint64_t)grid.x * grid.y, total = pf * grid.z;
+        if (gx < 2 || total * pf >= (1ull << 32)) P.frame_per_xcd = 0;
+        else { P.xcd_rcp_pf = (uint32_t)((1ull << 32) / pf + 1); P.xcd_rcp_gx = (uint32_t)((1ull << 32) / gx + 1); }
+    }
     if (P.k.W % 4 == 0) hipExtLaunchKernelGGL(dg_raster_tiles, grid, dim3(THREADS), 0, stream, start, stop, 0, P);
     else hipExtLaunchKernelGGL(dg_raster_tiles_anyw, grid, dim3(THREADS), 0, stream, start, stop, 0, P);
     return hipGetLastError();

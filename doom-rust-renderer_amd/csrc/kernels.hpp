@@ -19,7 +19,8 @@ struct RasterParams {
     uint8_t *fb;                 // n_frames x 3*W*H, RGB24
     const uint4 *row_tab;        // [H] per screen row: prepared 1 / vy, vy = CFY - y, sky row | fast-divide bit, sky factor (dg_row_table, kernels.hip)
     int32_t n_frames;
-    int32_t frame_per_xcd;       // the workgroups of a frame on one XCD (kernels.hip: raster_block); set by launch_raster
+    int32_t frame_per_xcd;       // the workgroups of a frame on one XCD (kernels.hip: raster_block); set by launch_raster, like the two
+    uint32_t xcd_rcp_pf, xcd_rcp_gx;   // reciprocals it divides by (workgroups per frame, strips per frame)
     int32_t tile_rows_per_wg;    // tile rows one workgroup of dg_raster_tiles renders out of one staging pass; <= 0: launch_raster picks
 };
 
