@@ -662,10 +662,10 @@ __device__ __forceinline__ void strip_body(const RasterParams &P, TileLds &L, in
 // whole frames — an even share of the work whatever the strips cost, where dispatch order gives an XCD the SAME few strips of every frame
 // (at 1024 columns, 16 strips: two of them) — and neighbouring strips, which sample the same wall textures and flats, find each other's
 // lines in that XCD's L2 (a strip's two segments read the same span records: once from HBM instead of twice).  Measured, 1 000-frame batches
-// (profiles/r05_raster_tiles.md section 5g), with the non-temporal frame stores of the read-out: 1024x768 - 7 %, 320x200 - 2 %, 800x600 - 4 %,
-// 1280x800 and 640x400 0 (before those stores, when the written frame still pushed spans and texels out of the L2: - 2.4 %), 2560x1600
-// + 2 % — there a frame is more workgroups (160) than an XCD holds (128), and launch_raster keeps dispatch order.  Runs of 2 / 4 / 8
-// consecutive frames per XCD + 2 %.  The frames beyond the last multiple of eight keep dispatch order.
+// (profiles/r05_raster_tiles.md sections 5g, 5i), with the non-temporal frame stores of the read-out: 1024x768 - 7 %, 800x600 - 4 %,
+// 320x200 - 2 %, 1280x800 and 640x400 0 (before those stores, when the written frame still pushed spans and texels out of the L2: - 2.4 %),
+// 1920x1080 + 1 %, 2560x1600 + 3 to + 6 % — launch_raster asks for it up to 1.1 M pixels.  Runs of 2 / 4 / 8 consecutive frames per XCD
+// + 2 %.  The frames beyond the last multiple of eight keep dispatch order.
 __device__ __forceinline__ void raster_block(const RasterParams &P, uint32_t &bx, uint32_t &by, uint32_t &f) {
     bx = blockIdx.x; by = blockIdx.y; f = blockIdx.z;
     if (!P.frame_per_xcd) return;
@@ -786,7 +786,7 @@ hipError_t launch_raster(const RasterParams &P_in, hipStream_t stream, hipEvent_
     const int n_tile_rows = (P.k.H + TILE_H - 1) / TILE_H;
     if (P.tile_rows_per_wg <= 0) P.tile_rows_per_wg = raster_tile_rows_per_wg(P.k.W, P.k.H, P.n_frames);
     dim3 grid((unsigned)((P.k.W + TILE_W - 1) / TILE_W), (unsigned)((n_tile_rows + P.tile_rows_per_wg - 1) / P.tile_rows_per_wg), (unsigned)P.n_frames);
-    P.frame_per_xcd = (uint64_t)grid.x * grid.y <= 128 ? 1 : 0;                       // (raster_block: a frame that fits the 32 CUs x 4 workgroups of an XCD; DOOMGPU_FRAME_PER_XCD=0 / 1 overrides)
+    P.frame_per_xcd = (size_t)P.k.W * (size_t)P.k.H <= 1100000 ? 1 : 0;               // (raster_block; DOOMGPU_FRAME_PER_XCD=0 / 1 overrides)
     if (const char *e = std::getenv("DOOMGPU_FRAME_PER_XCD")) P.frame_per_xcd = std::atoi(e) != 0 ? 1 : 0;
     {   // n / d = (n * (2^32 / d + 1)) >> 32 for n * d < 2^32: asked of n < workgroups of the launch, d = workgroups per frame / strips per frame
         const uint64_t gx = grid.x, pf = (uint64_t)grid.x * grid.y, total = pf * grid.z;

@@ -95,7 +95,7 @@ def test_heavy_map_bit_exact(dg, scene1994, oracle_scene1994, path1994, golden_f
 @pytest.mark.parametrize("W,H,n", [(1280, 800, 21), (320, 200, 67), (1283, 97, 19), (640, 400, 8)])
 def test_workgroup_to_frame_mapping_of_the_rasteriser(dg, scene1993, oracle_scene1993, path1993, monkeypatch, W, H, n, setting):
     """dg_raster_tiles renders (frame, strip, segment) of a workgroup id that is either its dispatch order or a bijection of it that keeps a
-    frame's workgroups on one XCD (kernels.hip: raster_block; the default for frames of up to 128 workgroups): both settings forced at four sizes, with batch sizes that are and are not multiples of eight (the frames beyond the last multiple keep dispatch order) and a
+    frame's workgroups on one XCD (kernels.hip: raster_block; the default for frames of up to 1.1 M pixels): both settings forced at four sizes, with batch sizes that are and are not multiples of eight (the frames beyond the last multiple keep dispatch order) and a
     width that takes the byte-store read-out, every frame against the oracle."""
     monkeypatch.setenv("DOOMGPU_FRAME_PER_XCD", setting)
     sub = path1993[:: max(1, 1000 // n)][:n]
