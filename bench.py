@@ -341,6 +341,15 @@ def run(args, backend_factory=DoomGpuBackend):
 
     # ---- the headline: warmup, then exactly K timed steps ------------------------------------------------------------
     ctx_ran = [False] * n_slots
+    # The GPU's clocks first: an MI355X that has been idle for even 10 ms renders its next launches 15-20 % slower and takes ~25 ms of
+    # continuous work to be back at speed (tests/manual/gpu_warmup_probe.py: dg_raster_tiles 1.88, 1.97, 1.85, ... 1.62 ms over 14 launches,
+    # after a cold start and after every pause alike) — W = 2 warm-up steps are 4 ms.  So, before the W warm-up steps of the contract, the
+    # same steps run untimed until --clock-warmup-ms have passed (reported as `gpu_clock_warmup`); the K timed steps then measure the
+    # renderer, not the power management's ramp.
+    clock_warm_steps, t_warm = 0, time.perf_counter()
+    while (time.perf_counter() - t_warm) * 1e3 < args.clock_warmup_ms:
+        one_pass()
+        clock_warm_steps += 1
     for _ in range(args.warmup):
         one_pass()
     sync_all()
@@ -485,6 +494,8 @@ def run(args, backend_factory=DoomGpuBackend):
             "ms_per_step_first": float(step_ms[0]), "ms_per_step_last": float(step_ms[-1]),
             "gpu_ms_per_batch": {"median": float(np.median(np.add(raster_ms, setup_ms))), "min": float(np.min(np.add(raster_ms, setup_ms))),
                                  "max": float(np.max(np.add(raster_ms, setup_ms))), "what": "front-end kernels + raster launch of each timed batch (HIP events on the kernel stream)"},
+            "gpu_clock_warmup": {"ms": args.clock_warmup_ms, "steps": clock_warm_steps,
+                                 "why": "untimed steps before the warm-up steps: after any idle the GPU needs ~25 ms of work to reach its clocks (tests/manual/gpu_warmup_probe.py)"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "file" if args.wad else "synthetic",
             "config": {"workload": (f"NOT a BASELINE configuration: generated map {args.synth_map} (seed:rooms:things, heavy + vanilla) at the size of " if args.synth_map and not args.wad else "BASELINE ") +
                                    f"{CONFIGS[args.config][0]}; " +
@@ -693,6 +704,9 @@ def side_leg(args, backend_factory, device, np, config: int, steps: int, host_th
         return g0 + batches_per_step
 
     g = one_pass(0, False)
+    t_warm = time.perf_counter()                      # (the GPU's clocks, as in run(): untimed steps for --clock-warmup-ms)
+    while (time.perf_counter() - t_warm) * 1e3 < getattr(args, "clock_warmup_ms", 0.0):
+        g = one_pass(g, False)
     for s in range(n_slots):
         ctx.wait(s)
     t0 = time.perf_counter()
@@ -751,6 +765,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clock-warmup-ms", type=float, default=60.0, help="untimed steps run for this long before the --warmup steps, so that the GPU's clocks "
+                                                                         "are up when the timed steps start (0: none)")
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=3, help="BASELINE.json configuration (1-based); sets width / height / batch / maps")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)

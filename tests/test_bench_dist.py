@@ -77,7 +77,7 @@ def _worker(rank, world, port, q):
     dist.barrier()
     slow = bench.dist_max(0.5 + rank, dist)            # rank 1 is the slow one
     # bench.run end to end (rank plan, CPU binding, barriers, timed steps, MAX over ranks, report gather) on a stub context
-    args = bench.parse_args(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch", "250", "--config", "4"])
+    args = bench.parse_args(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch", "250", "--config", "4", "--clock-warmup-ms", "0"])
     holder = {}
 
     def factory(a, device):
@@ -322,5 +322,8 @@ def test_synth_map_runs_are_labelled_as_not_a_baseline_configuration(monkeypatch
     assert line["config"]["workload"].startswith("NOT a BASELINE configuration: generated map 2002:32x24:500")
     assert "synthetic IWAD 2002:32x24:500" in line["config"]["workload"] and line["side_legs"] is None
     assert line["n_gpus"] == 1 and line["steps"] == 2
+    # the GPU-clock warm-up: untimed steps before the W warm-up steps, for the time asked, reported in the line; the K timed steps stay K
+    assert line["gpu_clock_warmup"]["ms"] == 60.0 and line["gpu_clock_warmup"]["steps"] >= 1
+    assert holder["be"].ctx.submits == (line["gpu_clock_warmup"]["steps"] + 1 + 2) * 1          # one 1 000-frame batch per step: clock warm-up + W + K
     plain = bench.run(bench.parse_args(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-resident", "--no-host-frames", "--no-latency"]), factory)
     assert plain["config"]["workload"].startswith("BASELINE config 3")
