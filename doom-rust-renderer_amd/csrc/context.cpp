@@ -229,6 +229,8 @@ struct dg_ctx {
     double ema_host = -1.0, ema_gpu_dev = -1.0, ema_gpu_fs = -1.0;
     int host_samples = 0;               // batches the host walker was timed on (the first one pays for cold caches and arena growth: not counted)
     int since_probe = 0;                // seg-walk batches since the host walker was last timed (it is timed again every 32 batches)
+    int since_fs_probe = 0;             // host-walker batches since the seg walk was last timed (likewise)
+    int gpu_samples[2] = {0, 0};        // finished batches seen per mode (host per-seg half / seg walk): the first of each runs on cold caches and clocks, not counted
     uint8_t *d_fs_scene = nullptr;
     uint8_t *d_fs_scratch = nullptr;    // occupancy rows (zero between batches) | candidate rows F x n_segs x 5 x 8 B | candidate lists + keep bits of frames beyond FS_CL_CAP
     size_t fs_zero_bytes = 0;
@@ -602,11 +604,14 @@ bool choose_fs(dg_ctx *c, const dg_view *views, int n) {
     bool in_flight = false;
     for (Slot &s : c->slots) { harvest_gpu_time(c, s); in_flight |= s.busy; }
     if (!in_flight) return true;
-    bool fs = c->ema_gpu_fs < 0.0 ? (c->ema_gpu_dev > 0.0 && c->ema_host > c->ema_gpu_dev)   // host slower than the GPU's own share: try the seg walk
-                                  : c->ema_host > c->ema_gpu_fs;
-    // time the host walker again now and then (its speed depends on who else uses the CPUs); rarely when it was far behind
+    // No seg-walk batch timed yet: the GPU keeps the per-seg half until one has been (it costs the GPU ~0.1 ms per 1 000 frames; a batch on a
+    // host that turns out to be the slower side costs the pipeline a millisecond).  From then on: whoever is the slower side of the pipeline.
+    bool fs = c->ema_gpu_fs < 0.0 ? true : c->ema_host > c->ema_gpu_fs;
+    // time the other side again now and then (the host's speed depends on who else uses the CPUs, the first seg-walk samples may have been
+    // taken on a cold GPU); the host rarely when it was far behind
     if (fs && ++c->since_probe >= (c->ema_gpu_fs > 0.0 && c->ema_host > 2.0 * c->ema_gpu_fs ? 256 : 32)) fs = false;
-    if (!fs) c->since_probe = 0;
+    else if (!fs && ++c->since_fs_probe >= 32) fs = true;
+    if (!fs) c->since_probe = 0; else c->since_fs_probe = 0;
     return fs;
 }
 
@@ -908,6 +913,7 @@ void harvest_gpu_time(dg_ctx *c, Slot &s) {
         ms = std::max(fe_ms, r_ms);                        // (they overlap with the neighbouring batches': the longer one sets the pace)
         if (!(ms > 0.0f)) return;
     } else if (hipEventElapsedTime(&ms, s.ev_start, s.ev_raster) != hipSuccess || !(ms > 0.0f)) return;
+    if (c->gpu_samples[s.fs_mode ? 1 : 0]++ == 0) return;  // (the first batch of a mode: cold caches, code not yet resident, clocks down — a seg walk judged by it alone was never tried again)
     double &ema = s.fs_mode ? c->ema_gpu_fs : c->ema_gpu_dev;
     const double v = (double)ms / s.n_frames;
     ema = ema < 0.0 ? v : 0.75 * ema + 0.25 * v;
