@@ -26,6 +26,10 @@ torch.distributed (gloo, CPU tensors) is used only for the timing barrier, the M
 report; value = sum of frames / max time (weak scaling).  Each rank pins its host threads to its share of the CPUs
 (the NUMA node of its GPU when the topology is readable) before anything touches HIP.
 
+GPU clocks: before the W warm-up steps the same steps run untimed for --clock-warmup-ms (60): an MI355X that has been idle for 10 ms
+renders its next launches 15-20 % slower and needs ~25 ms of work to be back at speed (tests/manual/gpu_warmup_probe.py); the line says
+so (`gpu_clock_warmup`).  The K timed steps are exactly K, bracketed as the contract says.
+
 roofline: the dominant kernel, dg_raster_tiles (one launch per batch), HBM-bound model.  achieved = algorithmic bytes per launch / mean duration from HIP events recorded on the kernel's own stream during the
 timed steps (dg_slot_timing).  Algorithmic bytes per frame = 3*W*H (RGB24 stored
 once) + W*H (one texel byte per pixel) + list bytes read (32 B per span, 4*(W+1) column index) — SURVEY.md §8d,
