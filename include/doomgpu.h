@@ -115,7 +115,7 @@ typedef struct dg_config {
  *                      more than 307 segs (candidate lists longer than shared memory holds); when that allocation fails the ctx simply
  *                      keeps the host's per-seg half (DG_FE_DEVICE).
  *   DG_FE_AUTO         DG_FE_DEVICE or DG_FE_DEVICE_SEGS per batch, whichever is the faster way for it: the GPU takes the per-seg half when
- *                      nothing is in flight (the host's time would be exposed) or when the host has been measured to be the slower
+ *                      nothing is in flight (the host's time would be exposed), until a seg-walk batch has been timed, or when the host has been measured to be the slower
  *                      side (few host threads, small frames); batches of fewer than 64 views always use the host walker.  The pixels
  *                      are the same whichever is picked; dg_timing.front_end says which one it was.  The choice rests on wall-clock
  *                      measurements (host time per view, kernel time of finished batches): which front end — and therefore which
