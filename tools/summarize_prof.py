@@ -7,6 +7,16 @@ import os as _os
 ks = sorted(glob.glob(base + "/trace/*/*_kernel_stats.csv"), key=_os.path.getmtime)
 if ks:
     out.append("## --kernel-trace --stats (kernel_stats.csv)\n```\n" + open(ks[-1]).read() + "```\n")
+# dg_raster_tiles launch by launch (kernel_trace.csv): bench.py's untimed clock warm-up and warm-up steps come first, its timed steps last —
+# the stats above average over all of them, the GPU's clock ramp included
+kt = sorted(glob.glob(base + "/trace/*/*_kernel_trace.csv"), key=_os.path.getmtime)
+if kt:
+    rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(kt[-1])) if "dg_raster_tiles" in r["Kernel_Name"])
+    d = [x[1] / 1e6 for x in rows]
+    if d:
+        last = d[-20:]
+        out.append("## dg_raster_tiles launch by launch (kernel_trace.csv, ms, in launch order)\n```\n" + " ".join(f"{x:.3f}" for x in d) + "\n```\n"
+                   f"all {len(d)} launches: mean {sum(d)/len(d):.4f} ms; the last {len(last)} (bench.py's timed steps): **mean {sum(last)/len(last):.4f} ms**, min {min(last):.4f}, max {max(last):.4f}\n\n")
 out.append("## PMC passes (separate runs, mean per dispatch)\n```\n")
 import os
 latest = {}
