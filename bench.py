@@ -350,9 +350,9 @@ def run(args, backend_factory=DoomGpuBackend):
     # after a cold start and after every pause alike) — W = 2 warm-up steps are 4 ms.  So, before the W warm-up steps of the contract, the
     # same steps run untimed until --clock-warmup-ms have passed (reported as `gpu_clock_warmup`); the K timed steps then measure the
     # renderer, not the power management's ramp.
-    clock_warm_steps, t_warm = 0, time.perf_counter()
+    clock_warm_steps, t_warm, warm_raster_ms = 0, time.perf_counter(), []
     while (time.perf_counter() - t_warm) * 1e3 < args.clock_warmup_ms:
-        one_pass()
+        one_pass(lambda slot: warm_raster_ms.append(round(ctx.timing(slot)["raster_ms"], 3)))     # (the ramp itself goes into the line: the evidence)
         clock_warm_steps += 1
     for _ in range(args.warmup):
         one_pass()
@@ -498,7 +498,7 @@ def run(args, backend_factory=DoomGpuBackend):
             "ms_per_step_first": float(step_ms[0]), "ms_per_step_last": float(step_ms[-1]),
             "gpu_ms_per_batch": {"median": float(np.median(np.add(raster_ms, setup_ms))), "min": float(np.min(np.add(raster_ms, setup_ms))),
                                  "max": float(np.max(np.add(raster_ms, setup_ms))), "what": "front-end kernels + raster launch of each timed batch (HIP events on the kernel stream)"},
-            "gpu_clock_warmup": {"ms": args.clock_warmup_ms, "steps": clock_warm_steps,
+            "gpu_clock_warmup": {"ms": args.clock_warmup_ms, "steps": clock_warm_steps, "raster_ms_of_its_launches": warm_raster_ms[:24],
                                  "why": "untimed steps before the warm-up steps: after any idle the GPU needs ~25 ms of work to reach its clocks (tests/manual/gpu_warmup_probe.py)"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "file" if args.wad else "synthetic",
             "config": {"workload": (f"NOT a BASELINE configuration: generated map {args.synth_map} (seed:rooms:things, heavy + vanilla) at the size of " if args.synth_map and not args.wad else "BASELINE ") +
